@@ -1,0 +1,170 @@
+"""bench.py — prefill tokens/s/node of the Long-VITA hot path on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W
+    (N > 1: python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...)
+
+One "step" = one full prefill of the BASELINE.json metric's configuration: Long-VITA-128K —
+a 506-frame synthetic video through InternViT-300M + pixel-shuffle projector, visual-token
+scatter, the 48-layer 14B decoder at sequence 131072 and the logits-masked LM head producing the
+next-token logits (one iteration of the reference's decode loop,
+M/inference/text_generation/generation.py:123-205).  Context parallelism CP = N (zig-zag), TP = 1,
+total work fixed as N grows ("strong" scaling).  Synthetic data, seeded random bf16 weights of
+the real architecture; inputs are resident in HBM before the timed region.
+
+Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+  roofline      dominant kernel = flash-attention forward: algorithmic FLOPs per launch
+                (4*d*heads*visible (q,k) pairs on this rank) / mean launch time measured live with
+                HIP events on the launch stream, against the 2.5 PFLOP/s dense bf16 MFMA peak;
+  cpu_baseline  the CPU oracle ("port") timed on this host: a bounded sample of the same decoder.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+import torch  # noqa: E402
+import torch.distributed as dist  # noqa: E402
+
+MFMA_BF16_PEAK_TFLOPS = 2500.0        # MI355X dense bf16 (MI355X_MICROARCH.md)
+
+
+def flops_per_token(seq, frames, cfg, vcfg):
+    """algorithmic FLOPs of one prefill / seq."""
+    lin = cfg.num_layers * 2 * (cfg.hidden * cfg.qkv_out + cfg.hidden * cfg.heads * cfg.head_dim
+                                + cfg.hidden * 2 * cfg.ffn + cfg.ffn * cfg.hidden) * seq
+    attn = cfg.num_layers * 4 * cfg.head_dim * cfg.heads * (seq * (seq + 1) // 2)
+    s_v = vcfg.grid ** 2 + 1
+    vit_frame = (vcfg.num_layers * (2 * s_v * (vcfg.hidden * 3 * vcfg.hidden + vcfg.hidden * vcfg.hidden
+                                               + 2 * vcfg.hidden * vcfg.ffn) + 4 * s_v * s_v * vcfg.hidden)
+                 + 2 * vcfg.grid ** 2 * 588 * vcfg.hidden
+                 + 256 * 2 * (4 * vcfg.hidden * vcfg.hidden + vcfg.hidden * vcfg.llm_hidden))
+    head = 2 * cfg.hidden * cfg.vocab
+    return (lin + attn + frames * vit_frame + head) / seq
+
+
+def cpu_baseline(cores_hint=None):
+    """Oracle decoder on the host cores: 2 full-width layers (hidden 5120, 40/8 heads, ffn 13824)
+    at S = 2048, bf16-rounded weights, fp32 matmuls; extrapolated linearly to 48 layers."""
+    from oracle import glue, llm as ollm
+    from oracle.attention import core_attention
+    S, L = 2048, 2
+    cfg = ollm.LLMConfig(num_layers=L, vocab=64)
+    p = ollm.init_llm_params(cfg, seed=1)
+    h = (torch.randn(S, 1, cfg.hidden, generator=torch.Generator().manual_seed(0)) * 0.5).bfloat16()
+    freqs = glue.rope_emb(S, glue.rope_inv_freq(cfg.head_dim, cfg.rope_theta))
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        for lp in p["layers"]:
+            h, _ = ollm.decoder_layer(h, lp, cfg, freqs, lambda q, k, v: core_attention(q, k, v, causal=True))
+    dt = time.perf_counter() - t0
+    per_layer = dt / L
+    return {"value": S / (per_layer * 48), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{L} of 48 full-width decoder layers at S={S} (oracle.llm.decoder_layer, text-only, ViT and "
+                      f"LM head excluded) took {dt:.1f} s; tokens/s = S / (48 x per-layer time), linear extrapolation"}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--seq", type=int, default=131072, help="debug only; the metric is quoted at 131072")
+    ap.add_argument("--layers", type=int, default=48, help="debug only; the metric needs all 48 layers")
+    ap.add_argument("--vit-layers", type=int, default=24, help="debug only")
+    ap.add_argument("--frames", type=int, default=-1, help="debug only; default fills the sequence (506 @128K)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world != args.gpus:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
+    torch.cuda.set_device(local_rank)
+    dev = f"cuda:{local_rank}"
+    if world > 1:
+        dist.init_process_group("nccl", device_id=torch.device(dev))
+
+    from long_vita_amd import generation, gpt_vl_model, lib, parallel_state as mpu, synthetic, vision
+    lib.load(allow_build=False)                      # the HIP path or nothing
+    mpu.initialize_model_parallel()
+
+    cfg = gpt_vl_model.GPTConfig(num_layers=args.layers)
+    vcfg = vision.VisionConfig(num_layers=args.vit_layers)
+    seq = args.seq
+    frames = synthetic.frames_for_seq(seq, tail_text=512) if args.frames < 0 else args.frames
+    vit = vision.MegatronVisionModel.random_init(vcfg, seed=4321, device=dev)
+    model = gpt_vl_model.GPTVLModel.random_init(cfg, seed=1234, device=dev, external_feature_model=vit)
+    tokens, ext = synthetic.make_request(seq, frames, seed=1234, device=dev)
+    torch.cuda.synchronize()
+
+    def step():
+        return generation.prefill_step(model, tokens, seq, ext, reference_compat=False)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        step()
+    model.attn_events = []
+    fence()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        out = step()
+    fence()
+    dt = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([dt], dtype=torch.float64, device=dev)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    assert torch.isfinite(out.float()).all()
+
+    # dominant kernel: flash attention forward, one launch per layer per step on this rank
+    ev_ms = [a.elapsed_time(b) for a, b in model.attn_events]
+    attn_ms = sum(ev_ms) / max(len(ev_ms), 1)
+    pairs = seq * (seq + 1) // 2 / world
+    attn_flops = 4 * cfg.head_dim * cfg.heads * pairs
+    achieved = attn_flops / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
+
+    ms_per_step = dt / args.steps * 1e3
+    value = seq / (dt / args.steps)
+    fpt = flops_per_token(seq, frames, cfg, vcfg)
+    line = {
+        "metric": "prefill tokens/sec/node (ViT+LLM) at seq=128K",
+        "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
+        "dtype": "bf16", "data": "synthetic",
+        "config": {"workload": f"Long-VITA-128K prefill: {frames}-frame synthetic video (InternViT-300M + projector) + "
+                               f"Qwen2.5-14B decoder ({cfg.num_layers} layers), seq {seq}, logits-masked LM head",
+                   "seq_len": seq, "frames": frames, "global_batch": 1, "parallelism": f"cp{world}",
+                   "weights": "seeded random bf16 (N(0,0.02))",
+                   "algorithmic_gflop_per_token": fpt / 1e9,
+                   "end_to_end_tflops_per_gpu": fpt * value / world / 1e12,
+                   "end_to_end_frac_of_mfma_peak": fpt * value / world / 1e12 / MFMA_BF16_PEAK_TFLOPS},
+        "roofline": {"bound": "mfma", "kernel": "flash_fwd_kernel<128, causal>", "achieved": achieved,
+                     "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
+                     "traffic": None, "launches_timed": len(ev_ms), "ms_per_launch": attn_ms,
+                     "flop_per_launch": attn_flops},
+    }
+    if rank == 0:
+        if world == 1 and not args.no_cpu_baseline:
+            line["cpu_baseline"] = cpu_baseline()
+        else:
+            line["cpu_baseline"] = None
+        print(json.dumps(line), flush=True)
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,215 @@
+/*
+ * vita_hip.h — C ABI of libvita_hip.so, the MI355X (gfx950) hot path of Long-VITA prefill.
+ *
+ * The reference (VITA-MLLM/Long-VITA) contains no native code: every kernel on this path is
+ * reached from Python through a third-party package (flash_attn, transformer_engine, apex,
+ * cuBLAS via torch.matmul).  Each entry point below therefore cites the *Python call site* of
+ * the reference that it replaces (R/ = /root/reference, M/ = R/long_vita_megatron,
+ * H/ = R/long_vita).  A reference-side binding is a ctypes stub.
+ *
+ * Conventions
+ *   - plain pointers and sizes only; all pointers are DEVICE pointers unless noted;
+ *   - activations / weights are bf16 (uint16 bit pattern), indices int64, statistics fp32;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*); nothing is
+ *     allocated, retained or freed by the library;
+ *   - return value: VITA_OK (0) or a negative VITA_ERR_* code; no C++ exception crosses the ABI.
+ */
+#ifndef VITA_HIP_H
+#define VITA_HIP_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define VITA_OK 0
+#define VITA_ERR_INVALID_ARG (-1)   /* null pointer, non-positive size, bad enum                */
+#define VITA_ERR_UNSUPPORTED (-2)   /* shape outside what the gfx950 kernels are built for      */
+#define VITA_ERR_LAUNCH (-3)        /* hipGetLastError() != hipSuccess after the launch          */
+
+/* ABI version; bump on any signature change. */
+int vita_abi_version(void);
+/* Human-readable text for a VITA_ERR_* code (static storage). */
+const char* vita_error_string(int code);
+
+/* ---------------------------------------------------------------------------------------------
+ * RMSNorm forward.   y = (x.float() * rsqrt(mean(x^2) + eps)).to(bf16) * w        [rows, cols]
+ * Replaces M/core/transformer/custom_layers/transformer_engine.py:74-79 (RMSNorm._norm/forward;
+ * the TE-fused equivalent on GPU, M/core/models/gpt/gpt_layer_specs.py:39).
+ * rstd_out (fp32 [rows]) may be NULL; when given it holds rsqrt(mean(x^2)+eps) per row.
+ * ------------------------------------------------------------------------------------------- */
+int vita_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd_out,
+                     int64_t rows, int cols, float eps, void* stream);
+
+/* LayerNorm forward (biased variance, fp32 statistics), bf16 in/out.
+ * Replaces torch.nn.LayerNorm at M/core/models/vision/vit_layer_specs.py (ViT block norms,
+ * eps 1e-6) and M/pretrain_long_vita.py:443-446 (projector pre-norm, eps 1e-5). */
+int vita_layernorm_fwd(const void* x, const void* w, const void* b, void* y,
+                       int64_t rows, int cols, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * RoPE.  Replaces M/core/models/common/embeddings/rotary_pos_embedding.py:84-122 (table),
+ * :181-204 (apply_rotary_pos_emb_bshd) and apex fused_apply_rotary_pos_emb (:248-252).
+ *
+ * vita_rope_table: cos/sin tables, bf16 [n, dim/2], for integer positions pos[n] (int64):
+ *   freqs = float(pos) * inv_freq[i]  (fp32, like torch.outer),  cos/sin in fp32, cast to bf16
+ *   (rotary_pos_embedding.py:200-201 casts cos_/sin_ to t.dtype).  Positions are the *global*
+ *   token positions of the local rows, i.e. the zig-zag slice of :36-47 is an index choice.
+ * ------------------------------------------------------------------------------------------- */
+int vita_rope_table(const int64_t* pos, const float* inv_freq, void* cos_out, void* sin_out,
+                    int64_t n, int half_dim, void* stream);
+
+/* In-place RoPE on a strided [rows, heads, head_dim] bf16 view (non-interleaved halves):
+ *   t = bf16(bf16(t*cos) + bf16(rotate_half(t)*sin))   — the rounding chain of :203.
+ * row_stride / head_stride in elements.  sign = +1 forward, -1 backward (transpose rotation). */
+int vita_rope_apply(void* t, int64_t rows, int heads, int head_dim,
+                    int64_t row_stride, int64_t head_stride,
+                    const void* cos_tab, const void* sin_tab, int sign, void* stream);
+
+/* Fused RoPE over Megatron's mixed QKV activation [rows, groups, (qpg + 2) * d]
+ * (layout: L/core/models/vision/intern_vit_model.py:145-197; weights R/tools/hf2mcore_long_vita.py:597-609):
+ * rotates the qpg query heads and the key head of every group in place and, when kv_out != NULL,
+ * also packs rotated K and V into kv_out = [2][rows][groups][d] (the all-gather send buffer of
+ * the context-parallel attention). */
+int vita_rope_qkv_fwd(void* mixed_qkv, int64_t rows, int groups, int q_per_group, int head_dim,
+                      const void* cos_tab, const void* sin_tab, void* kv_out, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Row gather / scatter with int64 indices (bit-exact data movement).
+ * Replaces: VocabParallelEmbedding lookup M/core/tensor_parallel/layers.py:216-232;
+ *           visual-token scatter M/core/models/common/embeddings/language_model_embedding.py:123,126,131;
+ *           masked_select / masked_scatter of the logits-masked head M/core/tensor_parallel/layers.py:348,407,451,455.
+ *   gather : dst[i, :] = src[idx[i], :]            i in [0, n)
+ *   scatter: dst[dst_idx[i], :] = src[src_idx ? src_idx[i] : i, :]
+ * Out-of-range indices set *err_flag (int32 device word, may be NULL) to 1 and are skipped.
+ * ------------------------------------------------------------------------------------------- */
+int vita_row_gather(const void* src, int64_t src_rows, const int64_t* idx, void* dst,
+                    int64_t n, int cols, int elem_bytes, int* err_flag, void* stream);
+int vita_row_scatter(const void* src, int64_t src_rows, const int64_t* src_idx,
+                     void* dst, int64_t dst_rows, const int64_t* dst_idx,
+                     int64_t n, int cols, int elem_bytes, int* err_flag, void* stream);
+
+/* Ordered compaction of a boolean mask: idx_out[k] = position of the k-th true entry,
+ * *count_out = number of true entries (device int64).  This is the index form of
+ * torch.masked_select (layers.py:348,407).  n <= 2^31. */
+int vita_mask_to_index(const uint8_t* mask, int64_t n, int64_t* idx_out, int64_t* count_out,
+                       void* stream);
+
+/* Zig-zag context-parallel index remap, the integer arithmetic of
+ * M/training/utils.py:279-325,347-350 (get_batch_on_this_cp_rank + index_of_a_in_b):
+ *   indices_s [n_img, tok_per_img] int64 global positions -> per element
+ *   hit[n_img*tok] (uint8: position owned by this rank) and local[n_img*tok] (int64 local
+ *   position after the zig-zag slice, or -1).  seq_len % (2*cp) == 0. */
+int vita_cp_index_remap(const int64_t* indices_s, int64_t n, int64_t seq_len, int cp_size,
+                        int cp_rank, uint8_t* hit, int64_t* local_pos, void* stream);
+/* out[r] = any(mask[r, :])  — `selected_i = torch.any(mask, dim=1)` (M/training/utils.py:284,297). */
+int vita_rows_any(const uint8_t* mask, int64_t rows, int cols, uint8_t* out, void* stream);
+/* inv[idx[k]] = k  — renumbering of the selected images (utils.py:300 `arange(num_images)`). */
+int vita_index_inverse(const int64_t* idx, int64_t n, int64_t* inv, void* stream);
+/* For the k-th hit f = hit_idx[k] (flat index into [n_img, tok_per_img]):
+ *   src_b = img_rank[f / tok], src_s = f % tok   (utils.py:300-304)
+ *   tgt_b = indices_b[f],       tgt_s = local_pos[f]   (utils.py:306-309). */
+int vita_cp_src_tgt(const int64_t* hit_idx, int64_t n_hit, int tok_per_img,
+                    const int64_t* img_rank, const int64_t* indices_b, const int64_t* local_pos,
+                    int64_t* src_b, int64_t* src_s, int64_t* tgt_b, int64_t* tgt_s, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * bf16 GEMM on MFMA:   C[M,N] = epilogue(A[M,K] @ W[N,K]^T)        fp32 accumulation.
+ * W is row-major [N, K] exactly as torch.nn.Linear / Megatron store it, so this replaces
+ * torch.matmul(total_input, weight.t()) (M/core/tensor_parallel/layers.py:270,409), the TE
+ * linears of M/core/models/gpt/gpt_layer_specs.py:39-49, the ViT linears and the projector MLP
+ * (M/core/models/vision/multimodal_projector.py:53-69).
+ *   lda / ldw / ldc / ldr : row strides in elements.  K % 64 == 0, K >= 64; M, N arbitrary.
+ * Epilogues (v = fp32 accumulator; every arrow rounds to bf16 like the unfused reference chain):
+ *   VITA_EPI_NONE              C = bf16(v)
+ *   VITA_EPI_BIAS              C = bf16(v + bias[n])
+ *   VITA_EPI_BIAS_GELU         C = bf16(gelu_erf(bf16(v + bias[n])))              (bias may be NULL)
+ *   VITA_EPI_RESIDUAL          C = bf16(R[m,n] + bf16(v + bias[n]))               (bias may be NULL)
+ *   VITA_EPI_BIAS_SCALE_RES    C = bf16(R[m,n] + bf16(bf16(v + bias[n]) * scale[n]))   (LayerScale,
+ *                              M/core/models/vision/intern_vit_model.py:63,77)
+ *   VITA_EPI_SWIGLU            W holds [gate(N) ; up(N)] = 2N rows (fc1 = cat[gate, up],
+ *                              R/tools/hf2mcore_long_vita.py:612); C[M,N] = bf16(bf16(silu(bf16(g))) * bf16(u))
+ * ------------------------------------------------------------------------------------------- */
+#define VITA_EPI_NONE 0
+#define VITA_EPI_BIAS 1
+#define VITA_EPI_BIAS_GELU 2
+#define VITA_EPI_RESIDUAL 3
+#define VITA_EPI_BIAS_SCALE_RES 4
+#define VITA_EPI_SWIGLU 5
+
+int vita_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
+                   int64_t M, int64_t N, int64_t K, int epilogue, const void* bias,
+                   const void* scale, const void* R, int64_t ldr, void* stream);
+
+/* Skinny-M GEMM for the logits-masked LM head (n_sel rows, M <= 16):
+ *   logits[M, N] fp32-accumulated, stored bf16 (out_f32 == 0) or fp32 (out_f32 != 0).
+ * Replaces torch.matmul on the masked rows, M/core/tensor_parallel/layers.py:402-409. */
+int vita_gemm_skinny_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C,
+                          int64_t ldc, int M, int64_t N, int64_t K, int out_f32, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Flash attention forward (online softmax, fp32 statistics, bf16 I/O), head_dim 64 or 128.
+ * Replaces flash_attn_func (ViT, M/core/transformer/dot_product_attention.py:318-326),
+ * transformers._flash_attention_forward (LLM CP=1, :374-390) and TransformerEngine's
+ * AttnFuncWithCP ring (LLM CP>1, M/core/models/gpt/gpt_layer_specs.py:40).
+ *
+ * Sequence geometry is described by *chunks* so that one kernel serves plain causal, non-causal
+ * and zig-zag context-parallel attention:
+ *   - the local Q rows are n_q_chunks chunks of chunk_len rows, chunk i carrying the global
+ *     chunk id q_chunk_gid[i];
+ *   - the K/V rows visible to this rank are n_kv_chunks chunks of chunk_len rows; chunk j starts
+ *     at row kv_chunk_row[j] of the K / V buffers and carries global chunk id kv_chunk_gid[j];
+ *   - causal != 0: query (gq, i) attends key (gk, j) iff gk < gq or (gk == gq and j <= i);
+ *     causal == 0: everything is visible; kv_valid (<= chunk_len) masks the padded tail of a
+ *     single-chunk sequence (ViT: 1025 tokens).
+ * q/k/v/o strides are in elements; `batch` replicates the geometry (ViT frames).
+ * GQA: query head h uses kv head h / (n_q_heads / n_kv_heads); with G = n_q_heads / n_kv_heads the
+ * address of query head (g, j) is q + g * q_group_stride + j * q_head_stride (q_group_stride == 0
+ * means G * q_head_stride) so Q can be read in place from Megatron's mixed QKV activation;
+ * o_group_stride likewise.
+ * lse (fp32 [batch, n_q_heads, n_q_rows], natural log) may be NULL.
+ * All tables are HOST pointers (<= 64 chunks); they are copied into kernel arguments.
+ * ------------------------------------------------------------------------------------------- */
+typedef struct {
+  const void* q; int64_t q_batch_stride, q_row_stride, q_head_stride, q_group_stride;
+  const void* k; int64_t k_batch_stride, k_row_stride, k_head_stride;
+  const void* v; int64_t v_batch_stride, v_row_stride, v_head_stride;
+  void* o;       int64_t o_batch_stride, o_row_stride, o_head_stride, o_group_stride;
+  float* lse;
+  int batch, n_q_heads, n_kv_heads, head_dim;
+  int64_t chunk_len;        /* rows per chunk                                             */
+  int64_t q_valid;          /* valid rows of the last q chunk  (<= chunk_len)             */
+  int64_t kv_valid;         /* valid rows of the last kv chunk (<= chunk_len)             */
+  int n_q_chunks, n_kv_chunks;
+  const int32_t* q_chunk_gid;      /* host [n_q_chunks]  */
+  const int32_t* kv_chunk_gid;     /* host [n_kv_chunks] */
+  const int64_t* kv_chunk_row;     /* host [n_kv_chunks] */
+  int causal;
+  float softmax_scale;
+} vita_attn_params;
+
+int vita_flash_attn_fwd(const vita_attn_params* p, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * ViT front / back ends.
+ * vita_patchify14: im2col of the 14x14 / stride-14 patch conv (M/core/models/vision/intern_vit_model.py:139-145,203-205):
+ *   images [n, 3, H, W] bf16 -> patches [n * (H/14) * (W/14), k_pad] bf16, column = c*196 + dy*14 + dx
+ *   (the flattening of Conv2d.weight [out, 3, 14, 14]); columns 588..k_pad-1 are zero.
+ * vita_vit_assemble: x[n, 1 + P, h] = cat(cls, patch_embeds[n, P, h]) + pos[1 + P, h]   (:207-216),
+ *   rounding bf16 after the add.
+ * vita_pixel_shuffle_ln: drop cls, pixel-shuffle x0.5 and LayerNorm(4*h) in one pass
+ *   (M/pretrain_long_vita.py:467-483,572-582 + :443-446):
+ *   x [n, 1 + g*g, h] -> y [n, (g/2)*(g/2), 4h].
+ * ------------------------------------------------------------------------------------------- */
+int vita_patchify14(const void* images, void* patches, int64_t n, int H, int W, int k_pad,
+                    void* stream);
+int vita_vit_assemble(const void* patch_embeds, const void* cls_token, const void* pos_emb,
+                      void* x, int64_t n, int n_patches, int hidden, int has_cls, void* stream);
+int vita_pixel_shuffle_ln(const void* x, const void* w, const void* b, void* y, int64_t n,
+                          int grid, int hidden, int has_cls, float eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* VITA_HIP_H */

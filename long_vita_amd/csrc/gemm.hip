@@ -1,0 +1,345 @@
+// bf16 GEMM on gfx950 MFMA:  C[M,N] = epilogue(A[M,K] @ W[N,K]^T), fp32 accumulation.
+//
+// Bound: MFMA (dense bf16 peak ~2.5 PFLOP/s).  Algorithmic work 2*M*N*K flop.
+//
+// Structure (one workgroup = 4 waves = one 128x128 output tile, BK = 64):
+//   * both operands are K-contiguous, so an A tile and a W tile are each [128][64] bf16 = 16 KiB,
+//     staged HBM/L2 -> LDS with the LDS-DMA `global_load_lds_dwordx4` (16 B per lane, no VGPR
+//     round trip), double buffered (2 x 32 KiB), one barrier per K tile;
+//   * LDS-DMA writes lane-linear (wave base + lane*16 B), so the bank-conflict swizzle is applied
+//     to the per-lane *global source* address and mirrored on the ds_read_b128 side:
+//         physical 16-B slot = logical slot ^ ((row >> 1) & 7)        (conflict-free for the
+//     four 16-lane groups a ds_read_b128 is serviced in on gfx950);
+//   * each wave owns a 64x64 sub-tile = 2x2 v_mfma_f32_32x32x16_bf16 blocks; the W fragment is fed
+//     as the MFMA "A" operand and the activation fragment as "B", so a lane ends up with four
+//     *consecutive output columns* of one row per register quad -> 8-byte vector epilogue
+//     (bias / residual / LayerScale loads and the bf16 store are all 4-wide);
+//   * workgroup -> tile mapping is XCD-aware: the 8 XCDs (block id % 8) each walk a contiguous
+//     range of tiles in grouped (8 tile-rows) order so that concurrently resident workgroups of
+//     one XCD share A/W panels in that XCD's private 4 MiB L2.
+//
+// Replaces torch.matmul / TE linears (see include/vita_hip.h).
+#include "vita_common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128, BK = 64;
+constexpr int kTileBytes = BM * BK * 2;          // 16 KiB per operand tile
+constexpr int kStageBytes = 2 * kTileBytes;      // A + W
+constexpr int kLdsBytes = 2 * kStageBytes;       // double buffer = 64 KiB
+
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_cvoid;
+
+struct GemmArgs {
+  const bf16_t* A; int64_t lda;
+  const bf16_t* W; int64_t ldw;
+  bf16_t* C; int64_t ldc;
+  int64_t M, N, K;        // N = output columns (for SWIGLU: W has 2N rows)
+  const bf16_t* bias; const bf16_t* scale;
+  const bf16_t* R; int64_t ldr;
+  int tiles_m, tiles_n;
+};
+
+__device__ __forceinline__ float gelu_erf(float x) {
+  return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
+}
+
+// Stage one [128][64] tile (rows row0.., k offset k0) of a K-contiguous matrix into LDS.
+// `rowmap(r)` gives the global row for tile row r (clamped / permuted by the caller).
+template <typename RowMap>
+__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ base, int64_t ld, int64_t k0,
+                                           char* lds_tile, int wave, int lane, RowMap rowmap) {
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int rbase = (wave * 4 + q) * 8;          // 8 tile rows per wave-instruction (1 KiB)
+    const int lr = rbase + (lane >> 3);            // tile row written by this lane
+    const int ps = lane & 7;                       // physical 16-B slot inside the 128-B row
+    const int ls = ps ^ ((lr >> 1) & 7);           // logical slot whose data must land there
+    const bf16_t* src = base + rowmap(lr) * ld + k0 + ls * 8;
+    __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)(lds_tile + rbase * 128), 16, 0, 0);
+  }
+}
+
+__device__ __forceinline__ bf16x8 lds_frag(const char* lds_tile, int row, int slot) {
+  return *reinterpret_cast<const bf16x8*>(lds_tile + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
+}
+
+template <int EPI>
+__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+
+  // ---- XCD-aware, grouped tile order -------------------------------------------------------
+  const int nwg = p.tiles_m * p.tiles_n;
+  int pid;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  constexpr int GROUP_M = 8;
+  const int per_group = GROUP_M * p.tiles_n;
+  const int group = pid / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int in_group = pid - group * per_group;
+  const int tm = first_m + in_group % gsz;
+  const int tn = in_group / gsz;
+
+  const int64_t m0 = (int64_t)tm * BM;
+  // output-column origin of this tile: SWIGLU packs 64 outputs (gate+up) per 128 W rows
+  const int64_t n0 = (int64_t)tn * (EPI == VITA_EPI_SWIGLU ? BN / 2 : BN);
+
+  auto a_row = [&](int r) -> int64_t {
+    const int64_t g = m0 + r;
+    return g < p.M ? g : p.M - 1;
+  };
+  auto w_row = [&](int r) -> int64_t {
+    if (EPI == VITA_EPI_SWIGLU) {
+      // tile row r: blk = r / 32; blk&1 = 0 gate / 1 up; output column = n0 + (blk>>1)*32 + r%32
+      const int blk = r >> 5;
+      int64_t oc = n0 + (blk >> 1) * 32 + (r & 31);
+      if (oc >= p.N) oc = p.N - 1;
+      return ((blk & 1) ? p.N : 0) + oc;
+    } else {
+      const int64_t g = n0 + r;
+      return g < p.N ? g : p.N - 1;
+    }
+  };
+
+  f32x16 acc[2][2];  // [ni][mi] : 32 output columns x 32 rows each (transposed MFMA output)
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 2; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (int)(p.K / BK);
+  stage_tile(p.A, p.lda, 0, smem, wave, lane, a_row);
+  stage_tile(p.W, p.ldw, 0, smem + kTileBytes, wave, lane, w_row);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  const int frow_a = wm * 64 + (lane & 31), frow_w = wn * 64 + (lane & 31), fg = lane >> 5;
+  for (int t = 0; t < nk; ++t) {
+    char* cur = smem + (t & 1) * kStageBytes;
+    char* nxt = smem + ((t + 1) & 1) * kStageBytes;
+    if (t + 1 < nk) {
+      stage_tile(p.A, p.lda, (int64_t)(t + 1) * BK, nxt, wave, lane, a_row);
+      stage_tile(p.W, p.ldw, (int64_t)(t + 1) * BK, nxt + kTileBytes, wave, lane, w_row);
+    }
+    const char* ta = cur;
+    const char* tw = cur + kTileBytes;
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+      const bf16x8 a0 = lds_frag(ta, frow_a, kk * 2 + fg);
+      const bf16x8 a1 = lds_frag(ta, frow_a + 32, kk * 2 + fg);
+      const bf16x8 w0 = lds_frag(tw, frow_w, kk * 2 + fg);
+      const bf16x8 w1 = lds_frag(tw, frow_w + 32, kk * 2 + fg);
+      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a0, acc[0][0], 0, 0, 0);
+      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a1, acc[0][1], 0, 0, 0);
+      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a0, acc[1][0], 0, 0, 0);
+      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a1, acc[1][1], 0, 0, 0);
+    }
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+  }
+
+  // ---- epilogue: lane holds D^T: row m = ... + (lane & 31), columns 8*rg + 4*(lane>>5) + 0..3 --
+  const int hi = lane >> 5;
+#pragma unroll
+  for (int mi = 0; mi < 2; ++mi) {
+    const int64_t m = m0 + wm * 64 + mi * 32 + (lane & 31);
+    if (m >= p.M) continue;
+    if (EPI == VITA_EPI_SWIGLU) {
+      // wave's 64 tile rows of W = [gate 32 | up 32] for output columns n0 + wn*32 + 0..31
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int64_t n = n0 + wn * 32 + rg * 8 + hi * 4;
+        if (n >= p.N) continue;
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float g = bf16_round(acc[0][mi][rg * 4 + j]);
+          const float u = bf16_round(acc[1][mi][rg * 4 + j]);
+          const float s = bf16_round(g / (1.0f + __expf(-g)));
+          o[j] = s * u;
+        }
+        bf16_t* dst = p.C + m * p.ldc + n;
+        if (n + 3 < p.N) {
+          u32x2 v = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+          *reinterpret_cast<u32x2*>(dst) = v;
+        } else {
+          for (int j = 0; j < 4 && n + j < p.N; ++j) dst[j] = f32_to_bf16(o[j]);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ni = 0; ni < 2; ++ni) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int64_t n = n0 + wn * 64 + ni * 32 + rg * 8 + hi * 4;
+          if (n >= p.N) continue;
+          const bool full = n + 3 < p.N;
+          float o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = acc[ni][mi][rg * 4 + j];
+          if (EPI != VITA_EPI_NONE && p.bias) {
+            if (full) {
+              const u32x2 b = *reinterpret_cast<const u32x2*>(p.bias + n);
+              o[0] += bf16lo_to_f32(b[0]); o[1] += bf16hi_to_f32(b[0]);
+              o[2] += bf16lo_to_f32(b[1]); o[3] += bf16hi_to_f32(b[1]);
+            } else {
+              for (int j = 0; j < 4 && n + j < p.N; ++j) o[j] += bf16_to_f32(p.bias[n + j]);
+            }
+          }
+          if (EPI == VITA_EPI_BIAS_GELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = gelu_erf(bf16_round(o[j]));
+          }
+          if (EPI == VITA_EPI_BIAS_SCALE_RES) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int64_t nn = (n + j < p.N) ? n + j : p.N - 1;
+              o[j] = bf16_round(bf16_round(o[j]) * bf16_to_f32(p.scale[nn]));
+            }
+          }
+          if (EPI == VITA_EPI_RESIDUAL || EPI == VITA_EPI_BIAS_SCALE_RES) {
+            const bf16_t* rsrc = p.R + m * p.ldr + n;
+            if (EPI == VITA_EPI_RESIDUAL) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) o[j] = bf16_round(o[j]);
+            }
+            if (full) {
+              const u32x2 rv = *reinterpret_cast<const u32x2*>(rsrc);
+              o[0] += bf16lo_to_f32(rv[0]); o[1] += bf16hi_to_f32(rv[0]);
+              o[2] += bf16lo_to_f32(rv[1]); o[3] += bf16hi_to_f32(rv[1]);
+            } else {
+              for (int j = 0; j < 4 && n + j < p.N; ++j) o[j] += bf16_to_f32(rsrc[j]);
+            }
+          }
+          bf16_t* dst = p.C + m * p.ldc + n;
+          if (full) {
+            u32x2 v = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+            *reinterpret_cast<u32x2*>(dst) = v;
+          } else {
+            for (int j = 0; j < 4 && n + j < p.N; ++j) dst[j] = f32_to_bf16(o[j]);
+          }
+        }
+      }
+    }
+  }
+}
+
+// ---- skinny-M (M <= 16): one wave per output column, x rows cached in LDS ------------------
+// HBM-bound on W: algorithmic bytes = N*K*2.  Each lane streams 16-byte pieces of one W row.
+template <int MAXM>
+__global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restrict__ A, int64_t lda,
+                                                          const bf16_t* __restrict__ W, int64_t ldw,
+                                                          void* __restrict__ C, int64_t ldc, int M,
+                                                          int64_t N, int64_t K, int out_f32) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int64_t n = (int64_t)blockIdx.x * 4 + wave;
+  if (n >= N) return;
+  float acc[MAXM];
+#pragma unroll
+  for (int m = 0; m < MAXM; ++m) acc[m] = 0.f;
+  const int nvec = (int)(K >> 3);
+  const u32x4* wr = reinterpret_cast<const u32x4*>(W + n * ldw);
+  for (int v = lane; v < nvec; v += 64) {
+    const u32x4 wv = wr[v];
+    float wf[8];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) { wf[2 * j] = bf16lo_to_f32(wv[j]); wf[2 * j + 1] = bf16hi_to_f32(wv[j]); }
+#pragma unroll
+    for (int m = 0; m < MAXM; ++m) {
+      if (m < M) {
+        const u32x4 av = *reinterpret_cast<const u32x4*>(A + m * lda + v * 8);
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+          acc[m] += bf16lo_to_f32(av[j]) * wf[2 * j] + bf16hi_to_f32(av[j]) * wf[2 * j + 1];
+      }
+    }
+  }
+#pragma unroll
+  for (int m = 0; m < MAXM; ++m) {
+    if (m < M) {
+      const float s = wave_reduce_sum(acc[m]);
+      if (lane == 0) {
+        if (out_f32) reinterpret_cast<float*>(C)[m * ldc + n] = s;
+        else reinterpret_cast<bf16_t*>(C)[m * ldc + n] = f32_to_bf16(s);
+      }
+    }
+  }
+}
+
+template <int EPI>
+int launch_gemm(const GemmArgs& a, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256),
+                     kLdsBytes, st, a);
+  return vita_check_launch();
+}
+
+}  // namespace
+
+extern "C" int vita_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C,
+                              int64_t ldc, int64_t M, int64_t N, int64_t K, int epilogue,
+                              const void* bias, const void* scale, const void* R, int64_t ldr,
+                              void* stream) {
+  if (!A || !W || !C || M < 0 || N <= 0 || K <= 0) return VITA_ERR_INVALID_ARG;
+  if (K % BK) return VITA_ERR_UNSUPPORTED;
+  if ((lda & 7) || (ldw & 7) || (ldc & 3)) return VITA_ERR_UNSUPPORTED;
+  if (M == 0) return VITA_OK;
+  GemmArgs a;
+  a.A = (const bf16_t*)A; a.lda = lda; a.W = (const bf16_t*)W; a.ldw = ldw;
+  a.C = (bf16_t*)C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+  a.bias = (const bf16_t*)bias; a.scale = (const bf16_t*)scale; a.R = (const bf16_t*)R; a.ldr = ldr;
+  const int64_t tm = (M + BM - 1) / BM;
+  const int64_t tn = epilogue == VITA_EPI_SWIGLU ? (N + BN / 2 - 1) / (BN / 2) : (N + BN - 1) / BN;
+  if (tm * tn > 0x7fffffff) return VITA_ERR_UNSUPPORTED;
+  a.tiles_m = (int)tm; a.tiles_n = (int)tn;
+  hipStream_t st = (hipStream_t)stream;
+  switch (epilogue) {
+    case VITA_EPI_NONE: return launch_gemm<VITA_EPI_NONE>(a, st);
+    case VITA_EPI_BIAS:
+      if (!bias) return VITA_ERR_INVALID_ARG;
+      return launch_gemm<VITA_EPI_BIAS>(a, st);
+    case VITA_EPI_BIAS_GELU: return launch_gemm<VITA_EPI_BIAS_GELU>(a, st);
+    case VITA_EPI_RESIDUAL:
+      if (!R || (ldr & 3)) return VITA_ERR_INVALID_ARG;
+      return launch_gemm<VITA_EPI_RESIDUAL>(a, st);
+    case VITA_EPI_BIAS_SCALE_RES:
+      if (!R || !scale || (ldr & 3)) return VITA_ERR_INVALID_ARG;
+      return launch_gemm<VITA_EPI_BIAS_SCALE_RES>(a, st);
+    case VITA_EPI_SWIGLU: return launch_gemm<VITA_EPI_SWIGLU>(a, st);
+    default: return VITA_ERR_INVALID_ARG;
+  }
+}
+
+extern "C" int vita_gemm_skinny_bf16(const void* A, int64_t lda, const void* W, int64_t ldw,
+                                     void* C, int64_t ldc, int M, int64_t N, int64_t K,
+                                     int out_f32, void* stream) {
+  if (!A || !W || !C || M < 0 || N <= 0 || K <= 0) return VITA_ERR_INVALID_ARG;
+  if (M > 16 || (K & 7) || (lda & 7) || (ldw & 7)) return VITA_ERR_UNSUPPORTED;
+  if (M == 0) return VITA_OK;
+  dim3 grid((unsigned)((N + 3) / 4)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (M <= 2)
+    hipLaunchKernelGGL(gemm_skinny_kernel<2>, grid, block, 0, st, (const bf16_t*)A, lda,
+                       (const bf16_t*)W, ldw, C, ldc, M, N, K, out_f32);
+  else if (M <= 8)
+    hipLaunchKernelGGL(gemm_skinny_kernel<8>, grid, block, 0, st, (const bf16_t*)A, lda,
+                       (const bf16_t*)W, ldw, C, ldc, M, N, K, out_f32);
+  else
+    hipLaunchKernelGGL(gemm_skinny_kernel<16>, grid, block, 0, st, (const bf16_t*)A, lda,
+                       (const bf16_t*)W, ldw, C, ldc, M, N, K, out_f32);
+  return vita_check_launch();
+}

@@ -1,0 +1,157 @@
+// RoPE for gfx950: cos/sin table build + in-place apply (generic strided view, and the fused
+// variant over Megatron's mixed QKV activation that also packs K/V for the CP all-gather).
+// HBM-bound elementwise work: every lane moves 16-byte vectors (8 bf16).
+//
+// Reference arithmetic restated (M/core/models/common/embeddings/rotary_pos_embedding.py):
+//   :98-106  freqs = outer(pos, inv_freq) (fp32); emb = cat(freqs, freqs)
+//   :114-117 optional gather by position_ids  -> here: the caller passes the positions
+//   :36-47   zig-zag CP slice                  -> here: the caller passes the rank's positions
+//   :200-203 cos_ = cos(freqs).to(bf16); sin_ likewise; t = t*cos_ + rotate_half(t)*sin_
+//            with every bf16 op rounding: bf16(bf16(t*cos) + bf16(rot*sin))
+//   :169-171 rotate_half (non-interleaved): cat(-x2, x1)
+#include "vita_common.h"
+
+namespace {
+
+__global__ void rope_table_kernel(const int64_t* __restrict__ pos, const float* __restrict__ inv_freq,
+                                  bf16_t* __restrict__ cos_out, bf16_t* __restrict__ sin_out,
+                                  int64_t n, int half_dim) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * half_dim) return;
+  const int64_t r = i / half_dim;
+  const int c = (int)(i - r * half_dim);
+  const float f = (float)pos[r] * inv_freq[c];
+  cos_out[i] = f32_to_bf16(cosf(f));
+  sin_out[i] = f32_to_bf16(sinf(f));
+}
+
+// rotate one pair of 8-wide vectors (x1 = first half, x2 = second half) with cos/sin vectors.
+__device__ __forceinline__ void rope_rotate8(u32x4& x1, u32x4& x2, const u32x4& c, const u32x4& s,
+                                             float sign) {
+  u32x4 o1, o2;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a0 = bf16lo_to_f32(x1[j]), a1 = bf16hi_to_f32(x1[j]);
+    const float b0 = bf16lo_to_f32(x2[j]), b1 = bf16hi_to_f32(x2[j]);
+    const float c0 = bf16lo_to_f32(c[j]), c1 = bf16hi_to_f32(c[j]);
+    const float s0 = sign * bf16lo_to_f32(s[j]), s1 = sign * bf16hi_to_f32(s[j]);
+    // out1 = x1*cos + (-x2)*sin ; out2 = x2*cos + x1*sin
+    const float r10 = bf16_round(a0 * c0) + bf16_round(-b0 * s0);
+    const float r11 = bf16_round(a1 * c1) + bf16_round(-b1 * s1);
+    const float r20 = bf16_round(b0 * c0) + bf16_round(a0 * s0);
+    const float r21 = bf16_round(b1 * c1) + bf16_round(a1 * s1);
+    o1[j] = pack_bf16x2(r10, r11);
+    o2[j] = pack_bf16x2(r20, r21);
+  }
+  x1 = o1;
+  x2 = o2;
+}
+
+__global__ __launch_bounds__(256) void rope_apply_kernel(bf16_t* __restrict__ t, int64_t rows,
+                                                         int heads, int head_dim,
+                                                         int64_t row_stride, int64_t head_stride,
+                                                         const bf16_t* __restrict__ cos_tab,
+                                                         const bf16_t* __restrict__ sin_tab,
+                                                         float sign) {
+  const int half = head_dim >> 1, nv = half >> 3;
+  const int64_t total = rows * heads * nv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int vi = (int)(i % nv);
+    const int64_t rh = i / nv;
+    const int h = (int)(rh % heads);
+    const int64_t r = rh / heads;
+    bf16_t* p = t + r * row_stride + (int64_t)h * head_stride + vi * 8;
+    u32x4 x1 = *reinterpret_cast<const u32x4*>(p);
+    u32x4 x2 = *reinterpret_cast<const u32x4*>(p + half);
+    const u32x4 c = *reinterpret_cast<const u32x4*>(cos_tab + r * half + vi * 8);
+    const u32x4 s = *reinterpret_cast<const u32x4*>(sin_tab + r * half + vi * 8);
+    rope_rotate8(x1, x2, c, s, sign);
+    *reinterpret_cast<u32x4*>(p) = x1;
+    *reinterpret_cast<u32x4*>(p + half) = x2;
+  }
+}
+
+// mixed_qkv [rows, groups, (qpg + 2), d]: heads 0..qpg-1 = Q, qpg = K, qpg+1 = V.
+__global__ __launch_bounds__(256) void rope_qkv_kernel(bf16_t* __restrict__ mixed, int64_t rows,
+                                                       int groups, int qpg, int head_dim,
+                                                       const bf16_t* __restrict__ cos_tab,
+                                                       const bf16_t* __restrict__ sin_tab,
+                                                       bf16_t* __restrict__ kv_out) {
+  const int half = head_dim >> 1, nv = half >> 3, hpg = qpg + 2;
+  const int64_t per_row = (int64_t)groups * hpg * nv;
+  const int64_t total = rows * per_row;
+  const int64_t kv_plane = rows * (int64_t)groups * head_dim;  // elements in K (or V) of kv_out
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / per_row;
+    int rem = (int)(i - r * per_row);
+    const int vi = rem % nv;
+    rem /= nv;
+    const int h = rem % hpg;
+    const int g = rem / hpg;
+    bf16_t* p = mixed + (r * groups + g) * (int64_t)hpg * head_dim + (int64_t)h * head_dim + vi * 8;
+    u32x4 x1 = *reinterpret_cast<const u32x4*>(p);
+    u32x4 x2 = *reinterpret_cast<const u32x4*>(p + half);
+    if (h <= qpg) {
+      const u32x4 c = *reinterpret_cast<const u32x4*>(cos_tab + r * half + vi * 8);
+      const u32x4 s = *reinterpret_cast<const u32x4*>(sin_tab + r * half + vi * 8);
+      rope_rotate8(x1, x2, c, s, 1.0f);
+      *reinterpret_cast<u32x4*>(p) = x1;
+      *reinterpret_cast<u32x4*>(p + half) = x2;
+    }
+    if (kv_out && h >= qpg) {
+      bf16_t* o = kv_out + (h - qpg) * kv_plane + (r * groups + g) * (int64_t)head_dim + vi * 8;
+      *reinterpret_cast<u32x4*>(o) = x1;
+      *reinterpret_cast<u32x4*>(o + half) = x2;
+    }
+  }
+}
+
+inline unsigned grid_for(int64_t total, int block) {
+  int64_t g = (total + block - 1) / block;
+  const int64_t cap = 256 * 16;  // 256 CUs x 16 blocks, grid-stride beyond
+  return (unsigned)(g < cap ? (g < 1 ? 1 : g) : cap);
+}
+
+}  // namespace
+
+extern "C" int vita_rope_table(const int64_t* pos, const float* inv_freq, void* cos_out,
+                               void* sin_out, int64_t n, int half_dim, void* stream) {
+  if (!pos || !inv_freq || !cos_out || !sin_out || n < 0 || half_dim <= 0) return VITA_ERR_INVALID_ARG;
+  if (n == 0) return VITA_OK;
+  const int64_t total = n * half_dim;
+  hipLaunchKernelGGL(rope_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
+                     (hipStream_t)stream, pos, inv_freq, (bf16_t*)cos_out, (bf16_t*)sin_out, n,
+                     half_dim);
+  return vita_check_launch();
+}
+
+extern "C" int vita_rope_apply(void* t, int64_t rows, int heads, int head_dim, int64_t row_stride,
+                               int64_t head_stride, const void* cos_tab, const void* sin_tab,
+                               int sign, void* stream) {
+  if (!t || !cos_tab || !sin_tab || rows < 0 || heads <= 0 || head_dim <= 0) return VITA_ERR_INVALID_ARG;
+  if ((head_dim & 15) || (row_stride & 7) || (head_stride & 7)) return VITA_ERR_UNSUPPORTED;
+  if (sign != 1 && sign != -1) return VITA_ERR_INVALID_ARG;
+  if (rows == 0) return VITA_OK;
+  const int64_t total = rows * heads * (head_dim / 16);
+  hipLaunchKernelGGL(rope_apply_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, (bf16_t*)t, rows, heads, head_dim, row_stride,
+                     head_stride, (const bf16_t*)cos_tab, (const bf16_t*)sin_tab, (float)sign);
+  return vita_check_launch();
+}
+
+extern "C" int vita_rope_qkv_fwd(void* mixed_qkv, int64_t rows, int groups, int q_per_group,
+                                 int head_dim, const void* cos_tab, const void* sin_tab,
+                                 void* kv_out, void* stream) {
+  if (!mixed_qkv || !cos_tab || !sin_tab || rows < 0 || groups <= 0 || q_per_group <= 0 ||
+      head_dim <= 0)
+    return VITA_ERR_INVALID_ARG;
+  if (head_dim & 15) return VITA_ERR_UNSUPPORTED;
+  if (rows == 0) return VITA_OK;
+  const int64_t total = rows * groups * (q_per_group + 2) * (head_dim / 16);
+  hipLaunchKernelGGL(rope_qkv_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
+                     (hipStream_t)stream, (bf16_t*)mixed_qkv, rows, groups, q_per_group, head_dim,
+                     (const bf16_t*)cos_tab, (const bf16_t*)sin_tab, (bf16_t*)kv_out);
+  return vita_check_launch();
+}

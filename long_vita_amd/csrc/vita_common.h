@@ -1,0 +1,63 @@
+// Shared device helpers for the gfx950 (MI355X, CDNA4) kernels of libvita_hip.so.
+// gfx950 only: wave = 64 lanes, native __bf16 conversions (v_cvt_pk_bf16_f32, RNE).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include "../../include/vita_hip.h"
+
+typedef unsigned short bf16_t;  // raw bf16 bit pattern in memory
+
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+
+#define VITA_WAVE 64
+
+__device__ __forceinline__ float bf16_to_f32(bf16_t x) {
+  return __uint_as_float(((unsigned)x) << 16);
+}
+// round-to-nearest-even, NaN preserved (hardware v_cvt_pk_bf16_f32)
+__device__ __forceinline__ bf16_t f32_to_bf16(float f) {
+  __bf16 b = (__bf16)f;
+  return *reinterpret_cast<bf16_t*>(&b);
+}
+// round a float to the nearest bf16 value, keep it as float (the "arrow" of the reference's
+// unfused bf16 op chains)
+__device__ __forceinline__ float bf16_round(float f) { return bf16_to_f32(f32_to_bf16(f)); }
+
+__device__ __forceinline__ unsigned pack_bf16x2(float lo, float hi) {
+  bf16x2 v;
+  v[0] = (__bf16)lo;
+  v[1] = (__bf16)hi;
+  return *reinterpret_cast<unsigned*>(&v);
+}
+__device__ __forceinline__ float bf16lo_to_f32(unsigned w) { return __uint_as_float(w << 16); }
+__device__ __forceinline__ float bf16hi_to_f32(unsigned w) { return __uint_as_float(w & 0xffff0000u); }
+
+__device__ __forceinline__ float wave_reduce_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+
+// block-wide sum for blockDim.x <= 1024 (<= 16 waves); `red` is >= 16 floats of LDS.
+__device__ __forceinline__ float block_reduce_sum(float v, float* red) {
+  v = wave_reduce_sum(v);
+  const int lane = threadIdx.x & 63, wid = threadIdx.x >> 6, nw = (blockDim.x + 63) >> 6;
+  __syncthreads();  // protect `red` from a previous use
+  if (lane == 0) red[wid] = v;
+  __syncthreads();
+  float t = 0.f;
+  for (int i = 0; i < nw; ++i) t += red[i];
+  return t;
+}
+
+static inline int vita_check_launch() {
+  hipError_t e = hipGetLastError();
+  return e == hipSuccess ? VITA_OK : VITA_ERR_LAUNCH;
+}

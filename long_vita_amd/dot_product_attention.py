@@ -1,0 +1,80 @@
+"""Core attention — mirror of M/core/transformer/dot_product_attention.py
+(`DotProductAttention.forward(query, key, value, attention_mask, attn_mask_type, packed_seq_params)`).
+
+ViT branch  (:312-329)  non-causal, flash_attn_func            -> vita_flash_attn_fwd, d = 64
+LLM CP = 1  (:374-390)  causal, _flash_attention_forward        -> vita_flash_attn_fwd, d = 128
+LLM CP > 1  (TE AttnFuncWithCP P2P ring, gpt_layer_specs.py:40) -> ONE all-gather of the packed
+            K/V shard over the CP group (RCCL; every peer pushes over its own xGMI link) followed by
+            one kernel launch over the zig-zag chunk tables.  The gathered buffer keeps rank order,
+            so chunk 2p+h of the buffer is global chunk (h ? 2CP-1-p : p).
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import ops, parallel_state as mpu
+
+
+class DotProductAttention:
+    def __init__(self, num_attention_heads: int, num_query_groups: int, kv_channels: int, causal: bool = True,
+                 softmax_scale: Optional[float] = None):
+        self.np, self.ng, self.hn = num_attention_heads, num_query_groups, kv_channels
+        self.causal = causal
+        self.softmax_scale = softmax_scale
+        self._kv_gather = None
+
+    # -- Megatron calling convention: [s, b, heads, d] ---------------------------------------------
+    def forward(self, query, key, value, attention_mask=None, attn_mask_type=None, packed_seq_params=None):
+        assert packed_seq_params is None, (
+            "Packed sequence is not supported by DotProductAttention."
+            "Please use TEDotProductAttention instead.")                               # :156-159
+        sq, b, np_, hn = query.shape
+        q = query.transpose(0, 1)
+        k = key.transpose(0, 1)
+        v = value.transpose(0, 1)
+        cp = mpu.get_context_parallel_world_size()
+        if self.causal and cp > 1:
+            if b != 1:
+                raise ValueError("context-parallel attention runs batch 1")
+            kv = torch.stack([key.reshape(sq, self.ng, hn), value.reshape(sq, self.ng, hn)]).contiguous()
+            out = self.forward_cp(q, kv)
+        else:
+            out = ops.flash_attn(q, k, v, causal=self.causal, softmax_scale=self.softmax_scale)
+        return out.transpose(0, 1).reshape(sq, b, np_ * hn)                           # [sq, b, hp] :285-289
+
+    __call__ = forward
+
+    # -- context-parallel core: q [1, S_l, ...] view, kv_local packed [2, S_l, ng, d] ----------------
+    def forward_cp(self, q: torch.Tensor, kv_local: torch.Tensor, out: Optional[torch.Tensor] = None, events=None):
+        cp, r = mpu.get_context_parallel_world_size(), mpu.get_context_parallel_rank()
+        s_l = kv_local.shape[1]
+        if s_l % 2:
+            raise ValueError("local sequence must hold two zig-zag chunks")
+        c = s_l // 2
+        gathered = self._gather_buffer(kv_local, cp)
+        dist.all_gather_into_tensor(gathered, kv_local.view(-1), group=mpu.get_context_parallel_group())
+        g = gathered.view(cp, 2, s_l, self.ng, self.hn)
+        rows = g.view(cp * 2 * s_l, self.ng, self.hn)          # K rows of rank p start at p*2*s_l, V at +s_l
+        k_all = rows.unsqueeze(0)
+        v_all = rows[s_l:].unsqueeze(0)
+        kv_gid, kv_row = [], []
+        for p in range(cp):
+            kv_gid += [p, 2 * cp - 1 - p]
+            kv_row += [p * 2 * s_l, p * 2 * s_l + c]
+        if events:
+            events[0].record()
+        o = ops.flash_attn(q, k_all, v_all, causal=True, softmax_scale=self.softmax_scale, chunk_len=c,
+                           q_chunk_gid=mpu.zigzag_chunk_ids(cp, r), kv_chunk_gid=kv_gid, kv_chunk_row=kv_row,
+                           out=out)
+        if events:
+            events[1].record()
+        return o
+
+    def _gather_buffer(self, kv_local, cp):
+        n = kv_local.numel() * cp
+        if self._kv_gather is None or self._kv_gather.numel() != n or self._kv_gather.device != kv_local.device:
+            self._kv_gather = torch.empty(n, dtype=kv_local.dtype, device=kv_local.device)
+        return self._kv_gather

@@ -1,0 +1,349 @@
+"""Tensor-level entry points over the C ABI (include/vita_hip.h).
+
+PyTorch supplies device memory and the current HIP stream only; all arithmetic happens in
+libvita_hip.so.  Every function raises if its inputs are not on a HIP device — there is no CPU
+fallback and nothing here imports ``oracle/``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional, Sequence
+
+import torch
+
+from . import lib as _L
+from .lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_NONE, EPI_RESIDUAL,  # noqa: F401
+                  EPI_SWIGLU, AttnParams)
+
+BF16 = torch.bfloat16
+
+
+def _stream() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def _dev(t: torch.Tensor, name: str, dtype=None) -> int:
+    if not isinstance(t, torch.Tensor) or not t.is_cuda:
+        raise RuntimeError(f"{name} must be a HIP device tensor (the product path has no CPU fallback)")
+    if dtype is not None and t.dtype != dtype:
+        raise ValueError(f"{name} must be {dtype}, got {t.dtype}")
+    return t.data_ptr()
+
+
+def _opt(t: Optional[torch.Tensor], name: str, dtype=None) -> Optional[int]:
+    return None if t is None else _dev(t, name, dtype)
+
+
+# ------------------------------------------------------------------------------------------------
+# norms
+# ------------------------------------------------------------------------------------------------
+def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, out: Optional[torch.Tensor] = None,
+            rstd: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """RMSNorm.forward — M/core/transformer/custom_layers/transformer_engine.py:74-79."""
+    cols = x.shape[-1]
+    xc = x if x.is_contiguous() else x.contiguous()
+    rows = xc.numel() // cols
+    y = torch.empty_like(xc) if out is None else out
+    _L.check(_L.load().vita_rmsnorm_fwd(_dev(xc, "x", BF16), _dev(weight, "weight", BF16), _dev(y, "out", BF16),
+                                        _opt(rstd, "rstd", torch.float32), rows, cols, float(eps), _stream()),
+             "vita_rmsnorm_fwd")
+    return y
+
+
+def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], eps: float,
+              out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    cols = x.shape[-1]
+    xc = x if x.is_contiguous() else x.contiguous()
+    rows = xc.numel() // cols
+    y = torch.empty_like(xc) if out is None else out
+    _L.check(_L.load().vita_layernorm_fwd(_dev(xc, "x", BF16), _dev(weight, "weight", BF16), _opt(bias, "bias", BF16),
+                                          _dev(y, "out", BF16), rows, cols, float(eps), _stream()),
+             "vita_layernorm_fwd")
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+# RoPE
+# ------------------------------------------------------------------------------------------------
+def rope_inv_freq(dim: int, base: float, device) -> torch.Tensor:
+    """inv_freq exactly as RotaryEmbedding.__init__ (rotary_pos_embedding.py:74-80) builds it
+    (64 floats; computed with torch on the host so the bit pattern equals the reference's)."""
+    inv = 1.0 / (base ** (torch.arange(0, dim, 2, dtype=torch.float32) / dim))
+    return inv.to(device)
+
+
+def rope_table(positions: torch.Tensor, inv_freq: torch.Tensor):
+    """cos/sin (bf16 [n, dim/2]) for int64 global positions."""
+    pos = positions.reshape(-1)
+    if pos.dtype != torch.int64:
+        raise ValueError("positions must be int64")
+    n, half = pos.numel(), inv_freq.numel()
+    cos = torch.empty((n, half), dtype=BF16, device=pos.device)
+    sin = torch.empty_like(cos)
+    _L.check(_L.load().vita_rope_table(_dev(pos.contiguous(), "positions"), _dev(inv_freq, "inv_freq", torch.float32),
+                                       _dev(cos, "cos"), _dev(sin, "sin"), n, half, _stream()), "vita_rope_table")
+    return cos, sin
+
+
+def rope_apply_(t: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, sign: int = 1) -> torch.Tensor:
+    """In-place apply_rotary_pos_emb_bshd on t [rows, heads, d] (any row/head stride, d contiguous)."""
+    if t.dim() != 3 or t.stride(2) != 1:
+        raise ValueError("t must be [rows, heads, head_dim] with contiguous head_dim")
+    rows, heads, d = t.shape
+    _L.check(_L.load().vita_rope_apply(_dev(t, "t", BF16), rows, heads, d, t.stride(0), t.stride(1),
+                                       _dev(cos, "cos", BF16), _dev(sin, "sin", BF16), sign, _stream()),
+             "vita_rope_apply")
+    return t
+
+
+def rope_qkv_(mixed_qkv: torch.Tensor, groups: int, q_per_group: int, head_dim: int, cos: torch.Tensor,
+              sin: torch.Tensor, kv_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Rotate Q/K of Megatron's mixed QKV [rows, groups*(qpg+2)*d] in place; optionally pack
+    rotated K and V into kv_out [2, rows, groups, d]."""
+    if not mixed_qkv.is_contiguous():
+        raise ValueError("mixed_qkv must be contiguous")
+    rows = mixed_qkv.numel() // (groups * (q_per_group + 2) * head_dim)
+    if kv_out is not None and (not kv_out.is_contiguous() or kv_out.numel() != 2 * rows * groups * head_dim):
+        raise ValueError("kv_out must be contiguous [2, rows, groups, head_dim]")
+    _L.check(_L.load().vita_rope_qkv_fwd(_dev(mixed_qkv, "mixed_qkv", BF16), rows, groups, q_per_group, head_dim,
+                                         _dev(cos, "cos", BF16), _dev(sin, "sin", BF16), _opt(kv_out, "kv_out", BF16),
+                                         _stream()), "vita_rope_qkv_fwd")
+    return mixed_qkv
+
+
+# ------------------------------------------------------------------------------------------------
+# rows
+# ------------------------------------------------------------------------------------------------
+def _err_flag(device) -> torch.Tensor:
+    return torch.zeros(1, dtype=torch.int32, device=device)
+
+
+def row_gather(src: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor] = None,
+               check_bounds: bool = True) -> torch.Tensor:
+    """out[i] = src[idx[i]] over the first dimension (rows are the flattened trailing dims)."""
+    if not src.is_contiguous():
+        raise ValueError("src must be contiguous")
+    if idx.dtype != torch.int64:
+        raise ValueError("idx must be int64")
+    idx = idx.reshape(-1).contiguous()
+    n, cols = idx.numel(), src.numel() // max(src.shape[0], 1)
+    y = torch.empty((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device) if out is None else out
+    flag = _err_flag(src.device) if check_bounds else None
+    _L.check(_L.load().vita_row_gather(_dev(src, "src"), src.shape[0], _dev(idx, "idx"), _dev(y, "out"), n, cols,
+                                       src.element_size(), _opt(flag, "flag"), _stream()), "vita_row_gather")
+    if check_bounds and int(flag.item()):
+        raise IndexError("vita_row_gather: index out of range")
+    return y
+
+
+def row_scatter_(dst: torch.Tensor, dst_idx: torch.Tensor, src: torch.Tensor,
+                 src_idx: Optional[torch.Tensor] = None, check_bounds: bool = True) -> torch.Tensor:
+    """dst[dst_idx[i]] = src[src_idx[i] if src_idx is not None else i] (rows = flattened trailing dims)."""
+    if not dst.is_contiguous() or not src.is_contiguous():
+        raise ValueError("dst and src must be contiguous")
+    dst_idx = dst_idx.reshape(-1).contiguous()
+    if src_idx is not None:
+        src_idx = src_idx.reshape(-1).contiguous()
+    n = dst_idx.numel()
+    cols = dst.numel() // max(dst.shape[0], 1)
+    if src.numel() // max(src.shape[0], 1) != cols or src.dtype != dst.dtype:
+        raise ValueError("row width / dtype mismatch")
+    flag = _err_flag(dst.device) if check_bounds else None
+    _L.check(_L.load().vita_row_scatter(_dev(src, "src"), src.shape[0], _opt(src_idx, "src_idx", torch.int64),
+                                        _dev(dst, "dst"), dst.shape[0], _dev(dst_idx, "dst_idx", torch.int64), n, cols,
+                                        dst.element_size(), _opt(flag, "flag"), _stream()), "vita_row_scatter")
+    if check_bounds and int(flag.item()):
+        raise IndexError("vita_row_scatter: index out of range")
+    return dst
+
+
+def mask_to_index(mask: torch.Tensor) -> torch.Tensor:
+    """Positions of the True entries of a flattened bool mask, in order (index form of
+    torch.masked_select, M/core/tensor_parallel/layers.py:348,407)."""
+    m = mask.reshape(-1)
+    if m.dtype == torch.bool:
+        m = m.view(torch.uint8)
+    if m.dtype != torch.uint8:
+        raise ValueError("mask must be bool / uint8")
+    m = m.contiguous()
+    n = m.numel()
+    idx = torch.empty(n, dtype=torch.int64, device=m.device)
+    cnt = torch.zeros(1, dtype=torch.int64, device=m.device)
+    _L.check(_L.load().vita_mask_to_index(_dev(m, "mask"), n, _dev(idx, "idx"), _dev(cnt, "count"), _stream()),
+             "vita_mask_to_index")
+    return idx[: int(cnt.item())]
+
+
+def cp_index_remap(indices_s: torch.Tensor, seq_len: int, cp_size: int, cp_rank: int):
+    s = indices_s.contiguous()
+    hit = torch.empty(s.shape, dtype=torch.uint8, device=s.device)
+    local = torch.empty(s.shape, dtype=torch.int64, device=s.device)
+    _L.check(_L.load().vita_cp_index_remap(_dev(s, "indices_s", torch.int64), s.numel(), seq_len, cp_size, cp_rank,
+                                           _dev(hit, "hit"), _dev(local, "local"), _stream()), "vita_cp_index_remap")
+    return hit, local
+
+
+def rows_any(mask: torch.Tensor) -> torch.Tensor:
+    m = mask.contiguous()
+    rows, cols = m.shape
+    out = torch.empty(rows, dtype=torch.uint8, device=m.device)
+    _L.check(_L.load().vita_rows_any(_dev(m, "mask", torch.uint8), rows, cols, _dev(out, "out"), _stream()),
+             "vita_rows_any")
+    return out
+
+
+def index_inverse(idx: torch.Tensor, size: int) -> torch.Tensor:
+    inv = torch.full((size,), -1, dtype=torch.int64, device=idx.device)
+    _L.check(_L.load().vita_index_inverse(_dev(idx.contiguous(), "idx", torch.int64), idx.numel(), _dev(inv, "inv"),
+                                          _stream()), "vita_index_inverse")
+    return inv
+
+
+def cp_src_tgt(hit_idx, tok_per_img, img_rank, indices_b, local_pos):
+    n = hit_idx.numel()
+    outs = [torch.empty(n, dtype=torch.int64, device=hit_idx.device) for _ in range(4)]
+    _L.check(_L.load().vita_cp_src_tgt(_dev(hit_idx, "hit_idx", torch.int64), n, tok_per_img,
+                                       _dev(img_rank, "img_rank", torch.int64),
+                                       _dev(indices_b.contiguous(), "indices_b", torch.int64),
+                                       _dev(local_pos, "local_pos", torch.int64),
+                                       *[_dev(o, "out") for o in outs], _stream()), "vita_cp_src_tgt")
+    return outs
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM
+# ------------------------------------------------------------------------------------------------
+def gemm(a: torch.Tensor, w: torch.Tensor, epilogue: int = EPI_NONE, bias: Optional[torch.Tensor] = None,
+         scale: Optional[torch.Tensor] = None, residual: Optional[torch.Tensor] = None,
+         out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M, N] = epilogue(a[M, K] @ w[N(or 2N), K]^T) — see VITA_EPI_* in include/vita_hip.h.
+    `a` may have a row stride (a.stride(0) >= K); w is [rows, K] contiguous like nn.Linear.weight."""
+    if a.dim() != 2 or w.dim() != 2 or a.stride(1) != 1 or w.stride(1) != 1:
+        raise ValueError("a and w must be 2-D with contiguous last dim")
+    M, K = a.shape
+    wn, wk = w.shape
+    if wk != K:
+        raise RuntimeError(f"supplied weight's shape is {tuple(w.shape)}, K = {K} expected")  # layers.py:849-853
+    N = wn // 2 if epilogue == EPI_SWIGLU else wn
+    y = torch.empty((M, N), dtype=BF16, device=a.device) if out is None else out
+    if y.shape != (M, N) or y.stride(1) != 1:
+        raise ValueError("out has wrong shape")
+    r_ptr, ldr = None, 0
+    if residual is not None:
+        if residual.shape != (M, N) or residual.stride(1) != 1:
+            raise ValueError("residual has wrong shape")
+        r_ptr, ldr = _dev(residual, "residual", BF16), residual.stride(0)
+    _L.check(_L.load().vita_gemm_bf16(_dev(a, "a", BF16), a.stride(0), _dev(w, "w", BF16), w.stride(0),
+                                      _dev(y, "out", BF16), y.stride(0), M, N, K, epilogue, _opt(bias, "bias", BF16),
+                                      _opt(scale, "scale", BF16), r_ptr, ldr, _stream()), "vita_gemm_bf16")
+    return y
+
+
+def gemm_skinny(a: torch.Tensor, w: torch.Tensor, out_f32: bool = False) -> torch.Tensor:
+    """Logits-masked head GEMM for <= 16 selected rows."""
+    M, K = a.shape
+    N = w.shape[0]
+    if w.shape[1] != K:
+        raise RuntimeError(f"supplied weight's shape is {tuple(w.shape)}, K = {K} expected")
+    y = torch.empty((M, N), dtype=torch.float32 if out_f32 else BF16, device=a.device)
+    _L.check(_L.load().vita_gemm_skinny_bf16(_dev(a, "a", BF16), a.stride(0), _dev(w, "w", BF16), w.stride(0),
+                                             _dev(y, "out"), y.stride(0), M, N, K, int(out_f32), _stream()),
+             "vita_gemm_skinny_bf16")
+    return y
+
+
+# ------------------------------------------------------------------------------------------------
+# attention
+# ------------------------------------------------------------------------------------------------
+def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, causal: bool, softmax_scale: Optional[float] = None,
+               chunk_len: Optional[int] = None, q_chunk_gid: Optional[Sequence[int]] = None,
+               kv_chunk_gid: Optional[Sequence[int]] = None, kv_chunk_row: Optional[Sequence[int]] = None,
+               out: Optional[torch.Tensor] = None, return_lse: bool = False):
+    """q [B, Sq, Hq, D] or grouped [B, Sq, Hkv, G, D]; k/v [B, Sk, Hkv, D] — *views* (any batch / row /
+    head / group stride, D contiguous).  Returns o [B, Sq, Hq, D] (contiguous unless `out` given).
+
+    Chunk geometry (zig-zag context parallelism): Sq = len(q_chunk_gid) * chunk_len local rows,
+    kv chunk j starts at row kv_chunk_row[j] of k/v.  Defaults: one chunk, gid 0."""
+    if q.dim() == 5:
+        B, Sq, Hkv_q, G, D = q.shape
+        Hq = Hkv_q * G
+        q_bs, q_rs, q_gs, q_hs = q.stride(0), q.stride(1), q.stride(2), q.stride(3)
+    elif q.dim() == 4:
+        B, Sq, Hq, D = q.shape
+        q_bs, q_rs, q_hs, q_gs = q.stride(0), q.stride(1), q.stride(2), 0
+    else:
+        raise ValueError("q must be [B, S, H, D] or [B, S, Hkv, G, D]")
+    if k.dim() != 4 or v.dim() != 4:
+        raise ValueError("k, v must be [B, S, Hkv, D]")
+    _, Sk, Hkv, _ = k.shape
+    if q.stride(-1) != 1 or k.stride(3) != 1 or v.stride(3) != 1:
+        raise ValueError("head_dim must be contiguous")
+    if chunk_len is None:
+        if Sq != Sk and causal:
+            raise ValueError("causal attention without chunk geometry needs Sq == Sk")
+        chunk_len = max(Sq, Sk)
+        qg, kg, kr = [0], [0], [0]
+        q_valid, kv_valid = Sq, Sk
+    else:
+        qg, kg, kr = list(q_chunk_gid), list(kv_chunk_gid), list(kv_chunk_row)
+        if Sq != len(qg) * chunk_len:
+            raise ValueError("Sq must equal len(q_chunk_gid) * chunk_len")
+        q_valid = kv_valid = chunk_len
+    o = torch.empty((B, Sq, Hq, D), dtype=BF16, device=q.device) if out is None else out
+    lse = torch.empty((B, Hq, Sq), dtype=torch.float32, device=q.device) if return_lse else None
+    p = AttnParams()
+    p.q, p.q_batch_stride, p.q_row_stride, p.q_head_stride, p.q_group_stride = _dev(q, "q", BF16), q_bs, q_rs, q_hs, q_gs
+    p.k, p.k_batch_stride, p.k_row_stride, p.k_head_stride = _dev(k, "k", BF16), k.stride(0), k.stride(1), k.stride(2)
+    p.v, p.v_batch_stride, p.v_row_stride, p.v_head_stride = _dev(v, "v", BF16), v.stride(0), v.stride(1), v.stride(2)
+    p.o, p.o_batch_stride, p.o_row_stride, p.o_head_stride, p.o_group_stride = (
+        _dev(o, "out", BF16), o.stride(0), o.stride(1), o.stride(2), 0)
+    p.lse = _opt(lse, "lse")
+    p.batch, p.n_q_heads, p.n_kv_heads, p.head_dim = B, Hq, Hkv, D
+    p.chunk_len, p.q_valid, p.kv_valid = chunk_len, q_valid, kv_valid
+    p.n_q_chunks, p.n_kv_chunks = len(qg), len(kg)
+    qg_a = (C.c_int32 * len(qg))(*qg)
+    kg_a = (C.c_int32 * len(kg))(*kg)
+    kr_a = (C.c_int64 * len(kr))(*kr)
+    p.q_chunk_gid, p.kv_chunk_gid, p.kv_chunk_row = qg_a, kg_a, kr_a
+    p.causal = int(causal)
+    p.softmax_scale = float(softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(D))
+    _L.check(_L.load().vita_flash_attn_fwd(C.byref(p), _stream()), "vita_flash_attn_fwd")
+    return (o, lse) if return_lse else o
+
+
+# ------------------------------------------------------------------------------------------------
+# ViT helpers
+# ------------------------------------------------------------------------------------------------
+def patchify14(images: torch.Tensor, k_pad: int = 640) -> torch.Tensor:
+    n, c, H, W = images.shape
+    if c != 3:
+        raise ValueError("images must be [n, 3, H, W]")
+    im = images.contiguous()
+    out = torch.empty((n * (H // 14) * (W // 14), k_pad), dtype=BF16, device=im.device)
+    _L.check(_L.load().vita_patchify14(_dev(im, "images", BF16), _dev(out, "patches"), n, H, W, k_pad, _stream()),
+             "vita_patchify14")
+    return out
+
+
+def vit_assemble(patch_embeds: torch.Tensor, cls_token: Optional[torch.Tensor], pos_emb: torch.Tensor, n: int,
+                 n_patches: int) -> torch.Tensor:
+    hidden = patch_embeds.shape[-1]
+    has_cls = cls_token is not None
+    x = torch.empty((n, n_patches + int(has_cls), hidden), dtype=BF16, device=patch_embeds.device)
+    _L.check(_L.load().vita_vit_assemble(_dev(patch_embeds.contiguous(), "patch_embeds", BF16),
+                                         _opt(cls_token, "cls_token", BF16), _dev(pos_emb.contiguous(), "pos_emb", BF16),
+                                         _dev(x, "x"), n, n_patches, hidden, int(has_cls), _stream()),
+             "vita_vit_assemble")
+    return x
+
+
+def pixel_shuffle_ln(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], grid: int, has_cls: bool,
+                     eps: float = 1e-5) -> torch.Tensor:
+    n, _, hidden = x.shape
+    xc = x.contiguous()
+    y = torch.empty((n, (grid // 2) ** 2, hidden * 4), dtype=BF16, device=x.device)
+    _L.check(_L.load().vita_pixel_shuffle_ln(_dev(xc, "x", BF16), _dev(weight, "weight", BF16), _opt(bias, "bias", BF16),
+                                             _dev(y, "y"), n, grid, hidden, int(has_cls), float(eps), _stream()),
+             "vita_pixel_shuffle_ln")
+    return y

@@ -1,0 +1,64 @@
+"""Minimal context-parallel process-group state (the `mpu` accessors the hot path reads).
+
+Mirrors the names of megatron.core.parallel_state that the reference calls on this path
+(M/training/utils.py:276, M/core/models/common/embeddings/rotary_pos_embedding.py:37-38,
+M/inference/text_generation/generation.py:518-519,543-544).  One process per GPU; the group is a
+torch.distributed group (backend "nccl" = RCCL on ROCm, "gloo" in the CPU tests).
+TP/PP are 1 on this path (BASELINE configs 2-4); CP = world size unless told otherwise.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch.distributed as dist
+
+import threading
+
+
+class _State(threading.local):
+    """Thread-local so that the single-GPU tests can run several simulated ranks as threads."""
+    group = None
+    size = 1
+    rank = 0
+
+
+_S = _State()
+
+
+def initialize_model_parallel(context_parallel_size: Optional[int] = None, group=None) -> None:
+    """Create the context-parallel group over all ranks (or adopt `group`)."""
+    if not dist.is_available() or not dist.is_initialized():
+        _S.group, _S.size, _S.rank = None, 1, 0
+        return
+    world = dist.get_world_size()
+    cp = world if context_parallel_size is None else context_parallel_size
+    if cp != world:
+        raise ValueError("this path runs TP=PP=DP=1: context_parallel_size must equal the world size")
+    _S.group = group if group is not None else dist.group.WORLD
+    _S.size, _S.rank = cp, dist.get_rank()
+
+
+def set_context_parallel_state(size: int, rank: int, group=None) -> None:
+    """Explicit override (tests / embedding in a host framework that owns the groups)."""
+    _S.group, _S.size, _S.rank = group, size, rank
+
+
+def destroy_model_parallel() -> None:
+    _S.group, _S.size, _S.rank = None, 1, 0
+
+
+def get_context_parallel_world_size() -> int:
+    return _S.size
+
+
+def get_context_parallel_rank() -> int:
+    return _S.rank
+
+
+def get_context_parallel_group():
+    return _S.group
+
+
+def zigzag_chunk_ids(cp_size: int, cp_rank: int):
+    """Chunks of the 2*CP-chunk sequence view owned by `cp_rank` (M/training/utils.py:329-341)."""
+    return [cp_rank, 2 * cp_size - cp_rank - 1]

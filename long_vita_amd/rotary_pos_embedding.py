@@ -1,0 +1,60 @@
+"""RoPE host side — mirror of M/core/models/common/embeddings/rotary_pos_embedding.py.
+
+The reference materialises `emb = cat(freqs, freqs)` [s, b, 1, dim] in fp32 and every layer
+recomputes cos/sin from it (:200-201).  Here the table is built ONCE per forward on the device as
+bf16 cos/sin [s, dim/2] (vita_rope_table) for the rank's *global* positions, which folds the
+position_ids gather (:114-117) and the zig-zag CP slice (:36-47, :119-121) into an index choice.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+
+from . import ops, parallel_state as mpu
+from .training_utils import get_position_ids, zigzag_slice
+
+
+class RotaryEmbedding:
+    def __init__(self, kv_channels: int, rotary_percent: float = 1.0, rotary_interleaved: bool = False,
+                 seq_len_interpolation_factor: Optional[float] = None, rotary_base: float = 10000, device="cuda"):
+        if rotary_interleaved or seq_len_interpolation_factor is not None or rotary_percent != 1.0:
+            raise NotImplementedError("only full, non-interleaved RoPE is on the Long-VITA path")
+        self.dim = kv_channels
+        self.inv_freq = ops.rope_inv_freq(kv_channels, rotary_base, device)       # :74-80
+
+    def positions(self, max_seq_len: int, offset: int = 0) -> torch.Tensor:
+        """Global positions of this rank's rows, int64 [s_local]."""
+        pid = get_position_ids()
+        dev = self.inv_freq.device
+        if pid is not None:                                                      # [s, b] (b == 1)
+            pos = pid.reshape(pid.shape[0], -1)[:, 0].to(dev)
+        else:
+            pos = torch.arange(max_seq_len, dtype=torch.int64, device=dev) + offset
+        cp = mpu.get_context_parallel_world_size()
+        if cp > 1:
+            pos = zigzag_slice(pos, cp, mpu.get_context_parallel_rank(), seq_dim=0)
+        return pos.contiguous()
+
+    def forward(self, max_seq_len: int, offset: int = 0):
+        """-> (cos, sin) bf16 [s_local, dim/2]."""
+        return ops.rope_table(self.positions(max_seq_len, offset), self.inv_freq)
+
+    __call__ = forward
+
+    @staticmethod
+    def get_rotary_seq_len(local_rows: int) -> int:
+        """:124-156 — rows on this rank x context_parallel_size."""
+        return local_rows * mpu.get_context_parallel_world_size()
+
+
+def apply_rotary_pos_emb(t: torch.Tensor, cos_sin, config=None, cu_seqlens=None) -> torch.Tensor:
+    """apply_rotary_pos_emb (:232-259) for t [s, b(=1), heads, d]; rotates in place and returns t."""
+    if cu_seqlens is not None:
+        raise AssertionError("thd (packed) RoPE is not on this path")
+    s, b, h, d = t.shape
+    if b != 1:
+        raise ValueError("batch must be 1 on the Long-VITA path")
+    cos, sin = cos_sin
+    ops.rope_apply_(t.view(s, h, d) if t.is_contiguous() else t[:, 0], cos, sin)
+    return t

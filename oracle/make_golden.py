@@ -1,0 +1,367 @@
+"""Generate tests/golden/*.pt by running the REFERENCE'S OWN PYTHON (read-only /root/reference)
+in this container.  Run here only — /root/reference does not exist on the GPU box:
+
+    python -m oracle.make_golden
+
+The Megatron-side modules import `megatron.*` (absent); they are imported under
+permissive stub modules so that their first-party function bodies run unmodified on CPU.
+`torch.cuda.current_device()` / `.cuda()` / `device='cuda'` are redirected to CPU for the
+duration.  Only small tensors are stored (fixtures stay < 1 MB each); big inputs are re-derived
+from seeds by the tests.  TEST INFRASTRUCTURE ONLY.
+"""
+from __future__ import annotations
+
+import contextlib
+import importlib
+import os
+import sys
+import types
+from unittest import mock
+
+import torch
+
+REF = "/root/reference"
+OUT = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests", "golden")
+
+
+# ------------------------------------------------------------------------------------------------
+# stub environment
+# ------------------------------------------------------------------------------------------------
+class _Args:
+    pass
+
+
+STATE = {"args": _Args(), "cp_size": 1, "cp_rank": 0}
+
+
+class _StubModule(types.ModuleType):
+    """Module whose unknown attributes are MagicMocks (so `from megatron.x import Y` succeeds)."""
+
+    def __getattr__(self, name):
+        if name.startswith("__"):
+            raise AttributeError(name)
+        m = mock.MagicMock(name=f"{self.__name__}.{name}")
+        setattr(self, name, m)
+        return m
+
+
+def _install_stubs():
+    names = [
+        "megatron", "megatron.training", "megatron.core", "megatron.core.mpu", "megatron.core.parallel_state",
+        "megatron.core.tensor_parallel", "megatron.core.tensor_parallel.mappings",
+        "megatron.core.tensor_parallel.utils", "megatron.core.tensor_parallel.random",
+        "megatron.core.model_parallel_config", "megatron.core.utils", "megatron.core.transformer",
+        "megatron.core.transformer.module", "megatron.core.transformer.transformer_config",
+        "megatron.core.transformer.utils", "megatron.core.dist_checkpointing",
+        "megatron.core.dist_checkpointing.mapping", "megatron.legacy", "megatron.legacy.model",
+        "megatron.legacy.model.module", "apex", "apex.multi_tensor_apply", "amp_C",
+    ]
+    for n in names:
+        if n not in sys.modules:
+            sys.modules[n] = _StubModule(n)
+    for n in names:
+        if "." in n:
+            parent, child = n.rsplit(".", 1)
+            setattr(sys.modules[parent], child, sys.modules[n])
+    sys.modules["megatron.training"].get_args = lambda: STATE["args"]
+    for mod in ("megatron.core.mpu", "megatron.core.parallel_state"):
+        m = sys.modules[mod]
+        m.get_context_parallel_world_size = lambda: STATE["cp_size"]
+        m.get_context_parallel_rank = lambda: STATE["cp_rank"]
+        m.get_tensor_model_parallel_world_size = lambda: 1
+        m.get_tensor_model_parallel_rank = lambda: 0
+    sys.modules["megatron.core"].mpu = sys.modules["megatron.core.mpu"]
+    sys.modules["megatron.core"].parallel_state = sys.modules["megatron.core.parallel_state"]
+
+    class MegatronModule(torch.nn.Module):
+        def __init__(self, config=None):
+            super().__init__()
+            self.config = config
+
+    sys.modules["megatron.core.transformer.module"].MegatronModule = MegatronModule
+
+    def prepare_input_tensors_for_wgrad_compute(grad_output, all_gathered_input):
+        # Megatron-LM core_r0.7.0 megatron/core/utils.py (published behaviour): flatten [s, b, h] -> [s*b, h]
+        if grad_output.dim() == 3:
+            grad_output = grad_output.reshape(grad_output.shape[0] * grad_output.shape[1], grad_output.shape[2])
+            all_gathered_input = all_gathered_input.reshape(
+                all_gathered_input.shape[0] * all_gathered_input.shape[1], all_gathered_input.shape[2])
+        return grad_output, all_gathered_input
+
+    sys.modules["megatron.core.utils"].prepare_input_tensors_for_wgrad_compute = prepare_input_tensors_for_wgrad_compute
+    if REF not in sys.path:
+        sys.path.insert(0, REF)
+
+
+@contextlib.contextmanager
+def cpu_as_cuda():
+    """Redirect the reference's hard-coded CUDA placement to CPU."""
+    real_arange, real_tensor, real_zeros = torch.arange, torch.tensor, torch.zeros
+
+    def strip(fn):
+        def wrapped(*a, **k):
+            if str(k.get("device", "")).startswith("cuda") or isinstance(k.get("device"), int):
+                k["device"] = "cpu"
+            k.pop("pin_memory", None)
+            return fn(*a, **k)
+        return wrapped
+
+    patches = [
+        mock.patch.object(torch, "arange", strip(real_arange)),
+        mock.patch.object(torch, "tensor", strip(real_tensor)),
+        mock.patch.object(torch, "zeros", strip(real_zeros)),
+        mock.patch.object(torch.Tensor, "cuda", lambda self, *a, **k: self),
+        mock.patch.object(torch.cuda, "current_device", lambda: "cpu"),
+    ]
+    with contextlib.ExitStack() as st:
+        for p in patches:
+            st.enter_context(p)
+        yield
+
+
+# ------------------------------------------------------------------------------------------------
+# fixtures
+# ------------------------------------------------------------------------------------------------
+def golden_cp_slice():
+    """M/training/utils.py:252-350 on three synthetic layouts (incl. SURVEY.md §9's worked example)."""
+    utils = importlib.import_module("long_vita_megatron.training.utils")
+    cases = []
+    g = torch.Generator().manual_seed(1234)
+
+    def layout(seq, n_img, tok, start, gap):
+        pos = []
+        p = start
+        for _ in range(n_img):
+            pos.append(torch.arange(p, p + tok))
+            p += tok + gap
+        assert p - gap <= seq
+        return torch.stack([torch.zeros(n_img, tok, dtype=torch.long), torch.stack(pos)])
+
+    specs = [
+        dict(name="survey_appendix", seq=16, cp=2, indices=torch.stack(
+            [torch.zeros(2, 4, dtype=torch.long), torch.tensor([[2, 3, 4, 5], [12, 13, 14, 15]])])),
+        dict(name="video_like", seq=512, cp=4, indices=layout(512, 14, 32, 1, 2)),
+        dict(name="straddle", seq=1024, cp=8, indices=layout(1024, 5, 96, 30, 70)),
+    ]
+    for sp in specs:
+        seq, cp, ind = sp["seq"], sp["cp"], sp["indices"]
+        tokens = torch.randint(0, 1000, (1, seq), generator=g)
+        images = torch.randn(ind.shape[1], 3, 2, 2, generator=g)
+        per_rank = []
+        for r in range(cp):
+            STATE["cp_size"], STATE["cp_rank"] = cp, r
+            a = STATE["args"]
+            a.reset_position_ids, a.context_parallel_size, a.seq_length = False, cp, seq
+            batch = {"tokens": tokens.clone(), "labels": tokens.clone() + 1,
+                     "position_ids": torch.arange(seq)[None].clone(),
+                     "external_images": images.clone(), "external_indices": ind.clone()}
+            with cpu_as_cuda():
+                out = utils.get_batch_on_this_cp_rank(batch)
+            per_rank.append({k: v.clone() for k, v in out.items() if v is not None})
+        cases.append(dict(name=sp["name"], seq=seq, cp=cp, tokens=tokens, images=images, indices=ind, out=per_rank))
+    a_ = torch.tensor([7, 3, 11, 5])
+    b_ = torch.tensor([1, 3, 5, 7, 9, 11])
+    with cpu_as_cuda():
+        ioab = utils.index_of_a_in_b(a_, b_)
+    torch.save(dict(cases=cases, index_of_a_in_b=dict(a=a_, b=b_, out=ioab)), os.path.join(OUT, "cp_slice.pt"))
+
+
+def golden_rope_rmsnorm():
+    rpe = importlib.import_module("long_vita_megatron.core.models.common.embeddings.rotary_pos_embedding")
+    te = importlib.import_module("long_vita_megatron.core.transformer.custom_layers.transformer_engine")
+    utils = importlib.import_module("long_vita_megatron.training.utils")
+    g = torch.Generator().manual_seed(4321)
+    out = {}
+    with cpu_as_cuda():
+        rope = rpe.RotaryEmbedding(kv_channels=128, rotary_percent=1.0, rotary_base=1000000)
+        out["inv_freq"] = rope.inv_freq.clone()
+        # plain table, CP=1
+        STATE["cp_size"], STATE["cp_rank"] = 1, 0
+        utils.set_position_ids(None)
+        emb = rope(96)
+        out["emb_cp1"] = emb.clone()
+        # CP=4 zig-zag slices
+        out["emb_cp4"] = []
+        for r in range(4):
+            STATE["cp_size"], STATE["cp_rank"] = 4, r
+            out["emb_cp4"].append(rope(96).clone())
+        # position_ids gather (packed sequences), [s, b] as set_position_ids stores it
+        STATE["cp_size"], STATE["cp_rank"] = 1, 0
+        pid = torch.cat([torch.arange(40), torch.arange(56)])[:, None]
+        utils.set_position_ids(pid)
+        out["position_ids"] = pid
+        out["emb_pid"] = rope(96).clone()
+        utils.set_position_ids(None)
+        # large positions (1M context) — table rows only
+        big = torch.tensor([0, 1, 4095, 131071, 524288, 1048575])
+        out["big_pos"] = big
+        out["emb_big"] = rope(1048576)[big].clone()
+        # apply, bf16 and fp32
+        t = torch.randn(96, 1, 6, 128, generator=g)
+        out["t"] = t
+        out["apply_fp32"] = rpe.apply_rotary_pos_emb_bshd(t, emb).clone()
+        out["apply_bf16"] = rpe.apply_rotary_pos_emb_bshd(t.bfloat16(), emb).clone()
+        # RMSNorm (PTNorm's RMSNorm), bf16 and fp32
+        x = torch.randn(33, 5120, generator=g) * 3
+        w = 1 + 0.1 * torch.randn(5120, generator=g)
+        n = te.RMSNorm(5120, eps=1e-6)
+        n.weight.data = w.clone()
+        out["rms_x"], out["rms_w"] = x, w
+        out["rms_fp32"] = n(x).detach().clone()
+        nb = te.RMSNorm(5120, eps=1e-6).bfloat16()
+        nb.weight.data = w.bfloat16()
+        out["rms_bf16"] = nb(x.bfloat16()).detach().clone()
+    torch.save(out, os.path.join(OUT, "rope_rmsnorm.pt"))
+
+
+def golden_embedding_scatter():
+    lme = importlib.import_module("long_vita_megatron.core.models.common.embeddings.language_model_embedding")
+    g = torch.Generator().manual_seed(99)
+    emb = object.__new__(lme.LanguageModelEmbedding)
+    torch.nn.Module.__init__(emb)
+    cfg = types.SimpleNamespace(fp32_residual_connection=False, sequence_parallel=False,
+                                clone_scatter_output_in_embedding=False)
+    emb.config = cfg
+    emb.word_embeddings = torch.nn.Embedding(50, 16)
+    emb.word_embeddings.weight.data = torch.randn(50, 16, generator=g)
+    emb.add_position_embedding = False
+    emb.tokentype_embeddings = None
+    emb.embedding_dropout = torch.nn.Identity()
+    STATE["cp_size"] = 1
+    ids = torch.randint(0, 50, (2, 12), generator=g)
+    feats = torch.randn(3, 4, 16, generator=g)
+    out = dict(weight=emb.word_embeddings.weight.data.clone(), ids=ids, feats=feats)
+    with torch.no_grad():
+        out["plain"] = emb(ids, None).clone()
+        ind = torch.stack([torch.tensor([[0] * 4, [1] * 4, [1] * 4]),
+                           torch.tensor([[1, 2, 3, 4], [0, 1, 2, 3], [8, 9, 10, 11]])])
+        out["indices"] = ind
+        out["with_indices"] = emb(ids, None, external_feature_dict={"features": feats, "indices": ind}).clone()
+        out["with_pre_len"] = emb(ids[:1].repeat(3, 1), None,
+                                  external_feature_dict={"features": feats, "pre_len": 5}).clone()
+        src = torch.stack([torch.tensor([0, 0, 2, 2, 2]), torch.tensor([1, 3, 0, 1, 2])])
+        tgt = torch.stack([torch.tensor([0, 0, 1, 1, 1]), torch.tensor([5, 6, 0, 1, 11])])
+        out["src"], out["tgt"] = src, tgt
+        out["with_src_tgt"] = emb(ids, None, external_feature_dict={"features": feats, "src_indices": src,
+                                                                      "tgt_indices": tgt}).clone()
+    torch.save(out, os.path.join(OUT, "embedding_scatter.pt"))
+
+
+def golden_masked_linear():
+    layers = importlib.import_module("long_vita_megatron.core.tensor_parallel.layers")
+    g = torch.Generator().manual_seed(7)
+    s, b, c, o = 24, 1, 32, 40
+    x = torch.randn(s, b, c, generator=g, requires_grad=True)
+    w = torch.randn(o, c, generator=g, requires_grad=True)
+    mask = torch.zeros(b, s, dtype=torch.bool)
+    mask[0, [3, 4, 11, 23]] = True
+    fn = layers.LinearWithGradAccumulationAndAsyncCommunication
+    y = fn.apply(x, w, None, False, False, False, None, mask)
+    go = torch.randn(y.shape, generator=g)
+    y.backward(go)
+    out = dict(x=x.detach().clone(), w=w.detach().clone(), mask=mask, y=y.detach().clone(), go=go,
+               dx=x.grad.clone(), dw=w.grad.clone())
+    # frozen-weight path (layers.py:288-363), forward only
+    wf = w.detach().clone()
+    wf.requires_grad = False
+    inp = x.detach()
+    m = mask
+    sel = torch.masked_select(inp, m.transpose(0, 1).unsqueeze(2)).reshape(-1, b, c)   # layers.py:344-348 verbatim shape logic
+    out["y_frozen"] = torch.matmul(sel, wf.t())
+    torch.save(out, os.path.join(OUT, "masked_linear.pt"))
+
+
+def golden_hf_vit():
+    """The reference's HF InternVisionModel + ResamplerProjector imported UNMODIFIED
+    (H/models/long_vita_qwen2_intern/modeling_intern_vit.py, resampler_projector.py), fp32 on CPU,
+    seeded weights, 2 layers and the full 24 layers, one 448x448 frame."""
+    import json
+
+    import transformers  # noqa: F401  (before stubbing timm)
+    timm = types.ModuleType("timm"); timm_m = types.ModuleType("timm.models"); timm_l = types.ModuleType("timm.models.layers")
+
+    class DropPath(torch.nn.Identity):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+    timm_l.DropPath = DropPath
+    sys.modules.update({"timm": timm, "timm.models": timm_m, "timm.models.layers": timm_l})
+    # bypass long_vita/__init__.py (imports cv2): register empty parents
+    for n in ["long_vita", "long_vita.models", "long_vita.models.long_vita_qwen2_intern"]:
+        m = types.ModuleType(n)
+        m.__path__ = [os.path.join(REF, *n.split("."))]
+        sys.modules[n] = m
+    civ = importlib.import_module("long_vita.models.long_vita_qwen2_intern.configuration_intern_vit")
+    miv = importlib.import_module("long_vita.models.long_vita_qwen2_intern.modeling_intern_vit")
+    rp = importlib.import_module("long_vita.models.long_vita_qwen2_intern.resampler_projector")
+    cfg_json = json.load(open(os.path.join(REF, "long_vita/models/long_vita_qwen2_intern/config_14B.json")))
+
+    from oracle import vit as ovit
+
+    out = {}
+    for tag, nl in (("l2", 2), ("l24", 24)):
+        vcfg = dict(cfg_json["visual"]); vcfg["num_hidden_layers"] = nl; vcfg["use_flash_attn"] = False
+        hcfg = civ.InternVisionConfig(**vcfg)
+        model = miv.InternVisionModel(hcfg).eval().float()
+        proj = rp.ResamplerProjector(types.SimpleNamespace(hidden_size=5120), hcfg).eval().float()
+        ocfg = ovit.ViTConfig(num_layers=nl)
+        p = ovit.init_vit_params(ocfg, seed=1234, dtype=torch.float32)
+        # the bf16-rounded values are what both sides use
+        p = _tree_map(p, lambda t: t.bfloat16().float())
+        sd = model.state_dict()
+        sd["embeddings.class_embedding"] = p["cls"]
+        sd["embeddings.patch_embedding.weight"] = p["conv_w"]; sd["embeddings.patch_embedding.bias"] = p["conv_b"]
+        sd["embeddings.position_embedding"] = p["pos"][None]
+        for i, lp in enumerate(p["layers"]):
+            pre = f"encoder.layers.{i}."
+            sd[pre + "attn.qkv.weight"] = ovit.megatron_qkv_to_hf(lp["qkv_w"], 16, 64)
+            sd[pre + "attn.qkv.bias"] = ovit.megatron_qkv_to_hf(lp["qkv_b"], 16, 64)
+            sd[pre + "attn.proj.weight"] = lp["proj_w"]; sd[pre + "attn.proj.bias"] = lp["proj_b"]
+            sd[pre + "mlp.fc1.weight"] = lp["fc1_w"]; sd[pre + "mlp.fc1.bias"] = lp["fc1_b"]
+            sd[pre + "mlp.fc2.weight"] = lp["fc2_w"]; sd[pre + "mlp.fc2.bias"] = lp["fc2_b"]
+            sd[pre + "norm1.weight"] = lp["ln1_w"]; sd[pre + "norm1.bias"] = lp["ln1_b"]
+            sd[pre + "norm2.weight"] = lp["ln2_w"]; sd[pre + "norm2.bias"] = lp["ln2_b"]
+            sd[pre + "ls1"] = lp["ls1"]; sd[pre + "ls2"] = lp["ls2"]
+        model.load_state_dict(sd)
+        psd = proj.state_dict()
+        psd["pre_proj_layernorm.weight"] = p["proj_ln_w"]; psd["pre_proj_layernorm.bias"] = p["proj_ln_b"]
+        psd["mlp.0.weight"] = p["proj_fc1"]; psd["mlp.2.weight"] = p["proj_fc2"]
+        proj.load_state_dict(psd)
+        g = torch.Generator().manual_seed(2024)
+        images = torch.randn(1, 3, 448, 448, generator=g).bfloat16().float()
+        with torch.no_grad():
+            hid = model(images).last_hidden_state            # [1, 1025, 1024]
+            feat = proj(hid[:, 1:, :])                       # [1, 256, 5120]   (modeling_long_vita.py:91-98)
+        out[tag] = dict(hidden_sub=hid[:, ::41, ::16].clone(), feat_sub=feat[:, ::8, ::40].clone(),
+                        hidden_sum=hid.double().sum(), feat_sum=feat.double().sum(),
+                        hidden_absmean=hid.abs().mean(), feat_absmean=feat.abs().mean())
+    out["image_seed"] = 2024
+    out["weight_seed"] = 1234
+    torch.save(out, os.path.join(OUT, "hf_vit.pt"))
+
+
+def _tree_map(p, f):
+    if isinstance(p, dict):
+        return {k: _tree_map(v, f) for k, v in p.items()}
+    if isinstance(p, list):
+        return [_tree_map(v, f) for v in p]
+    return f(p)
+
+
+def main():
+    os.makedirs(OUT, exist_ok=True)
+    _install_stubs()
+    golden_cp_slice()
+    print("cp_slice ok")
+    golden_rope_rmsnorm()
+    print("rope_rmsnorm ok")
+    golden_embedding_scatter()
+    print("embedding_scatter ok")
+    golden_masked_linear()
+    print("masked_linear ok")
+    golden_hf_vit()
+    print("hf_vit ok")
+
+
+if __name__ == "__main__":
+    main()

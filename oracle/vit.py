@@ -1,0 +1,134 @@
+"""InternViT-300M + pixel-shuffle projector restated in Megatron weight layout
+(SURVEY.md §8a rows a3-a6).  TEST INFRASTRUCTURE ONLY.
+
+Arithmetic follows the dtype of the tensors handed in: fp32 tensors give the exact-math
+reference, bf16 tensors give the per-op-rounded chain the GPU path of the reference runs
+(GEMMs accumulate in fp32 and round once, elementwise ops round per op)."""
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass
+
+import torch
+import torch.nn.functional as F
+
+from .attention import core_attention
+from .glue import pixel_shuffle
+
+
+@dataclass
+class ViTConfig:
+    """M/pretrain_long_vita.py:183-223 (get_vision_model_args_intern_300m) + config_14B.json:2-30."""
+    num_layers: int = 24
+    hidden: int = 1024
+    heads: int = 16
+    head_dim: int = 64
+    ffn: int = 4096
+    patch: int = 14
+    image: int = 448
+    ln_eps: float = 1e-6        # block norms, SURVEY.md §9 quirk 4
+    proj_ln_eps: float = 1e-5   # bare torch.nn.LayerNorm(4096)
+    llm_hidden: int = 5120
+    add_class_token: bool = True
+
+    @property
+    def grid(self):
+        return self.image // self.patch
+
+    @property
+    def seq(self):
+        return self.grid ** 2 + (1 if self.add_class_token else 0)
+
+
+def linear(x, w, b=None):
+    """fp32-accumulated GEMM rounded once to x.dtype (torch.matmul on GPU / TE linear)."""
+    y = x.float() @ w.float().t()
+    if b is not None:
+        y = y + b.float()
+    return y.to(x.dtype)
+
+
+def init_vit_params(cfg: ViTConfig, seed: int = 1234, dtype=torch.bfloat16):
+    """Seeded synthetic weights in MEGATRON layout: qkv rows per head [q_h, k_h, v_h]
+    (L/ckpt_converter_intern_vit.py:54-66).  Linears N(0, 0.02), norms 1/0, LayerScale 0.1."""
+    g = torch.Generator().manual_seed(seed)
+
+    def rn(*shape, std=0.02):
+        return (torch.randn(*shape, generator=g) * std).to(dtype)
+
+    p = {
+        "conv_w": rn(cfg.hidden, 3, cfg.patch, cfg.patch), "conv_b": rn(cfg.hidden),
+        "cls": rn(1, 1, cfg.hidden, std=1.0), "pos": rn(cfg.seq, cfg.hidden, std=0.02),
+        "layers": [],
+        "proj_ln_w": torch.ones(4 * cfg.hidden, dtype=dtype), "proj_ln_b": torch.zeros(4 * cfg.hidden, dtype=dtype),
+        "proj_fc1": rn(cfg.hidden, 4 * cfg.hidden), "proj_fc2": rn(cfg.llm_hidden, cfg.hidden),
+    }
+    for _ in range(cfg.num_layers):
+        p["layers"].append({
+            "ln1_w": torch.ones(cfg.hidden, dtype=dtype), "ln1_b": torch.zeros(cfg.hidden, dtype=dtype),
+            "qkv_w": rn(3 * cfg.hidden, cfg.hidden), "qkv_b": rn(3 * cfg.hidden),
+            "proj_w": rn(cfg.hidden, cfg.hidden), "proj_b": rn(cfg.hidden),
+            "ls1": torch.full((cfg.hidden,), 0.1, dtype=dtype),
+            "ln2_w": torch.ones(cfg.hidden, dtype=dtype), "ln2_b": torch.zeros(cfg.hidden, dtype=dtype),
+            "fc1_w": rn(cfg.ffn, cfg.hidden), "fc1_b": rn(cfg.ffn),
+            "fc2_w": rn(cfg.hidden, cfg.ffn), "fc2_b": rn(cfg.hidden),
+            "ls2": torch.full((cfg.hidden,), 0.1, dtype=dtype),
+        })
+    return p
+
+
+def megatron_qkv_to_hf(w_or_b: torch.Tensor, heads: int, head_dim: int) -> torch.Tensor:
+    """Inverse of the converter permutation L/ckpt_converter_intern_vit.py:54-66,100-107:
+    Megatron rows [h][q|k|v][d]  ->  HF rows [q|k|v][h][d]."""
+    rest = w_or_b.shape[1:]
+    return w_or_b.view(heads, 3, head_dim, *rest).transpose(0, 1).reshape(3 * heads * head_dim, *rest)
+
+
+def vit_embed(images, p, cfg: ViTConfig):
+    """M/core/models/vision/intern_vit_model.py:203-216: conv14/14 + cls + learned pos-emb -> [b, s, h]."""
+    x = F.conv2d(images.float(), p["conv_w"].float(), p["conv_b"].float(), stride=cfg.patch).to(images.dtype)
+    x = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)
+    if cfg.add_class_token:
+        x = torch.cat([p["cls"].expand(x.shape[0], -1, -1).to(x.dtype), x], dim=1)
+    return x + p["pos"][None].to(x.dtype)
+
+
+def vit_layer(x, lp, cfg: ViTConfig):
+    """InternViTTransformerLayer.forward, intern_vit_model.py:32-89; x [b, s, h].
+    QKV split per head [q, k, v] (Megatron SelfAttention with ng == np)."""
+    b, s, h = x.shape
+    res = x
+    y = F.layer_norm(x.float(), (h,), lp["ln1_w"].float(), lp["ln1_b"].float(), cfg.ln_eps).to(x.dtype)
+    qkv = linear(y, lp["qkv_w"], lp["qkv_b"]).view(b, s, cfg.heads, 3 * cfg.head_dim)
+    q, k, v = torch.split(qkv, cfg.head_dim, dim=-1)
+    ctx = core_attention(q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1), causal=False)  # [s, b, h]
+    out = linear(ctx.transpose(0, 1), lp["proj_w"], lp["proj_b"])
+    x = res + out * lp["ls1"].to(x.dtype)
+    res = x
+    y = F.layer_norm(x.float(), (h,), lp["ln2_w"].float(), lp["ln2_b"].float(), cfg.ln_eps).to(x.dtype)
+    y = linear(y, lp["fc1_w"], lp["fc1_b"])
+    y = F.gelu(y.float()).to(x.dtype)
+    y = linear(y, lp["fc2_w"], lp["fc2_b"])
+    return res + y * lp["ls2"].to(x.dtype)
+
+
+def vit_project(x, p, cfg: ViTConfig):
+    """forward_downsample + forward_projection, M/pretrain_long_vita.py:452-483."""
+    if cfg.add_class_token:
+        x = x[:, 1:, :]
+    n = x.shape[0]
+    x = x.reshape(n, cfg.grid, cfg.grid, -1)
+    x = pixel_shuffle(x, 0.5)
+    x = x.reshape(n, -1, x.shape[-1])
+    y = F.layer_norm(x.float(), (x.shape[-1],), p["proj_ln_w"].float(), p["proj_ln_b"].float(), cfg.proj_ln_eps).to(x.dtype)
+    y = linear(y, p["proj_fc1"])
+    y = F.gelu(y.float()).to(x.dtype)
+    return linear(y, p["proj_fc2"])
+
+
+def vision_model(images, p, cfg: ViTConfig):
+    """MegatronVisionModel.forward_once (M/pretrain_long_vita.py:485-520): [N,3,H,W] -> [N,256,5120]."""
+    x = vit_embed(images, p, cfg)
+    for lp in p["layers"]:
+        x = vit_layer(x, lp, cfg)
+    return vit_project(x, p, cfg)

@@ -1,0 +1,210 @@
+"""CPU-side checks (no GPU): the C-ABI library builds, loads and exports every symbol the header
+declares; host logic (patch manager, parallel state, sync_output over gloo world_size 2); oracle
+self-consistency (restated decoder == transformers Qwen2, zig-zag CP == monolithic)."""
+import os
+import re
+import socket
+import subprocess
+import sys
+import types
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+# ---------------------------------------------------------------------------------------------
+def test_library_builds_and_exports_every_declared_symbol():
+    from long_vita_amd import lib
+    lib.build()
+    declared = set(re.findall(r"\b(vita_[a-z0-9_]+)\s*\(", open(lib.HEADER_PATH).read()))
+    declared -= {"vita_attn_params"}
+    assert declared == set(lib.PROTOTYPES), declared ^ set(lib.PROTOTYPES)
+    handle = lib.load()                                  # resolves + type-annotates every symbol
+    assert handle.vita_abi_version() == 1
+    assert handle.vita_error_string(-2).decode().startswith("shape")
+    out = subprocess.run(["nm", "-D", "--defined-only", lib.LIB_PATH], capture_output=True, text=True).stdout
+    exported = set(re.findall(r" T (vita_[a-z0-9_]+)", out))
+    assert declared <= exported
+
+
+def test_product_path_has_no_cpu_fallback_and_does_not_import_oracle():
+    from long_vita_amd import ops
+    with pytest.raises(RuntimeError, match="no CPU fallback"):
+        ops.rmsnorm(torch.zeros(2, 64, dtype=torch.bfloat16), torch.ones(64, dtype=torch.bfloat16))
+    pkg = os.path.join(ROOT, "long_vita_amd")
+    for fn in os.listdir(pkg):
+        if fn.endswith(".py"):
+            src = open(os.path.join(pkg, fn)).read()
+            assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), fn
+
+
+def test_attn_params_struct_matches_header_field_order():
+    from long_vita_amd import lib
+    hdr = open(lib.HEADER_PATH).read()
+    body = hdr[hdr.index("typedef struct {"): hdr.index("} vita_attn_params;")]
+    body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
+    names = []
+    for decl in body.split(";"):
+        decl = decl.replace("typedef struct {", "").strip()
+        if not decl:
+            continue
+        first, *rest = decl.split(",")
+        names.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", first)[-1])
+        names += [re.findall(r"[A-Za-z_][A-Za-z0-9_]*", r)[-1] for r in rest]
+    assert names == [f[0] for f in lib.AttnParams._fields_]
+
+
+# ---------------------------------------------------------------------------------------------
+def test_patch_manager_semantics():
+    from long_vita_amd.patch_utils import MindSpeedPatchesManager as aspm, Patch
+    aspm.patches_info = {}
+    mod = types.ModuleType("vita_fake_target")
+    mod.f = lambda x: x + 1
+
+    class K:
+        def m(self, x):
+            return x * 2
+    mod.K = K
+    sys.modules["vita_fake_target"] = mod
+    holder = types.ModuleType("vita_fake_holder")
+    holder.f = mod.f                                             # `from vita_fake_target import f`
+    sys.modules["vita_fake_holder"] = holder
+
+    aspm.register_patch("vita_fake_target.f", lambda x: x + 100)
+    with pytest.raises(RuntimeError):
+        aspm.register_patch("vita_fake_target.f", lambda x: x)   # second outright patch
+    aspm.register_patch("vita_fake_target.f", lambda x: x + 200, force_patch=True)
+
+    def double_wrapper(fn):
+        return lambda self, x: fn(self, x) * 10
+    aspm.register_patch("vita_fake_target.K.m", double_wrapper)  # name ends with "wrapper" -> decorates
+    aspm.register_patch("vita_missing_pkg.sub.g", None, create_dummy=True)
+    aspm.apply_patches()
+    assert mod.f(1) == 201 and holder.f(1) == 201                # identity-propagated
+    assert mod.K().m(3) == 60
+    with pytest.raises(RuntimeError, match="no exist"):
+        sys.modules["vita_missing_pkg.sub"].g()
+    with pytest.raises(ModuleNotFoundError):
+        Patch("vita_other_missing.x", lambda: 0, False).apply_patch()
+    for k in ("vita_fake_target", "vita_fake_holder", "vita_missing_pkg", "vita_missing_pkg.sub"):
+        sys.modules.pop(k, None)
+    aspm.patches_info = {}
+
+
+def test_adaptor_registers_reference_targets_with_dummy_megatron():
+    """With fabricated megatron modules the adaptor lands its replacements on the reference's dotted
+    names (M/megatron_adaptor.py:21-22,93-94,105-106)."""
+    import long_vita_amd.megatron_adaptor as ad
+    from long_vita_amd.patch_utils import MindSpeedPatchesManager as aspm
+    assert not ad.APPLIED                                         # no Megatron in this container
+    aspm.patches_info = {}
+    try:
+        dpa = types.ModuleType("megatron.core.transformer.dot_product_attention")
+
+        class DotProductAttention:
+            def forward(self, *a, **k):
+                return "orig"
+        dpa.DotProductAttention = DotProductAttention
+        for name in ["megatron", "megatron.core", "megatron.core.transformer"]:
+            sys.modules[name] = types.ModuleType(name)
+        sys.modules["megatron.core.transformer.dot_product_attention"] = dpa
+        sys.modules["megatron.core.transformer"].dot_product_attention = dpa
+        sys.modules["megatron.core"].transformer = sys.modules["megatron.core.transformer"]
+        sys.modules["megatron"].core = sys.modules["megatron.core"]
+        assert ad.exe_adaptation(create_dummy=True)
+        from long_vita_amd.layers import ColumnParallelLinear
+        assert sys.modules["megatron.core.tensor_parallel.layers"].ColumnParallelLinear is ColumnParallelLinear
+        assert DotProductAttention.forward.__name__ == "forward" and DotProductAttention.forward is not None
+        assert DotProductAttention.forward.__wrapped__.__qualname__.endswith("DotProductAttention.forward")
+    finally:
+        for k in [k for k in sys.modules if k == "megatron" or k.startswith("megatron.")]:
+            sys.modules.pop(k)
+        aspm.patches_info = {}
+
+
+# ---------------------------------------------------------------------------------------------
+_GLOO_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["VITA_ROOT"])
+from long_vita_amd import generation, parallel_state as mpu
+from oracle import glue
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+mpu.initialize_model_parallel()
+cp, r = mpu.get_context_parallel_world_size(), mpu.get_context_parallel_rank()
+assert (cp, r) == (dist.get_world_size(), dist.get_rank())
+V = 11
+# rank r "computed" logits for its two zig-zag halves: value = chunk id
+ids = mpu.zigzag_chunk_ids(cp, r)
+local = torch.stack([torch.full((V,), float(i)) for i in ids])[None]          # [1, 2, V]
+out = generation.sync_output(local)
+assert out.shape == (1, 2 * cp, V)
+assert torch.equal(out[0, :, 0], torch.arange(2 * cp, dtype=torch.float32)), out[0, :, 0]
+assert glue.sync_output_order(cp) == sorted(range(2 * cp), key=lambda j: [i for q in range(cp) for i in mpu.zigzag_chunk_ids(cp, q)][j])
+# logit-mask rule vs oracle restatement on every context length
+toks = torch.zeros(1, 16, dtype=torch.long)
+for ctx in range(1, 16 * cp):
+    for compat in (True, False):
+        m, blk = generation.build_logit_mask(toks, ctx, compat)
+        pos, b2 = glue.cp_logit_mask_positions(ctx, 16, cp, compat)
+        assert m[0].nonzero().flatten().tolist() == pos and blk == b2, (ctx, compat)
+dist.barrier()
+dist.destroy_process_group()
+print("OK", r)
+"""
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def test_sync_output_and_parallel_state_gloo_world2(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   VITA_ROOT=ROOT)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    for p in procs:
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0 and "OK" in out, out
+
+
+# ---------------------------------------------------------------------------------------------
+def test_oracle_decoder_matches_transformers_qwen2():
+    """Restated Megatron-layout decoder (fp32) == transformers Qwen2ForCausalLM on converted weights
+    (SURVEY.md §8c cross-checks iv, v: RoPE theta=1e6 convention, RMSNorm, QKV group layout)."""
+    from transformers import Qwen2Config, Qwen2ForCausalLM
+
+    from oracle import llm as ollm
+    cfg = ollm.LLMConfig(num_layers=2, hidden=256, heads=8, kv_groups=2, head_dim=32, ffn=512, vocab=300)
+    p = ollm.init_llm_params(cfg, seed=3, dtype=torch.float32, std=0.05)
+    hf = Qwen2ForCausalLM(Qwen2Config(vocab_size=300, hidden_size=256, intermediate_size=512, num_hidden_layers=2,
+                                      num_attention_heads=8, num_key_value_heads=2, rms_norm_eps=1e-6,
+                                      rope_theta=1e6, max_position_embeddings=4096, tie_word_embeddings=False,
+                                      attn_implementation="eager")).eval()
+    missing, unexpected = hf.load_state_dict(ollm.to_hf_state_dict(p, cfg), strict=False)
+    assert not unexpected and all("rotary" in m or "inv_freq" in m for m in missing), (missing, unexpected)
+    tokens = torch.randint(0, 300, (1, 96), generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        ref = hf(tokens).logits
+    out = ollm.prefill_logits(tokens, p, cfg, range(96))
+    torch.testing.assert_close(out, ref, rtol=2e-4, atol=2e-4)
+
+
+def test_oracle_cp_prefill_equals_cp1():
+    from oracle import glue, llm as ollm
+    cfg = ollm.LLMConfig(num_layers=2, hidden=128, heads=4, kv_groups=2, head_dim=32, ffn=256, vocab=200)
+    p = ollm.init_llm_params(cfg, seed=4, dtype=torch.float32, std=0.05)
+    S, cp = 64, 4
+    tokens = torch.randint(0, 200, (1, S), generator=torch.Generator().manual_seed(2))
+    full = ollm.prefill_logits(tokens, p, cfg, range(S))[0]                     # [S, V]
+    outs = ollm.prefill_logits_cp(tokens, p, cfg, cp, [range(S // cp)] * cp)
+    for r in range(cp):
+        torch.testing.assert_close(outs[r][0], glue.zigzag_slice(full[None], cp, r)[0], rtol=1e-4, atol=1e-4)

@@ -1,0 +1,223 @@
+"""End-to-end parity of the HIP path (ViT -> scatter -> decoder -> masked head, CP = 1 and simulated
+CP > 1) against the CPU oracle and the fixtures produced by the reference's own code."""
+import threading
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from conftest import load_golden  # noqa: E402
+from oracle import glue, llm as ollm, vit as ovit  # noqa: E402
+
+DEV = "cuda"
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.fixture(scope="module")
+def amd():
+    from long_vita_amd import generation, gpt_vl_model, ops, parallel_state, synthetic, vision
+    ops._L.load(allow_build=False)
+    return dict(ops=ops, vision=vision, gpt=gpt_vl_model, gen=generation, mpu=parallel_state, syn=synthetic)
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("nl,tag", [(2, "l2"), (24, "l24")])
+def test_vit_vs_oracle_and_reference_fixture(amd, nl, tag):
+    """HIP ViT+projector (bf16) vs (a) the bf16-rounding oracle on the same weights, (b) the fp32
+    outputs of the reference's HF InternVisionModel + ResamplerProjector (tests/golden/hf_vit.pt)."""
+    g = load_golden("hf_vit.pt")
+    ocfg = ovit.ViTConfig(num_layers=nl)
+    p = ovit.init_vit_params(ocfg, seed=g["weight_seed"], dtype=torch.bfloat16)
+    images = torch.randn(1, 3, 448, 448, generator=torch.Generator().manual_seed(g["image_seed"])).bfloat16()
+    model = amd["vision"].MegatronVisionModel.from_oracle_layout(amd["vision"].VisionConfig(num_layers=nl), p, DEV)
+    hid = model.vit(images.to(DEV))
+    feat = model.project(hid)
+    ref = g[tag]
+    # (b) bf16 path vs fp32 reference: tolerance = accumulated bf16 rounding over nl layers
+    tol = 2e-2 if nl <= 2 else 5e-2
+    assert rel_l2(hid[:, ::41, ::16], ref["hidden_sub"]) < tol
+    assert rel_l2(feat[:, ::8, ::40], ref["feat_sub"]) < tol
+    # (a) vs the oracle run with the same per-op bf16 rounding: much tighter
+    x = ovit.vit_embed(images, p, ocfg)
+    for lp in p["layers"]:
+        x = ovit.vit_layer(x, lp, ocfg)
+    of = ovit.vit_project(x, p, ocfg)
+    assert rel_l2(hid, x) < (6e-3 if nl <= 2 else 2e-2)
+    assert rel_l2(feat, of) < (8e-3 if nl <= 2 else 2.5e-2)
+
+
+def test_vit_frame_chunking_and_batch(amd):
+    """forward_chunk (M/pretrain_long_vita.py:522-533): chunked == unchunked, frames independent."""
+    V = amd["vision"]
+    cfg = V.VisionConfig(num_layers=2, chunk_frames=2)
+    m = V.MegatronVisionModel.random_init(cfg, seed=3, device=DEV)
+    images = torch.randn(5, 3, 448, 448, generator=torch.Generator().manual_seed(1)).bfloat16().to(DEV)
+    a = m(images=images)
+    cfg1 = V.VisionConfig(num_layers=2, chunk_frames=256)
+    b = V.MegatronVisionModel(cfg1, m.p)(images=images)
+    assert a.shape == (5, 256, 5120) and torch.equal(a, b)
+    c = V.MegatronVisionModel(cfg1, m.p)(images=images[3:4])
+    assert torch.equal(a[3:4], c)
+
+
+# ---------------------------------------------------------------------------------------------
+SMALL = dict(num_layers=2, hidden=1024, heads=8, kv_groups=2, head_dim=128, ffn=2816, vocab=1024)
+WIDE1 = dict(num_layers=1, hidden=5120, heads=40, kv_groups=8, head_dim=128, ffn=13824, vocab=2048)
+
+
+def _llm_pair(amd, cfgd, seed=11):
+    ocfg = ollm.LLMConfig(**cfgd)
+    p = ollm.init_llm_params(ocfg, seed=seed)
+    G = amd["gpt"]
+    model = G.GPTVLModel.from_oracle_layout(G.GPTConfig(**cfgd), p, None, DEV)
+    return ocfg, p, model
+
+
+@pytest.mark.parametrize("cfgd,S", [(SMALL, 512), (SMALL, 1344), (WIDE1, 1024)])
+def test_llm_prefill_cp1_vs_oracle(amd, cfgd, S):
+    ocfg, p, model = _llm_pair(amd, cfgd)
+    tokens = torch.randint(0, cfgd["vocab"], (1, S), generator=torch.Generator().manual_seed(5))
+    pos = [S - 1, S // 2, 0]
+    ref = ollm.prefill_logits(tokens, p, ocfg, pos)                       # [1, 3, V] fp32 head on bf16 trunk
+    mask = torch.zeros(1, S, dtype=torch.bool)
+    mask[0, pos] = True
+    out = model(tokens.to(DEV), None, None, logit_mask=mask.to(DEV))
+    assert out.shape == ref.shape
+    # bf16 trunk on both sides; differences = fp32 accumulation order + P rounding in attention
+    assert rel_l2(out, ref) < 2e-2, rel_l2(out, ref)
+    # indexing: the selected rows are the requested positions in ascending order (masked head ==
+    # rows of the full head, SURVEY.md §8c cross-check iii; skinny vs MFMA GEMM differ in
+    # accumulation order only, a wrong row would differ by O(1))
+    full = model(tokens.to(DEV), None, None, logit_mask=None)
+    assert rel_l2(full[:, sorted(pos)], out) < 5e-3
+
+
+def test_prefill_with_images_cp1(amd):
+    """ViT features scattered at `indices` (language_model_embedding.py:119-123) then prefill."""
+    cfgd = SMALL | dict(hidden=1024)
+    ocfg, p, model = _llm_pair(amd, cfgd)
+    V = amd["vision"]
+    vcfg = ovit.ViTConfig(num_layers=1, llm_hidden=cfgd["hidden"])
+    vp = ovit.init_vit_params(vcfg, seed=21)
+    model.external_feature_model = V.MegatronVisionModel.from_oracle_layout(
+        V.VisionConfig(num_layers=1, llm_hidden=cfgd["hidden"]), vp, DEV)
+    S, n_frames = 768, 2
+    tokens, ext = amd["syn"].make_request(S, n_frames, seed=9, device=DEV)
+    tokens = tokens % cfgd["vocab"]
+    feats = ovit.vision_model(ext["images"].cpu(), vp, vcfg)
+    ref = ollm.prefill_logits(tokens.cpu(), p, ocfg, [S - 1], {"features": feats, "indices": ext["indices"].cpu()})
+    out = amd["gen"].prefill_step(model, tokens, S, ext)
+    assert rel_l2(out, ref[:, -1]) < 2.5e-2
+
+
+# ---------------------------------------------------------------------------------------------
+class _FakeGroup:
+    """In-process stand-in for an RCCL group: `cp` threads rendezvous on a barrier."""
+
+    def __init__(self, cp):
+        self.cp, self.slots, self.barrier = cp, {}, threading.Barrier(cp)
+
+
+def _run_ranks(cp, fn, amd, monkeypatch):
+    import torch.distributed as dist
+    group = _FakeGroup(cp)
+    mpu = amd["mpu"]
+
+    def fake_all_gather_into_tensor(out, inp, group=None, async_op=False):
+        r = mpu.get_context_parallel_rank()
+        group.slots[r] = inp
+        group.barrier.wait()
+        flat = out.view(group.cp, -1)
+        for q in range(group.cp):
+            flat[q].copy_(group.slots[q].reshape(-1))
+        group.barrier.wait()
+
+    monkeypatch.setattr(dist, "all_gather_into_tensor", fake_all_gather_into_tensor)
+    results, errors = [None] * cp, []
+
+    def worker(r):
+        try:
+            torch.cuda.set_device(0)
+            mpu.set_context_parallel_state(cp, r, group)
+            results[r] = fn(r)
+        except BaseException as e:  # noqa: BLE001
+            errors.append((r, e))
+            group.barrier.abort()
+
+    threads = [threading.Thread(target=worker, args=(r,)) for r in range(cp)]
+    [t.start() for t in threads]
+    [t.join() for t in threads]
+    if errors:
+        raise errors[0][1]
+    return results
+
+
+@pytest.mark.parametrize("cp,S", [(2, 2048), (4, 4096)])
+def test_llm_prefill_context_parallel_vs_cp1(amd, monkeypatch, cp, S):
+    """Zig-zag CP prefill (all-gather of K/V + chunk-table attention + masked head + sync_output) on
+    `cp` simulated ranks reproduces the CP=1 logits; both are checked against the oracle."""
+    ocfg, p, model1 = _llm_pair(amd, SMALL)
+    G = amd["gpt"]
+    tokens = torch.randint(0, SMALL["vocab"], (1, S), generator=torch.Generator().manual_seed(7)).to(DEV)
+    ctx = S - 37                                              # last prompt token = ctx - 1
+    single = amd["gen"].prefill_step(model1, tokens, ctx, None, reference_compat=False)
+    ref = ollm.prefill_logits(tokens.cpu(), p, ocfg, [ctx - 1])[:, 0]
+
+    def rank_fn(r):
+        m = G.GPTVLModel(model1.cfg, model1.p)                # shared weights, private workspace
+        return amd["gen"].prefill_step(m, tokens, ctx, None, reference_compat=False)
+
+    outs = _run_ranks(cp, rank_fn, amd, monkeypatch)
+    for r in range(cp):
+        assert torch.equal(outs[r], outs[0])                  # every rank ends with the same logits
+    assert rel_l2(outs[0], ref) < 2e-2
+    assert rel_l2(outs[0], single) < 1.5e-2                   # same math, different tile order
+
+
+def test_cp_prefill_with_video_tokens(amd, monkeypatch):
+    """Frames follow their tokens (M/training/utils.py:279-325): each simulated rank encodes only the
+    frames whose tokens it owns and scatters by src/tgt indices; result == CP=1 with `indices`."""
+    cp, S, n_frames = 2, 2048, 7
+    cfgd = SMALL
+    ocfg, p, model1 = _llm_pair(amd, cfgd)
+    V, G = amd["vision"], amd["gpt"]
+    vcfg = V.VisionConfig(num_layers=1, llm_hidden=cfgd["hidden"])
+    vit = V.MegatronVisionModel.random_init(vcfg, seed=4, device=DEV)
+    model1.external_feature_model = vit
+    tokens, ext = amd["syn"].make_request(S, n_frames, seed=2, device=DEV)
+    tokens = tokens % cfgd["vocab"]
+    ctx = S - 5
+    single = amd["gen"].prefill_step(model1, tokens, ctx, ext, reference_compat=False)
+
+    def rank_fn(r):
+        m = G.GPTVLModel(model1.cfg, model1.p, vit)
+        return amd["gen"].prefill_step(m, tokens, ctx, ext, reference_compat=False)
+
+    outs = _run_ranks(cp, rank_fn, amd, monkeypatch)
+    assert torch.equal(outs[0], outs[1])
+    assert rel_l2(outs[0], single) < 1.5e-2
+
+
+def test_reference_compat_logit_mask_rule(amd):
+    """generation.py:141-165 incl. the wrap at ctx % half == 0."""
+    gen, mpu = amd["gen"], amd["mpu"]
+    toks = torch.zeros(1, 8, dtype=torch.long, device=DEV)
+    try:
+        mpu.set_context_parallel_state(2, 0, None)
+        m, blk = gen.build_logit_mask(toks, 8, True)
+        assert m[0].nonzero().flatten().tolist() == [3, 7] and blk == 2          # marks (-1, 3), picks block 2
+        m, blk = gen.build_logit_mask(toks, 6, True)
+        assert m[0].nonzero().flatten().tolist() == [1, 5] and blk == 1
+        m, blk = gen.build_logit_mask(toks, 8, False)
+        assert m[0].nonzero().flatten().tolist() == [3, 7] and blk == 1          # the correct block
+        for ctx in (1, 5, 6, 13):
+            pos, b2 = glue.cp_logit_mask_positions(ctx, 8, 2, True)
+            m, blk = gen.build_logit_mask(toks, ctx, True)
+            assert m[0].nonzero().flatten().tolist() == pos and blk == b2
+    finally:
+        mpu.destroy_model_parallel()

@@ -1,0 +1,339 @@
+"""Parity of every HIP entry point (through the C ABI) against the CPU oracle on seeded inputs.
+Integer / byte work is bit-exact; floating point tolerances are stated per test."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import attention as oattn  # noqa: E402
+from oracle import glue  # noqa: E402
+from oracle import vit as ovit  # noqa: E402
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from long_vita_amd import ops as _ops
+    _ops._L.load(allow_build=False)     # fail loudly if the .so is missing on the GPU box
+    return _ops
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def bf16_ulp_diff(a, b):
+    """max difference in bf16 ulps (bit patterns as sign-magnitude integers)."""
+    ai = a.cpu().view(torch.int16).to(torch.int32)
+    bi = b.cpu().view(torch.int16).to(torch.int32)
+    ai = torch.where(ai < 0, -(ai & 0x7FFF), ai)
+    bi = torch.where(bi < 0, -(bi & 0x7FFF), bi)
+    return int((ai - bi).abs().max())
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,cols", [(1, 5120), (33, 5120), (257, 1024), (64, 4096), (5, 8192), (7, 1152)])
+def test_rmsnorm(ops, rows, cols):
+    x = (torch.randn(rows, cols, generator=g(1)) * 3).bfloat16()
+    w = (1 + 0.1 * torch.randn(cols, generator=g(2))).bfloat16()
+    ref = glue.rmsnorm(x, w, 1e-6)
+    out = ops.rmsnorm(x.to(DEV), w.to(DEV), 1e-6)
+    # fp32 statistic may differ in the last ulp (reduction order) -> at most 1 bf16 ulp after rounding
+    assert bf16_ulp_diff(out, ref) <= 1
+    assert (out.cpu() == ref).float().mean() > 0.995
+
+
+@pytest.mark.parametrize("rows,cols,eps", [(3, 1024, 1e-6), (130, 1024, 1e-6), (17, 4096, 1e-5), (9, 1152, 1e-6)])
+def test_layernorm(ops, rows, cols, eps):
+    x = (torch.randn(rows, cols, generator=g(3)) * 2 + 0.5).bfloat16()
+    w = (1 + 0.1 * torch.randn(cols, generator=g(4))).bfloat16()
+    b = (0.1 * torch.randn(cols, generator=g(5))).bfloat16()
+    ref = torch.nn.functional.layer_norm(x.float(), (cols,), w.float(), b.float(), eps).bfloat16()
+    out = ops.layernorm(x.to(DEV), w.to(DEV), b.to(DEV), eps)
+    assert bf16_ulp_diff(out, ref) <= 1
+    assert (out.cpu() == ref).float().mean() > 0.99
+
+
+def test_rope_table_and_apply(ops):
+    inv = glue.rope_inv_freq(128, 1e6)
+    assert torch.equal(ops.rope_inv_freq(128, 1e6, "cpu"), inv)
+    pos = torch.cat([torch.arange(0, 300), torch.tensor([4095, 65535, 131071, 524288, 1048575])])
+    cos, sin = ops.rope_table(pos.to(DEV), inv.to(DEV))
+    freqs = torch.outer(pos.float(), inv)
+    # device cosf/sinf vs torch CPU: <= 1 bf16 ulp after the cast
+    assert bf16_ulp_diff(cos, torch.cos(freqs).bfloat16()) <= 1
+    assert bf16_ulp_diff(sin, torch.sin(freqs).bfloat16()) <= 1
+    # apply with the DEVICE's tables: the rounding chain bf16(bf16(t*cos)+bf16(rot*sin)) is bit-exact
+    t = torch.randn(305, 6, 128, generator=g(6)).bfloat16()
+    emb_cos, emb_sin = cos.cpu(), sin.cpu()
+    c2 = torch.cat([emb_cos, emb_cos], -1)[:, None, :]
+    s2 = torch.cat([emb_sin, emb_sin], -1)[:, None, :]
+    ref = t * c2 + glue.rotate_half(t) * s2
+    out = ops.rope_apply_(t.to(DEV).clone(), cos, sin)
+    assert torch.equal(out.cpu(), ref)
+    # strided view + backward sign: R(-theta) R(theta) x ~= x
+    big = torch.zeros(305, 8, 200, dtype=torch.bfloat16, device=DEV)
+    view = big[:, 1:7, 8:136]
+    view.copy_(t.to(DEV))
+    ops.rope_apply_(view, cos, sin)
+    assert torch.equal(view.cpu(), ref)
+    assert float(big[:, 0].abs().max()) == 0 and float(big[:, :, :8].abs().max()) == 0
+
+
+def test_rope_qkv_fused(ops):
+    rows, ng, qpg, d = 70, 8, 5, 128
+    mixed = torch.randn(rows, ng, (qpg + 2) * d, generator=g(7)).bfloat16()
+    pos = torch.arange(1000, 1000 + rows)
+    inv = glue.rope_inv_freq(d, 1e6)
+    cos, sin = ops.rope_table(pos.to(DEV), inv.to(DEV))
+    c2 = torch.cat([cos.cpu(), cos.cpu()], -1)[:, None, :]
+    s2 = torch.cat([sin.cpu(), sin.cpu()], -1)[:, None, :]
+    m = mixed.view(rows, ng, qpg + 2, d)
+    ref = m.clone()
+    for h in range(qpg + 1):
+        ref[:, :, h] = m[:, :, h] * c2 + glue.rotate_half(m[:, :, h]) * s2
+    md = mixed.to(DEV).clone()
+    kv = torch.empty(2, rows, ng, d, dtype=torch.bfloat16, device=DEV)
+    ops.rope_qkv_(md, ng, qpg, d, cos, sin, kv)
+    assert torch.equal(md.cpu().view(rows, ng, qpg + 2, d), ref)
+    assert torch.equal(kv[0].cpu(), ref[:, :, qpg]) and torch.equal(kv[1].cpu(), ref[:, :, qpg + 1])
+
+
+# ---------------------------------------------------------------------------------------------
+def test_row_gather_scatter_bit_exact(ops):
+    table = torch.randn(1000, 5120, generator=g(8)).bfloat16()
+    idx = torch.randint(0, 1000, (777,), generator=g(9))
+    out = ops.row_gather(table.to(DEV), idx.to(DEV))
+    assert torch.equal(out.cpu(), table[idx])
+    with pytest.raises(IndexError):
+        ops.row_gather(table.to(DEV), torch.tensor([0, 1000], device=DEV))
+    # scatter forms of language_model_embedding.py:123,131
+    we = torch.randn(2, 64, 5120, generator=g(10)).bfloat16()
+    feats = torch.randn(3, 8, 5120, generator=g(11)).bfloat16()
+    src_b = torch.tensor([0, 0, 2, 2, 2]); src_s = torch.tensor([1, 3, 0, 1, 7])
+    tgt_b = torch.tensor([0, 0, 1, 1, 1]); tgt_s = torch.tensor([5, 6, 0, 1, 63])
+    ref = we.clone(); ref[tgt_b, tgt_s] = feats[src_b, src_s]
+    dst = we.to(DEV).clone().view(128, 5120)
+    ops.row_scatter_(dst, (tgt_b * 64 + tgt_s).to(DEV), feats.to(DEV).view(24, 5120), (src_b * 8 + src_s).to(DEV))
+    assert torch.equal(dst.cpu().view(2, 64, 5120), ref)
+    # empty
+    assert ops.row_gather(table.to(DEV), torch.empty(0, dtype=torch.int64, device=DEV)).shape == (0, 5120)
+    # fp32 rows too
+    t32 = torch.randn(50, 12, generator=g(12))
+    assert torch.equal(ops.row_gather(t32.to(DEV), idx[:20].to(DEV) % 50).cpu(), t32[idx[:20] % 50])
+
+
+@pytest.mark.parametrize("n,p", [(1, 1.0), (1000, 0.01), (131072, 0.004), (131072, 0.5), (5, 0.0), (1048576, 1e-5)])
+def test_mask_to_index(ops, n, p):
+    mask = torch.rand(n, generator=g(13)) < p
+    out = ops.mask_to_index(mask.to(DEV))
+    assert torch.equal(out.cpu(), mask.nonzero().flatten())
+
+
+@pytest.mark.parametrize("name", ["survey_appendix", "video_like", "straddle"])
+def test_cp_batch_slice_matches_reference_fixture(ops, name):
+    """get_batch_on_this_cp_rank on the device vs the fixture produced by the reference's own code."""
+    from conftest import load_golden
+    from long_vita_amd.training_utils import get_batch_on_this_cp_rank
+
+    case = [c for c in load_golden("cp_slice.pt")["cases"] if c["name"] == name][0]
+    for r in range(case["cp"]):
+        batch = {"tokens": case["tokens"].to(DEV), "labels": (case["tokens"] + 1).to(DEV),
+                 "position_ids": torch.arange(case["seq"])[None].to(DEV),
+                 "external_images": case["images"].to(DEV), "external_indices": case["indices"].to(DEV)}
+        mine = get_batch_on_this_cp_rank(batch, seq_length=case["seq"], cp_size=case["cp"], cp_rank=r)
+        ref = case["out"][r]
+        assert set(mine.keys()) == set(ref.keys())
+        for k in ref:
+            assert mine[k].dtype == ref[k].dtype and torch.equal(mine[k].cpu(), ref[k]), (name, r, k)
+
+
+# ---------------------------------------------------------------------------------------------
+def _gemm_ref(a, w, epi, bias, scale, res, ops):
+    v = a.float() @ w.float().t()
+    bf = lambda t: t.bfloat16().float()
+    if epi == ops.EPI_NONE:
+        return v.bfloat16()
+    if epi == ops.EPI_BIAS:
+        return (v + bias.float()).bfloat16()
+    if epi == ops.EPI_BIAS_GELU:
+        t = bf(v + (bias.float() if bias is not None else 0))
+        return torch.nn.functional.gelu(t).bfloat16()
+    if epi == ops.EPI_RESIDUAL:
+        return (res.float() + bf(v + (bias.float() if bias is not None else 0))).bfloat16()
+    if epi == ops.EPI_BIAS_SCALE_RES:
+        return (res.float() + bf(bf(v + bias.float()) * scale.float())).bfloat16()
+    if epi == ops.EPI_SWIGLU:
+        gate, up = torch.chunk(v, 2, dim=-1)
+        gte, u = bf(gate), bf(up)
+        return (bf(torch.nn.functional.silu(gte)) * u).bfloat16()
+    raise AssertionError
+
+
+@pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 1024), (1025, 1024, 1024), (300, 200, 640),
+                                   (77, 5120, 1024), (2048, 7168, 5120)])
+@pytest.mark.parametrize("epi", [0, 1, 2, 3, 4, 5])
+def test_gemm_epilogues(ops, M, N, K, epi):
+    if epi == 5 and N % 2:
+        pytest.skip("swiglu needs even rows")
+    if M * N * K > 2e10 and epi not in (0, 5):
+        pytest.skip("large shape only for plain / swiglu")
+    a = (torch.randn(M, K, generator=g(20)) * 0.5).bfloat16()
+    wrows = 2 * N if epi == ops.EPI_SWIGLU else N
+    w = (torch.randn(wrows, K, generator=g(21)) * (1.0 / math.sqrt(K))).bfloat16()
+    bias = (torch.randn(N, generator=g(22)) * 0.1).bfloat16() if epi in (1, 2, 3, 4) else None
+    scale = (0.1 + 0.01 * torch.randn(N, generator=g(23))).bfloat16() if epi == 4 else None
+    res = torch.randn(M, N, generator=g(24)).bfloat16() if epi in (3, 4) else None
+    ref = _gemm_ref(a, w, epi, bias, scale, res, ops)
+    out = ops.gemm(a.to(DEV), w.to(DEV), epi, None if bias is None else bias.to(DEV),
+                   None if scale is None else scale.to(DEV), None if res is None else res.to(DEV))
+    # fp32 accumulation order differs from the CPU GEMM -> a few results flip one bf16 ulp
+    err = rel_l2(out, ref)
+    assert err < 2e-3, err
+    assert bf16_ulp_diff(out, ref) <= 2 or (out.cpu().float() - ref.float()).abs().max() < 2e-2
+
+
+def test_gemm_asymmetric_identity(ops):
+    """A = I with an asymmetric W catches a transposed C write (cdna guide §3)."""
+    K = 128
+    a = torch.eye(K).bfloat16()
+    w = (torch.arange(192 * K).reshape(192, K) % 251 - 125).float().bfloat16()
+    out = ops.gemm(a.to(DEV), w.to(DEV))
+    assert torch.equal(out.cpu(), w.t().contiguous())
+
+
+def test_gemm_strided_a_and_errors(ops):
+    big = torch.randn(100, 2048, generator=g(25)).bfloat16().to(DEV)
+    a = big[:, 512:512 + 1024]
+    w = torch.randn(64, 1024, generator=g(26)).bfloat16().to(DEV)
+    ref = (a.float().cpu() @ w.float().cpu().t()).bfloat16()
+    assert rel_l2(ops.gemm(a, w), ref) < 2e-3
+    with pytest.raises(RuntimeError):
+        ops.gemm(a, torch.zeros(64, 512, dtype=torch.bfloat16, device=DEV))     # weight shape mismatch
+    with pytest.raises(RuntimeError):
+        ops.gemm(big[:, :100].contiguous(), torch.zeros(8, 100, dtype=torch.bfloat16, device=DEV))  # K % 64
+    with pytest.raises(RuntimeError):
+        ops.rmsnorm(torch.zeros(4, 64).bfloat16(), torch.ones(64).bfloat16())    # CPU tensor: no fallback
+
+
+@pytest.mark.parametrize("M", [1, 2, 5, 16])
+def test_gemm_skinny(ops, M):
+    K, N = 5120, 3000
+    a = torch.randn(M, K, generator=g(27)).bfloat16()
+    w = (torch.randn(N, K, generator=g(28)) * 0.02).bfloat16()
+    ref = a.float() @ w.float().t()
+    out = ops.gemm_skinny(a.to(DEV), w.to(DEV), out_f32=True)
+    torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-4)
+    outb = ops.gemm_skinny(a.to(DEV), w.to(DEV))
+    assert rel_l2(outb, ref) < 4e-3
+
+
+# ---------------------------------------------------------------------------------------------
+def _attn_ref(q, k, v, causal, q_pos=None, k_pos=None):
+    # q [B,S,H,D] -> oracle layout [s,b,h,d]
+    o = oattn.core_attention(q.transpose(0, 1).float(), k.transpose(0, 1).float(), v.transpose(0, 1).float(), causal,
+                             q_pos=q_pos, k_pos=k_pos)
+    B, S, H, D = q.shape
+    return o.view(S, B, H, D).transpose(0, 1)
+
+
+@pytest.mark.parametrize("S,Hq,Hkv,D,causal", [
+    (256, 5, 1, 128, True), (512, 10, 2, 128, True), (1024, 40, 8, 128, True), (320, 5, 1, 128, True),
+    (1025, 16, 16, 64, False), (192, 4, 4, 64, False), (2048, 5, 1, 128, True), (704, 2, 2, 128, False),
+])
+def test_flash_attention_single_chunk(ops, S, Hq, Hkv, D, causal):
+    B = 2 if D == 64 else 1
+    q = torch.randn(B, S, Hq, D, generator=g(30)).bfloat16()
+    k = torch.randn(B, S, Hkv, D, generator=g(31)).bfloat16()
+    v = torch.randn(B, S, Hkv, D, generator=g(32)).bfloat16()
+    ref = _attn_ref(q, k, v, causal)
+    out, lse = ops.flash_attn(q.to(DEV), k.to(DEV), v.to(DEV), causal=causal, return_lse=True)
+    # P is rounded to bf16 before PV (as flash-attn / TE do): tolerance 1e-2 relative L2, 3e-2 abs
+    assert rel_l2(out, ref) < 1e-2, rel_l2(out, ref)
+    assert float((out.cpu().float() - ref).abs().max()) < 3e-2
+    # lse against fp32 math
+    sc = torch.einsum("bqhd,bkhd->bhqk", q.float(), k.float().repeat_interleave(Hq // Hkv, 2)) / math.sqrt(D)
+    if causal:
+        sc = sc.masked_fill(torch.triu(torch.ones(S, S, dtype=torch.bool), 1), float("-inf"))
+    torch.testing.assert_close(lse.cpu(), torch.logsumexp(sc, -1), rtol=2e-3, atol=2e-3)
+
+
+def test_flash_attention_forced_rescale(ops):
+    """Spike one key so the running max jumps late in the sequence (cdna guide rule 26)."""
+    S, D = 1024, 128
+    q = torch.randn(1, S, 5, D, generator=g(33)).bfloat16()
+    k = torch.randn(1, S, 1, D, generator=g(34)).bfloat16()
+    v = torch.randn(1, S, 1, D, generator=g(35)).bfloat16()
+    k[0, 700] = (q[0, 900, 2].float() * 3).bfloat16()       # huge score for (row 900, key 700)
+    ref = _attn_ref(q, k, v, True)
+    out = ops.flash_attn(q.to(DEV), k.to(DEV), v.to(DEV), causal=True)
+    assert rel_l2(out, ref) < 1e-2
+    assert float((out.cpu().float() - ref).abs().max()) < 5e-2
+
+
+def test_flash_attention_mixed_qkv_views(ops):
+    """Q/K/V read in place from Megatron's mixed QKV activation [S, ng, (qpg+2), d] (grouped q view)."""
+    S, ng, qpg, d = 512, 8, 5, 128
+    mixed = torch.randn(1, S, ng, qpg + 2, d, generator=g(36)).bfloat16().to(DEV)
+    q5 = mixed[:, :, :, :qpg]                  # [1, S, ng, qpg, d]  group stride (qpg+2)*d
+    kview = mixed[:, :, :, qpg]                # [1, S, ng, d]
+    vview = mixed[:, :, :, qpg + 1]
+    out = ops.flash_attn(q5, kview, vview, causal=True)
+    ref = _attn_ref(q5.reshape(1, S, ng * qpg, d).cpu(), kview.cpu(), vview.cpu(), True)
+    assert rel_l2(out, ref) < 1e-2
+
+
+@pytest.mark.parametrize("cp,S", [(2, 2048), (4, 4096), (8, 4096)])
+def test_flash_attention_zigzag_chunks(ops, cp, S):
+    """Every rank's zig-zag context-parallel attention (local Q x all-gathered K/V in rank order)
+    re-assembled == monolithic causal attention (SURVEY.md §8c cross-check ii)."""
+    Hq, Hkv, D = 5, 1, 128
+    C = S // (2 * cp)
+    q = torch.randn(1, S, Hq, D, generator=g(40)).bfloat16()
+    k = torch.randn(1, S, Hkv, D, generator=g(41)).bfloat16()
+    v = torch.randn(1, S, Hkv, D, generator=g(42)).bfloat16()
+    full = _attn_ref(q, k, v, True)
+    # gathered buffer = concat over ranks of each rank's local (zig-zag) K/V
+    k_g = torch.cat([glue.zigzag_slice(k, cp, r) for r in range(cp)], 1).to(DEV)
+    v_g = torch.cat([glue.zigzag_slice(v, cp, r) for r in range(cp)], 1).to(DEV)
+    kv_gid, kv_row = [], []
+    for r in range(cp):
+        kv_gid += [r, 2 * cp - 1 - r]
+        kv_row += [2 * r * C, (2 * r + 1) * C]
+    for r in range(cp):
+        q_l = glue.zigzag_slice(q, cp, r).to(DEV)
+        out = ops.flash_attn(q_l, k_g, v_g, causal=True, chunk_len=C, q_chunk_gid=[r, 2 * cp - 1 - r],
+                             kv_chunk_gid=kv_gid, kv_chunk_row=kv_row)
+        ref = glue.zigzag_slice(full, cp, r)
+        assert rel_l2(out, ref) < 1e-2, (r, rel_l2(out, ref))
+        assert float((out.cpu().float() - ref).abs().max()) < 3e-2
+
+
+# ---------------------------------------------------------------------------------------------
+def test_vit_front_back_kernels(ops):
+    cfg = ovit.ViTConfig(num_layers=0)
+    p = ovit.init_vit_params(cfg, seed=5)
+    images = torch.randn(2, 3, 448, 448, generator=g(50)).bfloat16()
+    # patchify is pure data movement: bit-exact against unfold
+    patches = ops.patchify14(images.to(DEV), 640)
+    ref = torch.nn.functional.unfold(images.float(), 14, stride=14).transpose(1, 2).reshape(-1, 588).bfloat16()
+    assert torch.equal(patches[:, :588].cpu(), ref) and float(patches[:, 588:].abs().max()) == 0
+    # patch GEMM + assemble == conv + cls + pos (oracle vit_embed)
+    w = torch.zeros(1024, 640, dtype=torch.bfloat16); w[:, :588] = p["conv_w"].reshape(1024, 588)
+    pe = ops.gemm(patches, w.to(DEV), ops.EPI_BIAS, p["conv_b"].to(DEV))
+    x = ops.vit_assemble(pe, p["cls"].to(DEV).view(-1), p["pos"].to(DEV), 2, 1024)
+    xr = ovit.vit_embed(images, p, cfg)
+    assert rel_l2(x, xr) < 3e-3
+    # pixel-shuffle + LayerNorm
+    y = ops.pixel_shuffle_ln(xr.to(DEV), p["proj_ln_w"].to(DEV), p["proj_ln_b"].to(DEV), 32, True, 1e-5)
+    t = glue.pixel_shuffle(xr[:, 1:].reshape(2, 32, 32, -1), 0.5).reshape(2, 256, 4096)
+    yr = torch.nn.functional.layer_norm(t.float(), (4096,), p["proj_ln_w"].float(), p["proj_ln_b"].float(), 1e-5).bfloat16()
+    assert bf16_ulp_diff(y, yr) <= 1

@@ -1,0 +1,103 @@
+"""Kernel micro-benchmarks on the GPU box (HIP events on the launch stream): GEMM shapes of the 14B
+decoder / ViT, flash attention at the BASELINE sequence lengths, HBM-bound kernels.
+Writes one JSON line per case to stdout (and gpurun_out/microbench.jsonl)."""
+import json
+import math
+import os
+import sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch  # noqa: E402
+
+from long_vita_amd import ops  # noqa: E402
+
+DEV = "cuda"
+OUT = os.path.join(ROOT, "gpurun_out")
+os.makedirs(OUT, exist_ok=True)
+LOG = open(os.path.join(OUT, "microbench.jsonl"), "a")
+
+
+def timeit(fn, warmup=2, iters=5):
+    for _ in range(warmup):
+        fn()
+    torch.cuda.synchronize()
+    evs = []
+    for _ in range(iters):
+        a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        a.record(); fn(); b.record()
+        evs.append((a, b))
+    torch.cuda.synchronize()
+    ts = sorted(a.elapsed_time(b) for a, b in evs)
+    return ts[len(ts) // 2], ts[0]
+
+
+def emit(**kw):
+    s = json.dumps(kw)
+    print(s, flush=True)
+    LOG.write(s + "\n"); LOG.flush()
+
+
+def bench_gemm(M, N, K, epi=0, tag=""):
+    a = (torch.randn(M, K, device=DEV) * 0.5).bfloat16()
+    w = (torch.randn((2 * N if epi == 5 else N), K, device=DEV) * 0.02).bfloat16()
+    out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+    res = torch.randn(M, N, device=DEV).bfloat16() if epi == 3 else None
+    bias = torch.randn(N, device=DEV).bfloat16() if epi == 1 else None
+    med, best = timeit(lambda: ops.gemm(a, w, epi, bias, None, res, out=out))
+    fl = 2.0 * M * (2 * N if epi == 5 else N) * K
+    emit(kind="gemm", tag=tag, M=M, N=N, K=K, epi=epi, ms=med, ms_best=best, tflops=fl / med / 1e9)
+
+
+def bench_attn(S, Hq=40, Hkv=8, D=128, causal=True, B=1, tag=""):
+    q = torch.randn(B, S, Hq, D, device=DEV).bfloat16()
+    k = torch.randn(B, S, Hkv, D, device=DEV).bfloat16()
+    v = torch.randn(B, S, Hkv, D, device=DEV).bfloat16()
+    o = torch.empty_like(q)
+    med, best = timeit(lambda: ops.flash_attn(q, k, v, causal=causal, out=o), warmup=1, iters=3)
+    pairs = S * (S + 1) / 2 if causal else S * S
+    fl = 4.0 * D * Hq * pairs * B
+    emit(kind="attn", tag=tag, S=S, Hq=Hq, Hkv=Hkv, D=D, causal=causal, B=B, ms=med, ms_best=best, tflops=fl / med / 1e9)
+
+
+def bench_hbm():
+    rows, cols = 131072, 5120
+    x = torch.randn(rows, cols, device=DEV).bfloat16()
+    w = torch.ones(cols, device=DEV).bfloat16()
+    y = torch.empty_like(x)
+    med, _ = timeit(lambda: ops.rmsnorm(x, w, 1e-6, out=y))
+    emit(kind="rmsnorm", rows=rows, cols=cols, ms=med, gbps=2 * rows * cols * 2 / med / 1e6)
+    qkv = torch.randn(rows, 7168, device=DEV).bfloat16()
+    inv = ops.rope_inv_freq(128, 1e6, DEV)
+    cos, sin = ops.rope_table(torch.arange(rows, device=DEV), inv)
+    kv = torch.empty(2, rows, 8, 128, dtype=torch.bfloat16, device=DEV)
+    med, _ = timeit(lambda: ops.rope_qkv_(qkv, 8, 5, 128, cos, sin, kv))
+    emit(kind="rope_qkv", rows=rows, ms=med, gbps=(rows * 6144 * 2 * 2 + rows * 2048 * 2 * 2) / med / 1e6)
+    idx = torch.randint(0, 152064, (rows,), device=DEV)
+    table = torch.randn(152064, cols, device=DEV).bfloat16()
+    med, _ = timeit(lambda: ops.row_gather(table, idx, out=y, check_bounds=False))
+    emit(kind="row_gather", rows=rows, cols=cols, ms=med, gbps=2 * rows * cols * 2 / med / 1e6)
+    a = torch.randn(2, cols, device=DEV).bfloat16()
+    med, _ = timeit(lambda: ops.gemm_skinny(a, table))
+    emit(kind="gemm_skinny", M=2, N=152064, K=cols, ms=med, gbps=152064 * cols * 2 / med / 1e6)
+
+
+if __name__ == "__main__":
+    which = sys.argv[1:] or ["gemm", "attn", "hbm"]
+    if "gemm" in which:
+        for (M, tag) in [(16384, "S16K"), (131072, "S128K")]:
+            bench_gemm(M, 7168, 5120, 1, tag + "/qkv")
+            bench_gemm(M, 5120, 5120, 3, tag + "/o")
+            bench_gemm(M, 13824, 5120, 5, tag + "/fc1_swiglu")
+            bench_gemm(M, 5120, 13824, 3, tag + "/fc2")
+        bench_gemm(8192, 8192, 8192, 0, "square8k")
+        bench_gemm(4096, 4096, 4096, 0, "square4k")
+        bench_gemm(64 * 1025, 3072, 1024, 1, "vit/qkv64f")
+        bench_gemm(64 * 1025, 4096, 1024, 0, "vit/fc1")
+        bench_gemm(64 * 1025, 1024, 4096, 0, "vit/fc2")
+    if "attn" in which:
+        for S in (4096, 16384, 32768, 131072):
+            bench_attn(S, tag=f"llm{S}")
+        bench_attn(1025, 16, 16, 64, False, 64, tag="vit64f")
+    if "hbm" in which:
+        bench_hbm()
