@@ -129,6 +129,8 @@ def row_gather(src: torch.Tensor, idx: torch.Tensor, out: Optional[torch.Tensor]
     idx = idx.reshape(-1).contiguous()
     n, cols = idx.numel(), src.numel() // max(src.shape[0], 1)
     y = torch.empty((n,) + tuple(src.shape[1:]), dtype=src.dtype, device=src.device) if out is None else out
+    if n == 0:
+        return y
     flag = _err_flag(src.device) if check_bounds else None
     _L.check(_L.load().vita_row_gather(_dev(src, "src"), src.shape[0], _dev(idx, "idx"), _dev(y, "out"), n, cols,
                                        src.element_size(), _opt(flag, "flag"), _stream()), "vita_row_gather")
@@ -149,6 +151,8 @@ def row_scatter_(dst: torch.Tensor, dst_idx: torch.Tensor, src: torch.Tensor,
     cols = dst.numel() // max(dst.shape[0], 1)
     if src.numel() // max(src.shape[0], 1) != cols or src.dtype != dst.dtype:
         raise ValueError("row width / dtype mismatch")
+    if n == 0:
+        return dst
     flag = _err_flag(dst.device) if check_bounds else None
     _L.check(_L.load().vita_row_scatter(_dev(src, "src"), src.shape[0], _opt(src_idx, "src_idx", torch.int64),
                                         _dev(dst, "dst"), dst.shape[0], _dev(dst_idx, "dst_idx", torch.int64), n, cols,
