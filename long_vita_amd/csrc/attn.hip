@@ -24,10 +24,15 @@
 // math: softmax(QK^T / sqrt(d)) V with GQA repeat :171-175), :312-329 (ViT, non-causal),
 // :374-390 (LLM causal).  Zig-zag chunk ownership: M/training/utils.py:329-341.
 #include "vita_common.h"
+#include <stdlib.h>
+#include <type_traits>
 
 namespace {
 
 constexpr int kMaxChunks = 32;
+
+// developer aid (VITA_ATTN_VARIANT bit 2): per-phase shader-clock totals, [group A|B][top, qk, sm_pv, barrier, n]
+__device__ unsigned long long g_attn_timing[16];
 constexpr int QTILE = 256;   // query rows per workgroup (8 waves x 32)
 constexpr int KVT = 64;      // keys per tile
 
@@ -73,16 +78,40 @@ __device__ __forceinline__ int v_lds_off(int row, int chunk, int b) {
   else return row * 128 + ((chunk ^ (row & 2)) << 5) + b;
 }
 
-template <int D, bool CAUSAL>
+// One kv tile position of the iteration space (all fields wave-uniform -> SGPRs).
+struct TileIt {
+  int c, j, n;        // chunk, tile inside chunk, tiles to visit in this chunk; c == n_kv_chunks -> end
+  int rows;           // valid rows of chunk c
+  int diag;           // CAUSAL and chunk c is the query tile's own chunk
+  int64_t crow;       // first row of chunk c in the K/V buffers
+};
+
+// VARIANT (developer tuning aid, see attn_variant()):
+//   0 = K/V tiles go HBM/L2 -> LDS directly with the LDS-DMA (global_load_lds_dwordx4); the DMA writes
+//       lane-linear, so the bank swizzles are applied to the per-lane SOURCE address (same involution
+//       on the fragment reads); no staging VGPRs, no ds_write burst behind the barrier;
+//   1 = register staging (global_load -> VGPR -> ds_write_b128), loads issued two tiles ahead;
+//   bits 1-2 = QK_AHEAD: K-fragment reads pinned that many k-steps ahead of their MFMAs.
+// (A 3-slot "staggered" variant — waves 4..7 half a tile behind waves 0..3 — measured 0 to -3 %.)
+template <int D, bool CAUSAL, int VARIANT = 0, bool TIMING = false>
 __global__ __launch_bounds__(512, 2) void flash_fwd_kernel(AttnArgs p) {
   constexpr int DS = D / 16;              // QK^T k-steps
   constexpr int DB = D / 32;              // O^T row blocks
   constexpr int ROWB = D * 2;             // bytes per K/V row
   constexpr int TILEB = KVT * ROWB;       // bytes per K (or V) tile
+  constexpr int SLOTB = 2 * TILEB;        // bytes per ring slot (K tile | V tile)
   constexpr int SLOTS = ROWB / 16;        // 16-byte slots per row
   constexpr int LD_PER_THR = (KVT * SLOTS) / 512;  // 16-byte loads per thread per operand
+  constexpr bool GLDS = !(VARIANT & 1);
+  constexpr int QK_AHEAD = (VARIANT >> 1) & 3;          // 0 = compiler's own schedule
 
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2 stages][K tile | V tile]
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | V tile]
+  typedef __attribute__((address_space(3))) char lds_char;
+  typedef __attribute__((address_space(3))) const bf16x8 lds_bf16x8;
+  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+  typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
+  // LDS byte address of the ring (32-bit); fragment reads use  VGPR(lane offset + slot base) + imm
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
 
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // provably wave-uniform
@@ -107,6 +136,7 @@ __global__ __launch_bounds__(512, 2) void flash_fwd_kernel(AttnArgs p) {
   const bool q_live = my_q < q_rows_in_chunk;
   const int64_t q_local_row = (int64_t)qc * p.chunk_len + (q_live ? my_q : q_rows_in_chunk - 1);
   const int q_last_wg = min(q_off_wg + QTILE, q_rows_in_chunk) - 1;  // last valid row of the WG
+  const float scale_log2e = p.scale_log2e;
 
   // ---- Q fragments (B operand of S^T = K Q^T): lane = (query row l31, k-slot half hi) --------
   bf16x8 qf[DS];
@@ -114,6 +144,36 @@ __global__ __launch_bounds__(512, 2) void flash_fwd_kernel(AttnArgs p) {
     const bf16_t* qp = p.q + (int64_t)b * p.q_bs + q_local_row * p.q_rs + (int64_t)kvh * p.q_gs + (int64_t)hq * p.q_hs + hi * 8;
 #pragma unroll
     for (int ds = 0; ds < DS; ++ds) qf[ds] = *reinterpret_cast<const bf16x8*>(qp + ds * 16);
+  }
+
+  // ---- per-lane LDS read offsets (everything else is a compile-time immediate) ----------------
+  // K fragment (A operand): row l31 (+32), 16-byte slot 2*ds + hi
+  unsigned koff[DS];
+#pragma unroll
+  for (int ds = 0; ds < DS; ++ds) koff[ds] = k_lds_off<D>(l31, 2 * ds + hi);
+  // V^T fragment for O^T row block db: inside a 16-lane group, lane i supplies the 8-byte piece
+  // (row i>>2, columns 4*(i&3)..) of a [4 keys][16 d] block; keys 16t + 4*hi' + {0..3} (+8)
+  unsigned voff[DB];
+  {
+    const int g16 = lane >> 4, i16 = lane & 15;
+    const int key_l = 4 * (g16 >> 1) + (i16 >> 2);
+#pragma unroll
+    for (int db = 0; db < DB; ++db) {
+      const int col = 32 * db + 16 * (g16 & 1) + 4 * (i16 & 3);
+      voff[db] = TILEB + v_lds_off<D>(key_l, col >> 4, (col & 15) * 2);
+    }
+  }
+  // staging: this thread's LD_PER_THR 16-byte pieces of a tile -> global element offsets
+  // (relative to the tile's first row, 32-bit) and LDS byte offsets (relative to the slot)
+  unsigned g_koff[LD_PER_THR], g_voff[LD_PER_THR], l_koff[LD_PER_THR], l_voff[LD_PER_THR];
+#pragma unroll
+  for (int it = 0; it < LD_PER_THR; ++it) {
+    const int e = tid + it * 512;
+    const int row = e / SLOTS, slot = e % SLOTS;
+    g_koff[it] = (unsigned)(row * p.k_rs + slot * 8);
+    g_voff[it] = (unsigned)(row * p.v_rs + slot * 8);
+    l_koff[it] = k_lds_off<D>(row, slot);
+    l_voff[it] = TILEB + v_lds_off<D>(row, slot >> 1, (slot & 1) << 4);
   }
 
   f32x16 o_acc[DB];
@@ -126,157 +186,248 @@ __global__ __launch_bounds__(512, 2) void flash_fwd_kernel(AttnArgs p) {
   const bf16_t* kbase = p.k + (int64_t)b * p.k_bs + (int64_t)kvh * p.k_hs;
   const bf16_t* vbase = p.v + (int64_t)b * p.v_bs + (int64_t)kvh * p.v_hs;
 
-  // number of tiles of kv chunk c this workgroup must visit
-  auto chunk_tiles = [&](int c) -> int {
-    const int rows = (c == p.n_kv_chunks - 1) ? p.kv_valid : p.chunk_len;
-    const int all = (rows + KVT - 1) / KVT;
-    if (!CAUSAL) return all;
-    const int gk = p.kv_gid[c];
-    if (gk < gq) return all;
-    if (gk > gq) return 0;
-    return min(all, q_last_wg / KVT + 1);
-  };
-
-  // staging registers for the next tile
-  u32x4 kreg[LD_PER_THR], vreg[LD_PER_THR];
-  auto issue_loads = [&](int c, int j) {
-    const int rows = (c == p.n_kv_chunks - 1) ? p.kv_valid : p.chunk_len;
-    const int64_t row0 = p.kv_row[c] + (int64_t)j * KVT;
-#pragma unroll
-    for (int it = 0; it < LD_PER_THR; ++it) {
-      const int e = tid + it * 512;
-      const int row = e / SLOTS, slot = e % SLOTS;
-      int rr = j * KVT + row;
-      rr = rr < rows ? rr : rows - 1;               // clamp padded tail rows (masked later)
-      const int64_t grow = row0 + (rr - j * KVT);
-      kreg[it] = *reinterpret_cast<const u32x4*>(kbase + grow * p.k_rs + slot * 8);
-      vreg[it] = *reinterpret_cast<const u32x4*>(vbase + grow * p.v_rs + slot * 8);
+  // ---- tile iterator ------------------------------------------------------------------------------
+  auto enter_chunk = [&](TileIt& t) __attribute__((always_inline)) {   // skip chunks with nothing to visit
+    while (t.c < p.n_kv_chunks) {
+      t.rows = (t.c == p.n_kv_chunks - 1) ? p.kv_valid : p.chunk_len;
+      const int all = (t.rows + KVT - 1) / KVT;
+      const int gk = p.kv_gid[t.c];
+      t.diag = CAUSAL && gk == gq;
+      t.n = (!CAUSAL || gk < gq) ? all : (gk > gq ? 0 : min(all, q_last_wg / KVT + 1));
+      if (t.n > 0) { t.crow = p.kv_row[t.c]; t.j = 0; return; }
+      ++t.c;
     }
   };
-  auto write_lds = [&](char* stage) {
-#pragma unroll
-    for (int it = 0; it < LD_PER_THR; ++it) {
-      const int e = tid + it * 512;
-      const int row = e / SLOTS, slot = e % SLOTS;
-      *reinterpret_cast<u32x4*>(stage + k_lds_off<D>(row, slot)) = kreg[it];
-      *reinterpret_cast<u32x4*>(stage + TILEB + v_lds_off<D>(row, slot >> 1, (slot & 1) << 4)) = vreg[it];
-    }
+  auto advance = [&](TileIt& t) __attribute__((always_inline)) {
+    if (++t.j == t.n) { ++t.c; enter_chunk(t); }
   };
 
-  // ---- tile iterator over (chunk, tile) pairs -------------------------------------------------
-  int c_cur = 0, j_cur = 0, n_cur = 0;
-  while (c_cur < p.n_kv_chunks && (n_cur = chunk_tiles(c_cur)) == 0) ++c_cur;
-  const bool any = c_cur < p.n_kv_chunks;
-  if (any) {
-    issue_loads(c_cur, 0);
-    write_lds(smem);
+  // LDS-DMA path: wave w issues pieces q = 0..PIECES-1 of K and of V; piece (w, q) = rows
+  // 4*(w*PIECES+q)*(256/ROWB).. of the tile (1 KiB), lane i lands at byte 16*i of the piece.
+  constexpr int PIECES = TILEB / 1024 / 8;             // wave-instructions per operand per wave
+  constexpr int RPP = 1024 / ROWB;                      // tile rows per 1-KiB piece
+  typedef __attribute__((address_space(1))) const void gvoid;
+  typedef __attribute__((address_space(3))) void lvoid;
+  unsigned dk_off[PIECES], dv_off[PIECES];             // per-lane source offsets (elements) inside a tile
+  int d_row[PIECES], d_ks[PIECES], d_vs[PIECES];
+#pragma unroll
+  for (int q = 0; q < PIECES; ++q) {
+    const int row = (wave * PIECES + q) * RPP + lane / SLOTS;   // tile row this lane fills
+    const int ps = lane % SLOTS;                                 // physical 16-byte slot in the row
+    // logical slot whose data must land at physical slot ps (inverse of the read swizzles)
+    d_ks[q] = (D == 128) ? (ps ^ (row & 15)) : (ps ^ ((row >> 1) & 7));
+    d_vs[q] = (D == 128) ? ((((ps >> 1) ^ ((row & 3) << 1)) << 1) | (ps & 1))
+                         : ((((ps >> 1) ^ (row & 2)) << 1) | (ps & 1));
+    d_row[q] = row;
+    dk_off[q] = (unsigned)(row * p.k_rs + d_ks[q] * 8);
+    dv_off[q] = (unsigned)(row * p.v_rs + d_vs[q] * 8);
   }
-  __syncthreads();
-
-  int stage = 0;
-  while (c_cur < p.n_kv_chunks) {
-    // next tile
-    int c_nxt = c_cur, j_nxt = j_cur + 1, n_nxt = n_cur;
-    if (j_nxt == n_cur) {
-      j_nxt = 0;
-      ++c_nxt;
-      while (c_nxt < p.n_kv_chunks && (n_nxt = chunk_tiles(c_nxt)) == 0) ++c_nxt;
-    }
-    const bool has_next = c_nxt < p.n_kv_chunks;
-    if (has_next) issue_loads(c_nxt, j_nxt);
-
-    const char* kt = smem + stage * (2 * TILEB);
-    const char* vt = kt + TILEB;
-    const int kv_off = j_cur * KVT;                  // tile offset inside its chunk
-    const bool diag = CAUSAL && p.kv_gid[c_cur] == gq;
-    const int kv_rows = (c_cur == p.n_kv_chunks - 1) ? p.kv_valid : p.chunk_len;
-    const bool tail = kv_off + KVT > kv_rows;
-    // wave-uniform skip: the whole tile lies after this wave's last query row
-    const bool skip = diag && kv_off > q_off + 31;
-
-    if (!skip) {
-      // ---- S^T = K Q^T : two 32(key) x 32(query) blocks --------------------------------------
-      f32x16 s0, s1;
+  auto dma_tile = [&](const TileIt& t, unsigned sl) __attribute__((always_inline)) {
+    const int64_t row0 = t.crow + (int64_t)t.j * KVT;
+    const bf16_t* kp = kbase + row0 * p.k_rs;           // wave-uniform bases + 32-bit lane offsets
+    const bf16_t* vp = vbase + row0 * p.v_rs;
+    const int left = t.rows - t.j * KVT;               // valid rows in this tile (>= 1)
+    if (left >= KVT) {
 #pragma unroll
-      for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+      for (int q = 0; q < PIECES; ++q) {
+        const int piece = wave * PIECES + q;
+        __builtin_amdgcn_global_load_lds((gvoid*)(kp + dk_off[q]), (lvoid*)(uintptr_t)(sl + piece * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gvoid*)(vp + dv_off[q]), (lvoid*)(uintptr_t)(sl + TILEB + piece * 1024), 16, 0, 0);
+      }
+    } else {                                            // padded tail: clamp rows (masked later)
+#pragma unroll
+      for (int q = 0; q < PIECES; ++q) {
+        const int piece = wave * PIECES + q;
+        const int row = d_row[q] < left ? d_row[q] : left - 1;
+        __builtin_amdgcn_global_load_lds((gvoid*)(kp + (int64_t)row * p.k_rs + d_ks[q] * 8),
+                                         (lvoid*)(uintptr_t)(sl + piece * 1024), 16, 0, 0);
+        __builtin_amdgcn_global_load_lds((gvoid*)(vp + (int64_t)row * p.v_rs + d_vs[q] * 8),
+                                         (lvoid*)(uintptr_t)(sl + TILEB + piece * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  u32x4 kreg[LD_PER_THR], vreg[LD_PER_THR];
+  auto issue_loads = [&](const TileIt& t) __attribute__((always_inline)) {
+    const int64_t row0 = t.crow + (int64_t)t.j * KVT;
+    const bf16_t* kp = kbase + row0 * p.k_rs;          // wave-uniform base + 32-bit lane offset
+    const bf16_t* vp = vbase + row0 * p.v_rs;
+    const int left = t.rows - t.j * KVT;               // valid rows in this tile
+    if (left >= KVT) {
+#pragma unroll
+      for (int it = 0; it < LD_PER_THR; ++it) {
+        kreg[it] = *reinterpret_cast<const u32x4*>(kp + g_koff[it]);
+        vreg[it] = *reinterpret_cast<const u32x4*>(vp + g_voff[it]);
+      }
+    } else {                                            // padded tail: clamp rows (masked later)
+#pragma unroll
+      for (int it = 0; it < LD_PER_THR; ++it) {
+        const int e = tid + it * 512;
+        const int row = min(e / SLOTS, left - 1), slot = e % SLOTS;
+        kreg[it] = *reinterpret_cast<const u32x4*>(kp + (int64_t)row * p.k_rs + slot * 8);
+        vreg[it] = *reinterpret_cast<const u32x4*>(vp + (int64_t)row * p.v_rs + slot * 8);
+      }
+    }
+  };
+  auto write_lds = [&](unsigned sl) __attribute__((always_inline)) {
+#pragma unroll
+    for (int it = 0; it < LD_PER_THR; ++it) {
+      *(lds_u32x4*)(uintptr_t)(sl + l_koff[it]) = kreg[it];
+      *(lds_u32x4*)(uintptr_t)(sl + l_voff[it]) = vreg[it];
+    }
+  };
+
+  // ---- the phases of one tile -----------------------------------------------------------------
+  f32x16 s0, s1;
+  auto qk_phase = [&](unsigned sl) __attribute__((always_inline)) {     // sl = LDS address of the slot
+#pragma unroll
+    for (int r = 0; r < 16; ++r) { s0[r] = 0.f; s1[r] = 0.f; }
+    bf16x8 ka[DS], kb[DS];
+#pragma unroll
+    for (int ds = 0; ds < DS; ++ds) {
+      const unsigned a = sl + koff[ds];
+      ka[ds] = *(lds_bf16x8*)(uintptr_t)(a);
+      kb[ds] = *(lds_bf16x8*)(uintptr_t)(a + 32 * ROWB);
+    }
+#pragma unroll
+    for (int ds = 0; ds < DS; ++ds) {
+      s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ds], qf[ds], s0, 0, 0, 0);
+      s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[ds], qf[ds], s1, 0, 0, 0);
+    }
+    if (QK_AHEAD > 0) {
+      // pin the issue order: K fragments run QK_AHEAD k-steps ahead of the MFMAs that consume them
+      __builtin_amdgcn_sched_group_barrier(0x100, 2 * QK_AHEAD, 0);
 #pragma unroll
       for (int ds = 0; ds < DS; ++ds) {
-        const bf16x8 k0 = *reinterpret_cast<const bf16x8*>(kt + k_lds_off<D>(l31, 2 * ds + hi));
-        const bf16x8 k1 = *reinterpret_cast<const bf16x8*>(kt + k_lds_off<D>(32 + l31, 2 * ds + hi));
-        s0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k0, qf[ds], s0, 0, 0, 0);
-        s1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(k1, qf[ds], s1, 0, 0, 0);
-      }
-      // key index (inside the tile) of accumulator register r: (r&3) + 8*(r>>2) + 4*hi (+32 for s1)
-      if (diag || tail) {
-        const int lim_c = diag ? (my_q - kv_off) : 0x7fffffff;        // key <= lim_c visible
-        const int lim_t = kv_rows - kv_off - 1;                        // key <= lim_t valid
-        const int lim = min(lim_c, lim_t);
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = (r & 3) + 8 * (r >> 2) + 4 * hi;
-          if (key > lim) s0[r] = -INFINITY;
-          if (key + 32 > lim) s1[r] = -INFINITY;
-        }
-      }
-      // ---- online softmax (log2 domain) --------------------------------------------------------
-      float mx = fmaxf(s0[0], s1[0]);
-#pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(mx, fmaxf(s0[r], s1[r]));
-      mx = swap32_max(mx);
-      const float m_new = fmaxf(m_run, mx * p.scale_log2e);
-      const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-      m_run = m_new;
-      float psum = 0.f;
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], p.scale_log2e, -m_new));
-        s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], p.scale_log2e, -m_new));
-        psum += s0[r] + s1[r];
-      }
-      l_run = l_run * alpha + psum;
-      if (!__all(alpha == 1.0f)) {
-#pragma unroll
-        for (int i = 0; i < DB; ++i)
-#pragma unroll
-          for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
-      }
-      // ---- P^T operand: step t uses registers 8*(t&1).. of block t>>1 ---------------------------
-      bf16x8 pf[4];
-#pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        pf[0][j] = (__bf16)s0[j];
-        pf[1][j] = (__bf16)s0[8 + j];
-        pf[2][j] = (__bf16)s1[j];
-        pf[3][j] = (__bf16)s1[8 + j];
-      }
-      // ---- O^T += V^T P^T ------------------------------------------------------------------------
-      // V^T A-operand for step t, row block db: lane (d = 32*db + l31, k-half hi) needs keys
-      // 16t + 4hi + {0..3} and 16t + 8 + 4hi + {0..3}: two transpose reads.  Inside a 16-lane
-      // group, lane i supplies the 8-byte piece (row i>>2, columns 4*(i&3)..) of a 4x16 block.
-      const int g16 = lane >> 4, i16 = lane & 15;
-      const int v_key_l = 4 * (g16 >> 1) + (i16 >> 2);          // + 16 t (+8)
-      const int v_col_l = 16 * (g16 & 1) + 4 * (i16 & 3);       // + 32 db
-#pragma unroll
-      for (int t = 0; t < 4; ++t) {
-#pragma unroll
-        for (int db = 0; db < DB; ++db) {
-          const int col = 32 * db + v_col_l;
-          const int r0 = 16 * t + v_key_l, r1 = r0 + 8;
-          const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4*)(vt + v_lds_off<D>(r0, col >> 4, (col & 15) * 2)));
-          const s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
-              (__attribute__((address_space(3))) s16x4*)(vt + v_lds_off<D>(r1, col >> 4, (col & 15) * 2)));
-          union { struct { s16x4 lo, hi; } s; bf16x8 v; } u;
-          u.s.lo = a; u.s.hi = c;
-          o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(u.v, pf[t], o_acc[db], 0, 0, 0);
-        }
+        __builtin_amdgcn_sched_group_barrier(0x008, 2, 0);
+        if (ds + QK_AHEAD < DS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
       }
     }
+  };
+  auto sm_pv_phase = [&](unsigned sl, int kv_off, bool diag, int kv_rows) __attribute__((always_inline)) {
+    // key index (inside the tile) of accumulator register r: (r&3) + 8*(r>>2) + 4*hi (+32 for s1)
+    const bool need_mask = (diag && kv_off + KVT - 1 > q_off) || (kv_off + KVT > kv_rows);
+    if (need_mask) {
+      const int lim_c = diag ? (my_q - kv_off) : 0x7fffffff;        // key <= lim_c visible
+      const int lim = min(lim_c, kv_rows - kv_off - 1);              // key <= .. valid
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int key = (r & 3) + 8 * (r >> 2) + 4 * hi;
+        if (key > lim) s0[r] = -INFINITY;
+        if (key + 32 > lim) s1[r] = -INFINITY;
+      }
+    }
+    // online softmax, log2 domain
+    float mx = fmaxf(s0[0], s1[0]);
+#pragma unroll
+    for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(s0[r], s1[r]), mx);
+    mx = swap32_max(mx);
+    const float m_new = fmaxf(m_run, mx * scale_log2e);
+    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
+    m_run = m_new;
+    float psum = 0.f;
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      s0[r] = __builtin_amdgcn_exp2f(fmaf(s0[r], scale_log2e, -m_new));
+      s1[r] = __builtin_amdgcn_exp2f(fmaf(s1[r], scale_log2e, -m_new));
+      psum += s0[r] + s1[r];
+    }
+    l_run = l_run * alpha + psum;
+    if (!__all(alpha == 1.0f)) {
+#pragma unroll
+      for (int i = 0; i < DB; ++i)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
+    }
+    // P^T operand: step t uses registers 8*(t&1).. of block t>>1 (any consistent key <-> k-slot
+    // assignment is valid; the V^T fragment below uses the same one)
+    bf16x8 pf[4];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      pf[0][j] = (__bf16)s0[j];
+      pf[1][j] = (__bf16)s0[8 + j];
+      pf[2][j] = (__bf16)s1[j];
+      pf[3][j] = (__bf16)s1[8 + j];
+    }
+    unsigned va[DB];
+#pragma unroll
+    for (int db = 0; db < DB; ++db) va[db] = sl + voff[db];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+#pragma unroll
+      for (int db = 0; db < DB; ++db) {
+        const unsigned vp = va[db] + 16 * t * ROWB;
+        const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(vp));
+        const s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(vp + 8 * ROWB));
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        const s16x8 ac = __builtin_shufflevector(a, c, 0, 1, 2, 3, 4, 5, 6, 7);
+        o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, ac), pf[t], o_acc[db], 0, 0, 0);
+      }
+    }
+  };
 
-    if (has_next) write_lds(smem + (stage ^ 1) * (2 * TILEB));
+  // ---- prologue: tile 0 -> LDS slot 0, tile 1 -> registers --------------------------------------
+  TileIt cur;
+  cur.c = 0; cur.j = 0; cur.n = 0; cur.rows = 0; cur.diag = 0; cur.crow = 0;
+  enter_chunk(cur);
+  TileIt nx1 = cur;                                   // tile t+1 (its data sits in registers)
+  if (cur.c < p.n_kv_chunks) {
+    if (GLDS) {
+      dma_tile(cur, lds0);
+      advance(nx1);
+    } else {
+      issue_loads(cur);
+      write_lds(lds0);
+      advance(nx1);
+      if (nx1.c < p.n_kv_chunks) issue_loads(nx1);
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  unsigned long long t_top = 0, t_qk = 0, t_sm = 0, t_bar = 0, t_n = 0, tc = 0;
+  auto tick = [&](unsigned long long& acc) __attribute__((always_inline)) {
+    if (TIMING) { const unsigned long long now = __builtin_amdgcn_s_memtime(); acc += now - tc; tc = now; }
+  };
+  if (TIMING) tc = __builtin_amdgcn_s_memtime();
+
+  int slot = 0;
+  while (cur.c < p.n_kv_chunks) {
+    const bool has_n1 = nx1.c < p.n_kv_chunks;
+    TileIt nx2 = nx1;
+    // tile t+1 -> the other LDS slot (every wave finished reading it before the last barrier)
+    if (has_n1) {
+      if (GLDS) {
+        dma_tile(nx1, lds0 + (slot ^ 1) * SLOTB);      // lands under this tile's MFMA work
+        advance(nx2);
+      } else {
+        write_lds(lds0 + (slot ^ 1) * SLOTB);          // registers -> LDS
+        advance(nx2);
+        if (nx2.c < p.n_kv_chunks) issue_loads(nx2);    // tile t+2: HBM/L2 -> registers
+      }
+    }
+    const unsigned sl = lds0 + slot * SLOTB;
+    const int kv_off = cur.j * KVT;                  // tile offset inside its chunk
+    // wave-uniform skip: the whole tile lies after this wave's last query row
+    const bool skip = cur.diag && kv_off > q_off + 31;
+    tick(t_top);
+    if (!skip) {
+      qk_phase(sl);
+      if (TIMING) { asm volatile("s_nop 0" :: "v"(s0[15]), "v"(s1[15])); tick(t_qk); }
+      sm_pv_phase(sl, kv_off, cur.diag, cur.rows);
+      if (TIMING) { asm volatile("s_nop 0" :: "v"(o_acc[DB - 1][15])); tick(t_sm); }
+    }
+    if (GLDS) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's DMA pieces have landed
     __syncthreads();
-    stage ^= 1;
-    c_cur = c_nxt; j_cur = j_nxt; n_cur = n_nxt;
+    tick(t_bar);
+    ++t_n;
+    slot ^= 1;
+    cur = nx1;
+    nx1 = nx2;
+  }
+  if (TIMING && lane == 0 && (wave == 0 || wave == 4)) {
+    unsigned long long* g = g_attn_timing + (wave == 4 ? 8 : 0);
+    atomicAdd(g + 0, t_top); atomicAdd(g + 1, t_qk); atomicAdd(g + 2, t_sm); atomicAdd(g + 3, t_bar); atomicAdd(g + 4, t_n);
   }
 
   // ---- epilogue ----------------------------------------------------------------------------------
@@ -302,20 +453,58 @@ __global__ __launch_bounds__(512, 2) void flash_fwd_kernel(AttnArgs p) {
   }
 }
 
-template <int D, bool CAUSAL>
-int launch_attn(const AttnArgs& a, int64_t nblocks, hipStream_t st) {
+template <int D, bool CAUSAL, int VARIANT, bool TIMING = false>
+int launch_attn_v(const AttnArgs& a, int64_t nblocks, hipStream_t st) {
   constexpr int lds = 2 * 2 * KVT * D * 2;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd_kernel<D, CAUSAL>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd_kernel<D, CAUSAL, VARIANT, TIMING>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL((flash_fwd_kernel<D, CAUSAL>), dim3((unsigned)nblocks), dim3(512), lds, st, a);
+  hipLaunchKernelGGL((flash_fwd_kernel<D, CAUSAL, VARIANT, TIMING>), dim3((unsigned)nblocks), dim3(512), lds, st, a);
   return vita_check_launch();
 }
 
+// VITA_ATTN_VARIANT (developer tuning aid): bits 0-3 = kernel VARIANT (default 6 = LDS-DMA + QK_AHEAD 3), bit 4 = phase timers.
+inline int attn_variant() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("VITA_ATTN_VARIANT");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
+template <int D, bool CAUSAL>
+int launch_attn(const AttnArgs& a, int64_t nblocks, hipStream_t st) {
+  const int v = attn_variant();
+  if ((v & 16) && D == 128 && CAUSAL) {
+    switch (v & 15) {
+      case 1: return launch_attn_v<128, true, 1, true>(a, nblocks, st);
+      case 0: return launch_attn_v<128, true, 0, true>(a, nblocks, st);
+      default: return launch_attn_v<128, true, 6, true>(a, nblocks, st);
+    }
+  }
+  switch (v & 15) {
+    case 1: return launch_attn_v<D, CAUSAL, 1>(a, nblocks, st);
+    case 0: return launch_attn_v<D, CAUSAL, 0>(a, nblocks, st);
+    default: return launch_attn_v<D, CAUSAL, 6>(a, nblocks, st);
+  }
+}
+
 }  // namespace
+
+// developer aid, not part of the public ABI: copy (and optionally clear) the phase timers
+extern "C" int vita_debug_attn_timing(unsigned long long* host_out16, int reset) {
+  if (host_out16 && hipMemcpyFromSymbol(host_out16, HIP_SYMBOL(g_attn_timing), 16 * sizeof(unsigned long long)) != hipSuccess)
+    return VITA_ERR_LAUNCH;
+  if (reset) {
+    unsigned long long z[16] = {0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_attn_timing), z, sizeof(z)) != hipSuccess) return VITA_ERR_LAUNCH;
+  }
+  return VITA_OK;
+}
 
 extern "C" int vita_flash_attn_fwd(const vita_attn_params* p, void* stream) {
   if (!p || !p->q || !p->k || !p->v || !p->o) return VITA_ERR_INVALID_ARG;

@@ -1,0 +1,17 @@
+"""Aggregate rocprofv3 counter_collection.csv files: mean counter value per kernel per dispatch."""
+import csv, glob, sys, collections
+def main(root):
+    agg = collections.defaultdict(lambda: collections.defaultdict(list))
+    for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
+        for row in csv.DictReader(open(f)):
+            k = row["Kernel_Name"]
+            if "flash_fwd" in k: k = "flash_fwd<" + ("128" if "128" in k else "64") + ">"
+            elif "gemm_bf16" in k: k = "gemm_bf16<" + k.split("<")[1].split(">")[0] + ">"
+            else: continue
+            agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
+    for k in sorted(agg):
+        print(k)
+        for c in sorted(agg[k]):
+            v = agg[k][c]
+            print(f"   {c:28s} n={len(v):3d} mean={sum(v)/len(v):.6g}")
+main(sys.argv[1])
