@@ -92,7 +92,9 @@ struct TileIt {
 //       on the fragment reads); no staging VGPRs, no ds_write burst behind the barrier;
 //   1 = register staging (global_load -> VGPR -> ds_write_b128), loads issued two tiles ahead;
 //   bits 1-2 = QK_AHEAD: K-fragment reads pinned that many k-steps ahead of their MFMAs.
-// (A 3-slot "staggered" variant — waves 4..7 half a tile behind waves 0..3 — measured 0 to -3 %.)
+// Measured and dropped: a 3-slot "staggered" schedule (waves 4..7 half a tile behind
+// waves 0..3): 0 to -3 %; s_setprio around the MFMA clusters: -2 %; a 4-wave x 64-row variant with
+// one wave per SIMD and compiler-allocated AGPRs: -19 %.
 template <int D, bool CAUSAL, int VARIANT = 0, bool TIMING = false>
 __global__ __launch_bounds__(512, 2) void flash_fwd_kernel(AttnArgs p) {
   constexpr int DS = D / 16;              // QK^T k-steps
