@@ -20,15 +20,15 @@
 //
 // Replaces torch.matmul / TE linears (see include/vita_hip.h).
 #include "vita_common.h"
+#include <stdlib.h>
 
 namespace {
 
-constexpr int BM = 128, BN = 128, BK = 64;
-constexpr int kTileBytes = BM * BK * 2;          // 16 KiB per operand tile
-constexpr int kStageBytes = 2 * kTileBytes;      // A + W
-constexpr int kLdsBytes = 2 * kStageBytes;       // double buffer = 64 KiB
+constexpr int BK = 64;
 
 typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(3))) const bf16x8 lds_bf16x8;
+typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
 
 struct GemmArgs {
@@ -45,31 +45,30 @@ __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
 
-// Stage one [128][64] tile (rows row0.., k offset k0) of a K-contiguous matrix into LDS.
-// `rowmap(r)` gives the global row for tile row r (clamped / permuted by the caller).
-template <typename RowMap>
-__device__ __forceinline__ void stage_tile(const bf16_t* __restrict__ base, int64_t ld, int64_t k0,
-                                           char* lds_tile, int wave, int lane, RowMap rowmap) {
-#pragma unroll
-  for (int q = 0; q < 4; ++q) {
-    const int rbase = (wave * 4 + q) * 8;          // 8 tile rows per wave-instruction (1 KiB)
-    const int lr = rbase + (lane >> 3);            // tile row written by this lane
-    const int ps = lane & 7;                       // physical 16-B slot inside the 128-B row
-    const int ls = ps ^ ((lr >> 1) & 7);           // logical slot whose data must land there
-    const bf16_t* src = base + rowmap(lr) * ld + k0 + ls * 8;
-    __builtin_amdgcn_global_load_lds((gbl_cvoid*)src, (lds_void*)(lds_tile + rbase * 128), 16, 0, 0);
-  }
+// LDS image of a [rows][64] bf16 tile: 128-byte rows, 16-byte slot s of row r stored at
+// slot s ^ ((r >> 1) & 7)  (conflict-free for the 16-lane groups of ds_read_b128).
+__device__ __forceinline__ int tile_off(int row, int slot) {
+  return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
 }
 
-__device__ __forceinline__ bf16x8 lds_frag(const char* lds_tile, int row, int slot) {
-  return *reinterpret_cast<const bf16x8*>(lds_tile + row * 128 + ((slot ^ ((row >> 1) & 7)) << 4));
-}
+// One workgroup = WM x WN waves = one BM x BN output tile; each wave owns (BM/WM) x (BN/WN).
+//   <128,128,2,2>: 4 waves, 64 KiB LDS, 2 workgroups per CU (small / ragged problems)
+//   <256,256,2,4>: 8 waves, 128 KiB LDS, per-wave tile 128 x 64 -> 0.75 LDS fragment reads and
+//                  0.25 KiB of DMA per MFMA instead of 1.0 / 0.5 (the 128^2 tile is LDS-bound)
+template <int EPI, int BM, int BN, int WM, int WN, bool PIN = true>
+__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(GemmArgs p) {
+  constexpr int NW = WM * WN;
+  constexpr int TM = BM / WM, TN = BN / WN;          // per-wave tile
+  constexpr int MI = TM / 32, NI = TN / 32;          // 32x32 MFMA blocks per wave
+  constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
+  constexpr int QA = BM / 8 / NW, QW = BN / 8 / NW;  // 1-KiB DMA pieces per wave per operand
+  static_assert(EPI != VITA_EPI_SWIGLU || TN == 64, "SwiGLU epilogue pairs the two 32-column blocks of a wave");
 
-template <int EPI>
-__global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
 
   // ---- XCD-aware, grouped tile order -------------------------------------------------------
   const int nwg = p.tiles_m * p.tiles_n;
@@ -78,7 +77,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
     const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  constexpr int GROUP_M = 8;
+  constexpr int GROUP_M = (BM == 256) ? 4 : 8;
   const int per_group = GROUP_M * p.tiles_n;
   const int group = pid / per_group;
   const int first_m = group * GROUP_M;
@@ -88,60 +87,108 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
   const int tn = in_group / gsz;
 
   const int64_t m0 = (int64_t)tm * BM;
-  // output-column origin of this tile: SWIGLU packs 64 outputs (gate+up) per 128 W rows
+  // output-column origin of this tile: SWIGLU packs BN/2 outputs (gate+up) per BN W rows
   const int64_t n0 = (int64_t)tn * (EPI == VITA_EPI_SWIGLU ? BN / 2 : BN);
 
-  auto a_row = [&](int r) -> int64_t {
-    const int64_t g = m0 + r;
-    return g < p.M ? g : p.M - 1;
-  };
-  auto w_row = [&](int r) -> int64_t {
+  // ---- DMA source pointers (advanced by BK per K tile) and LDS piece offsets ------------------
+  // a wave-instruction moves 8 tile rows (1 KiB); lane -> (row rbase + lane/8, physical slot lane&7),
+  // which must receive logical slot ps ^ ((row>>1)&7): the swizzle is applied on the SOURCE side.
+  const bf16_t* a_src[QA];
+  const bf16_t* w_src[QW];
+#pragma unroll
+  for (int q = 0; q < QA; ++q) {
+    const int lr = (wave * QA + q) * 8 + (lane >> 3);
+    const int ls = (lane & 7) ^ ((lr >> 1) & 7);
+    int64_t g = m0 + lr;
+    g = g < p.M ? g : p.M - 1;
+    a_src[q] = p.A + g * p.lda + ls * 8;
+  }
+#pragma unroll
+  for (int q = 0; q < QW; ++q) {
+    const int lr = (wave * QW + q) * 8 + (lane >> 3);
+    const int ls = (lane & 7) ^ ((lr >> 1) & 7);
+    int64_t g;
     if (EPI == VITA_EPI_SWIGLU) {
-      // tile row r: blk = r / 32; blk&1 = 0 gate / 1 up; output column = n0 + (blk>>1)*32 + r%32
-      const int blk = r >> 5;
-      int64_t oc = n0 + (blk >> 1) * 32 + (r & 31);
-      if (oc >= p.N) oc = p.N - 1;
-      return ((blk & 1) ? p.N : 0) + oc;
+      // tile row lr: blk = lr / 32; blk&1 = 0 gate / 1 up; output column = n0 + (blk>>1)*32 + lr%32
+      const int blk = lr >> 5;
+      int64_t oc = n0 + (blk >> 1) * 32 + (lr & 31);
+      oc = oc < p.N ? oc : p.N - 1;
+      g = ((blk & 1) ? p.N : 0) + oc;
     } else {
-      const int64_t g = n0 + r;
-      return g < p.N ? g : p.N - 1;
+      g = n0 + lr;
+      g = g < p.N ? g : p.N - 1;
+    }
+    w_src[q] = p.W + g * p.ldw + ls * 8;
+  }
+  auto stage = [&](unsigned sl) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < QA; ++q) {
+      __builtin_amdgcn_global_load_lds((gbl_cvoid*)a_src[q], (lds_void*)(uintptr_t)(sl + (wave * QA + q) * 1024), 16, 0, 0);
+      a_src[q] += BK;
+    }
+#pragma unroll
+    for (int q = 0; q < QW; ++q) {
+      __builtin_amdgcn_global_load_lds((gbl_cvoid*)w_src[q], (lds_void*)(uintptr_t)(sl + A_BYTES + (wave * QW + q) * 1024), 16, 0, 0);
+      w_src[q] += BK;
     }
   };
 
-  f32x16 acc[2][2];  // [ni][mi] : 32 output columns x 32 rows each (transposed MFMA output)
+  // ---- per-lane fragment offsets: rows wm*TM + l31 (+32*mi as immediates), slot 2*kk + (lane>>5) ----
+  unsigned fa[4], fw[4];
 #pragma unroll
-  for (int i = 0; i < 2; ++i)
+  for (int kk = 0; kk < 4; ++kk) {
+    fa[kk] = tile_off(wm * TM + (lane & 31), kk * 2 + (lane >> 5));
+    fw[kk] = A_BYTES + tile_off(wn * TN + (lane & 31), kk * 2 + (lane >> 5));
+  }
+
+  f32x16 acc[NI][MI];  // [ni][mi]: 32 output columns x 32 rows each (transposed MFMA output)
 #pragma unroll
-    for (int j = 0; j < 2; ++j)
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j)
 #pragma unroll
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = (int)(p.K / BK);
-  stage_tile(p.A, p.lda, 0, smem, wave, lane, a_row);
-  stage_tile(p.W, p.ldw, 0, smem + kTileBytes, wave, lane, w_row);
+  stage(lds0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
-  const int frow_a = wm * 64 + (lane & 31), frow_w = wn * 64 + (lane & 31), fg = lane >> 5;
   for (int t = 0; t < nk; ++t) {
-    char* cur = smem + (t & 1) * kStageBytes;
-    char* nxt = smem + ((t + 1) & 1) * kStageBytes;
-    if (t + 1 < nk) {
-      stage_tile(p.A, p.lda, (int64_t)(t + 1) * BK, nxt, wave, lane, a_row);
-      stage_tile(p.W, p.ldw, (int64_t)(t + 1) * BK, nxt + kTileBytes, wave, lane, w_row);
-    }
-    const char* ta = cur;
-    const char* tw = cur + kTileBytes;
+    const unsigned cur = lds0 + (t & 1) * STAGE;
+    if (t + 1 < nk) stage(lds0 + ((t + 1) & 1) * STAGE);
+    bf16x8 af[4][MI], wf[4][NI];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
-      const bf16x8 a0 = lds_frag(ta, frow_a, kk * 2 + fg);
-      const bf16x8 a1 = lds_frag(ta, frow_a + 32, kk * 2 + fg);
-      const bf16x8 w0 = lds_frag(tw, frow_w, kk * 2 + fg);
-      const bf16x8 w1 = lds_frag(tw, frow_w + 32, kk * 2 + fg);
-      acc[0][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a0, acc[0][0], 0, 0, 0);
-      acc[0][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w0, a1, acc[0][1], 0, 0, 0);
-      acc[1][0] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a0, acc[1][0], 0, 0, 0);
-      acc[1][1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(w1, a1, acc[1][1], 0, 0, 0);
+#pragma unroll
+      for (int mi = 0; mi < MI; ++mi) af[kk][mi] = *(lds_bf16x8*)(uintptr_t)(cur + fa[kk] + mi * 32 * 128);
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) wf[kk][ni] = *(lds_bf16x8*)(uintptr_t)(cur + fw[kk] + ni * 32 * 128);
+    }
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk)
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi)
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][ni], af[kk][mi], acc[ni][mi], 0, 0, 0);
+    if (PIN) {
+      // issue order: fragments of k-step s+1 are read while the MFMAs of k-step s run
+      constexpr int NF = MI + NI, NM = MI * NI;
+      __builtin_amdgcn_sched_group_barrier(0x100, NF, 0);
+#pragma unroll
+      for (int kk = 0; kk < 4; ++kk) {
+        if (kk < 3) {
+#pragma unroll
+          for (int i = 0; i < NF; ++i) {
+            if (i < NM) __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          if (NM > NF) __builtin_amdgcn_sched_group_barrier(0x008, NM - NF, 0);
+        } else {
+          __builtin_amdgcn_sched_group_barrier(0x008, NM, 0);
+        }
+      }
     }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
@@ -150,11 +197,11 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
   // ---- epilogue: lane holds D^T: row m = ... + (lane & 31), columns 8*rg + 4*(lane>>5) + 0..3 --
   const int hi = lane >> 5;
 #pragma unroll
-  for (int mi = 0; mi < 2; ++mi) {
-    const int64_t m = m0 + wm * 64 + mi * 32 + (lane & 31);
+  for (int mi = 0; mi < MI; ++mi) {
+    const int64_t m = m0 + wm * TM + mi * 32 + (lane & 31);
     if (m >= p.M) continue;
     if (EPI == VITA_EPI_SWIGLU) {
-      // wave's 64 tile rows of W = [gate 32 | up 32] for output columns n0 + wn*32 + 0..31
+      // the wave's 64 tile rows of W = [gate 32 | up 32] for output columns n0 + wn*32 + 0..31
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const int64_t n = n0 + wn * 32 + rg * 8 + hi * 4;
@@ -163,7 +210,7 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const float g = bf16_round(acc[0][mi][rg * 4 + j]);
-          const float u = bf16_round(acc[1][mi][rg * 4 + j]);
+          const float u = bf16_round(acc[NI - 1][mi][rg * 4 + j]);
           const float s = bf16_round(g / (1.0f + __expf(-g)));
           o[j] = s * u;
         }
@@ -177,10 +224,10 @@ __global__ __launch_bounds__(256) void gemm_bf16_kernel(GemmArgs p) {
       }
     } else {
 #pragma unroll
-      for (int ni = 0; ni < 2; ++ni) {
+      for (int ni = 0; ni < NI; ++ni) {
 #pragma unroll
         for (int rg = 0; rg < 4; ++rg) {
-          const int64_t n = n0 + wn * 64 + ni * 32 + rg * 8 + hi * 4;
+          const int64_t n = n0 + wn * TN + ni * 32 + rg * 8 + hi * 4;
           if (n >= p.N) continue;
           const bool full = n + 3 < p.N;
           float o[4];
@@ -275,17 +322,45 @@ __global__ __launch_bounds__(256) void gemm_skinny_kernel(const bf16_t* __restri
   }
 }
 
-template <int EPI>
-int launch_gemm(const GemmArgs& a, hipStream_t st) {
+template <int EPI, int BM, int BN, int WM, int WN, bool PIN = true>
+int launch_gemm_cfg(GemmArgs a, hipStream_t st) {
+  constexpr int lds = 2 * (BM + BN) * BK * 2;
+  const int64_t tm = (a.M + BM - 1) / BM;
+  const int64_t bn_out = EPI == VITA_EPI_SWIGLU ? BN / 2 : BN;
+  const int64_t tn = (a.N + bn_out - 1) / bn_out;
+  if (tm * tn > 0x7fffffff) return VITA_ERR_UNSUPPORTED;
+  a.tiles_m = (int)tm; a.tiles_n = (int)tn;
   static bool attr_set = false;
   if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, kLdsBytes);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, WM, WN, PIN>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
     attr_set = true;
   }
-  hipLaunchKernelGGL(gemm_bf16_kernel<EPI>, dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256),
-                     kLdsBytes, st, a);
+  hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN, PIN>), dim3((unsigned)(tm * tn)), dim3(64 * WM * WN), lds, st, a);
   return vita_check_launch();
+}
+
+// VITA_GEMM_TILE=128|256 forces a tile configuration (developer tuning aid).
+inline int gemm_tile_override() {
+  static int v = -1;
+  if (v < 0) {
+    const char* e = getenv("VITA_GEMM_TILE");
+    v = e ? atoi(e) : 0;
+  }
+  return v;
+}
+
+template <int EPI>
+int launch_gemm(const GemmArgs& a, hipStream_t st) {
+  // the 256x256 tile needs enough tiles to fill 256 CUs with one workgroup each
+  const int64_t bn_out = EPI == VITA_EPI_SWIGLU ? 128 : 256;
+  const int64_t big_tiles = ((a.M + 255) / 256) * ((a.N + bn_out - 1) / bn_out);
+  bool big = big_tiles >= 192;
+  if (gemm_tile_override() == 128) big = false;
+  if (gemm_tile_override() == 256) big = true;
+  static const bool nopin = getenv("VITA_GEMM_NOPIN") != nullptr;     // developer tuning aid
+  if (nopin) return big ? launch_gemm_cfg<EPI, 256, 256, 2, 4, false>(a, st) : launch_gemm_cfg<EPI, 128, 128, 2, 2, false>(a, st);
+  return big ? launch_gemm_cfg<EPI, 256, 256, 2, 4>(a, st) : launch_gemm_cfg<EPI, 128, 128, 2, 2>(a, st);
 }
 
 }  // namespace
@@ -302,10 +377,7 @@ extern "C" int vita_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
   a.A = (const bf16_t*)A; a.lda = lda; a.W = (const bf16_t*)W; a.ldw = ldw;
   a.C = (bf16_t*)C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
   a.bias = (const bf16_t*)bias; a.scale = (const bf16_t*)scale; a.R = (const bf16_t*)R; a.ldr = ldr;
-  const int64_t tm = (M + BM - 1) / BM;
-  const int64_t tn = epilogue == VITA_EPI_SWIGLU ? (N + BN / 2 - 1) / (BN / 2) : (N + BN - 1) / BN;
-  if (tm * tn > 0x7fffffff) return VITA_ERR_UNSUPPORTED;
-  a.tiles_m = (int)tm; a.tiles_n = (int)tn;
+  a.tiles_m = a.tiles_n = 0;
   hipStream_t st = (hipStream_t)stream;
   switch (epilogue) {
     case VITA_EPI_NONE: return launch_gemm<VITA_EPI_NONE>(a, st);
