@@ -135,6 +135,16 @@ def main():
     attn_flops = 4 * cfg.head_dim * cfg.heads * pairs
     achieved = attn_flops / (attn_ms * 1e-3) / 1e12 if attn_ms > 0 else 0.0
 
+    # HBM traffic of that kernel: PMC counters cannot be read from inside this process; when a
+    # rocprofv3 --pmc measurement of the same launch shape is committed under profiles/, report it
+    traffic, traffic_src = None, None
+    try:
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_attn128k_pmc.json")))
+        if pmc["seq"] == seq and pmc["n_gpus"] == world:
+            traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/r01_attn128k_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, offline)"
+    except (OSError, KeyError, ValueError):
+        pass
+
     ms_per_step = dt / args.steps * 1e3
     value = seq / (dt / args.steps)
     fpt = flops_per_token(seq, frames, cfg, vcfg)
@@ -152,7 +162,7 @@ def main():
                    "end_to_end_frac_of_mfma_peak": fpt * value / world / 1e12 / MFMA_BF16_PEAK_TFLOPS},
         "roofline": {"bound": "mfma", "kernel": "flash_fwd_kernel<128, causal>", "achieved": achieved,
                      "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
-                     "traffic": None, "launches_timed": len(ev_ms), "ms_per_launch": attn_ms,
+                     "traffic": traffic, "traffic_source": traffic_src, "launches_timed": len(ev_ms), "ms_per_launch": attn_ms,
                      "flop_per_launch": attn_flops},
     }
     if rank == 0:

@@ -1,4 +1,5 @@
-"""Tiny driver for rocprofv3 --pmc passes: a few launches of the two dominant kernels."""
+"""Tiny driver for rocprofv3 --pmc passes: a few launches of the two dominant kernels.
+PMC_S = attention sequence length (default 32768); PMC_GEMM=0 skips the GEMM."""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
@@ -8,11 +9,14 @@ DEV = "cuda"
 S = int(os.environ.get("PMC_S", "32768"))
 q = torch.randn(1, S, 40, 128, device=DEV).bfloat16(); k = torch.randn(1, S, 8, 128, device=DEV).bfloat16()
 v = torch.randn(1, S, 8, 128, device=DEV).bfloat16(); o = torch.empty_like(q)
-M = 16384
-a = (torch.randn(M, 5120, device=DEV) * 0.5).bfloat16(); w = (torch.randn(2 * 13824, 5120, device=DEV) * 0.02).bfloat16()
-c = torch.empty(M, 13824, dtype=torch.bfloat16, device=DEV)
+do_gemm = os.environ.get("PMC_GEMM", "1") != "0"
+if do_gemm:
+    M = 16384
+    a = (torch.randn(M, 5120, device=DEV) * 0.5).bfloat16(); w = (torch.randn(2 * 13824, 5120, device=DEV) * 0.02).bfloat16()
+    c = torch.empty(M, 13824, dtype=torch.bfloat16, device=DEV)
 for _ in range(3):
     ops.flash_attn(q, k, v, causal=True, out=o)
-    ops.gemm(a, w, ops.EPI_SWIGLU, out=c)
+    if do_gemm:
+        ops.gemm(a, w, ops.EPI_SWIGLU, out=c)
 torch.cuda.synchronize()
 print("done")
