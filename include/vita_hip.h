@@ -74,6 +74,10 @@ int vita_rope_apply(void* t, int64_t rows, int heads, int head_dim,
  * the context-parallel attention). */
 int vita_rope_qkv_fwd(void* mixed_qkv, int64_t rows, int groups, int q_per_group, int head_dim,
                       const void* cos_tab, const void* sin_tab, void* kv_out, void* stream);
+/* Backward of the rotation on the gradient of the mixed QKV activation (in place): applies the
+ * transpose rotation to the dQ and dK heads, leaves dV untouched. */
+int vita_rope_qkv_bwd(void* d_mixed_qkv, int64_t rows, int groups, int q_per_group, int head_dim,
+                      const void* cos_tab, const void* sin_tab, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
  * Row gather / scatter with int64 indices (bit-exact data movement).
@@ -208,6 +212,82 @@ int vita_vit_assemble(const void* patch_embeds, const void* cls_token, const voi
                       void* x, int64_t n, int n_patches, int hidden, int has_cls, void* stream);
 int vita_pixel_shuffle_ln(const void* x, const void* w, const void* b, void* y, int64_t n,
                           int grid, int hidden, int has_cls, float eps, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
+ * Backward pass (training step, reference: torch autograd over the forward modules; the only
+ * first-party backward code is M/core/tensor_parallel/layers.py:416-534).
+ * ------------------------------------------------------------------------------------------- */
+
+/* dst[c][r] = src[r][c] (bf16).  Used to feed dgrad / wgrad to vita_gemm_bf16, whose operands are
+ * both contraction-contiguous:  dX = dY @ W  = gemm(dY, W^T),   dW = dY^T @ X = gemm(dY^T, X^T)
+ * (grad_input = grad_output.matmul(weight), grad_weight = grad_output.t().matmul(total_input):
+ * layers.py:444, :522-523). */
+int vita_transpose_bf16(const void* src, int64_t ld_src, void* dst, int64_t ld_dst, int64_t rows,
+                        int64_t cols, void* stream);
+
+/* RMSNorm backward of vita_rmsnorm_fwd's expression: dx bf16 (+ `res` when not NULL: the gradient
+ * arriving through the residual connection, dx = bf16(res + bf16(dx_norm))); dw_acc fp32 [cols] is
+ * ACCUMULATED (caller zeroes it; may be NULL). */
+int vita_rmsnorm_bwd(const void* dy, const void* x, const void* w, const void* res, void* dx,
+                     float* dw_acc, int64_t rows, int cols, float eps, void* stream);
+
+/* SwiGLU on the unfused fc1 output y = [gate | up] ([rows, 2*ffn]):  a = bf16(bf16(silu(g)) * u);
+ * backward writes dy = [dgate | dup]. */
+int vita_swiglu_fwd(const void* y, void* a, int64_t rows, int ffn, void* stream);
+int vita_swiglu_bwd(const void* y, const void* da, void* dy, int64_t rows, int ffn, void* stream);
+
+/* dx = bf16(dy * gelu_erf'(x)) over n elements (projector MLP, multimodal_projector.py:53-69). */
+int vita_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, void* stream);
+
+/* LayerNorm parameter gradients (projector pre-norm, M/pretrain_long_vita.py:443-446; its input is the
+ * frozen ViT's output, so no dx):  dgamma += sum_rows dy*xhat, dbeta += sum_rows dy (fp32, accumulated).
+ * prenormalized != 0: x already holds xhat (e.g. vita_pixel_shuffle_ln run with w = 1, b = 0). */
+int vita_layernorm_param_grad(const void* dy, const void* x, float* dgamma, float* dbeta,
+                              int64_t rows, int cols, float eps, int prenormalized, void* stream);
+
+/* Vocabulary cross-entropy of the selected rows (TP = 1 form of Megatron's vocab-parallel CE, called at
+ * M/core/models/multimodal/gpt_vl_model.py:414):  loss[i] = logsumexp(float(logits[i])) - logits[i, label[i]];
+ * when dlogits != NULL also dlogits[i] = bf16((softmax - onehot) * grad_scale[i]) (grad_scale NULL = 1).
+ * Labels outside [0, vocab) set *err_flag. */
+int vita_ce_loss(const void* logits, int64_t ld, const int64_t* labels, float* loss, void* dlogits,
+                 int64_t ld_d, const float* grad_scale, int64_t rows, int vocab, int* err_flag,
+                 void* stream);
+
+/* dst_f32[idx[i], :] += float(src_bf16[i, :]) — word-embedding weight gradient (the backward of
+ * M/core/tensor_parallel/layers.py:216-232); idx[i] < 0 skips row i (visual-token positions). */
+int vita_row_scatter_add_f32(const void* src, const int64_t* idx, float* dst, int64_t dst_rows,
+                             int64_t n, int cols, int* err_flag, void* stream);
+
+/* delta[h, row] = sum_d float(dO[row,h,d]) * float(O[row,h,d])  (attention backward pre-pass). */
+int vita_attn_delta(const void* o, const void* d_o, float* delta, int64_t rows, int heads,
+                    int head_dim, int64_t o_row_stride, int64_t o_head_stride, int64_t do_row_stride,
+                    int64_t do_head_stride, void* stream);
+
+/* Flash attention backward (head_dim 128, causal, batch 1) over the same chunk geometry as
+ * vita_flash_attn_fwd (chunk_len % 128 == 0).  q/k/v are the forward's (rotated) inputs, lse its
+ * log-sum-exp output [n_q_heads, n_q_rows], delta from vita_attn_delta.  dk/dv are written for EVERY
+ * key row of the visible K/V buffer (under context parallelism: the gathered layout, to be
+ * reduce-scattered by the caller). */
+typedef struct {
+  const void* q; int64_t q_row_stride, q_head_stride, q_group_stride;
+  const void* k; int64_t k_row_stride, k_head_stride;
+  const void* v; int64_t v_row_stride, v_head_stride;
+  const void* d_o; int64_t do_row_stride, do_head_stride;
+  const float* lse;
+  const float* delta;
+  void* dq; int64_t dq_row_stride, dq_head_stride, dq_group_stride;
+  void* dk; int64_t dk_row_stride, dk_head_stride;
+  void* dv; int64_t dv_row_stride, dv_head_stride;
+  int n_q_heads, n_kv_heads, head_dim;
+  int64_t chunk_len;
+  int n_q_chunks, n_kv_chunks;
+  const int32_t* q_chunk_gid;      /* host */
+  const int32_t* kv_chunk_gid;     /* host */
+  const int64_t* kv_chunk_row;     /* host */
+  float softmax_scale;
+} vita_attn_bwd_params;
+
+int vita_flash_attn_bwd(const vita_attn_bwd_params* p, void* stream);
 
 #ifdef __cplusplus
 }

@@ -1,0 +1,498 @@
+// Backward-pass kernels (training step, SURVEY.md §8a rows a9/a10/a12/a14/a15 backward halves) that
+// are HBM-bound: transpose, RMSNorm backward, SwiGLU forward/backward, GELU backward, LayerNorm
+// parameter gradients, vocabulary cross-entropy (+ its gradient), fp32 row scatter-add, and the
+// attention-backward pre-pass D = rowsum(dO * O).
+//
+// The reference obtains all of these from torch autograd over the modules of the forward pass
+// (no first-party backward code except M/core/tensor_parallel/layers.py:416-534); each kernel
+// states the forward expression it differentiates, with the reference's bf16 rounding points.
+#include "vita_common.h"
+
+namespace {
+
+inline unsigned grid_for(int64_t total, int block, int64_t cap = 256 * 16) {
+  int64_t g = (total + block - 1) / block;
+  return (unsigned)(g < cap ? (g < 1 ? 1 : g) : cap);
+}
+
+// ---------------------------------------------------------------------------------------------
+// dst[c][r] = src[r][c]   (bf16).  64x64 tiles through LDS (+1 padding), 256 threads.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict__ src, int64_t lds_,
+                                                        bf16_t* __restrict__ dst, int64_t ldd,
+                                                        int64_t R, int64_t C) {
+  __shared__ bf16_t tile[64][66];
+  const int64_t r0 = (int64_t)blockIdx.y * 64, c0 = (int64_t)blockIdx.x * 64;
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;   // 64 x 4
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int r = ty + 4 * i;
+    const int64_t gr = r0 + r, gc = c0 + tx;
+    tile[r][tx] = (gr < R && gc < C) ? src[gr * lds_ + gc] : (bf16_t)0;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    const int c = ty + 4 * i;
+    const int64_t gc = c0 + c, gr = r0 + tx;
+    if (gc < C && gr < R) dst[gc * ldd + gr] = tile[tx][c];
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// RMSNorm backward.  forward (transformer_engine.py:74-79):  n = x_f * rstd (fp32) ;
+//   o = bf16(n) ; y = bf16(o * w).      autograd:  do = bf16(dy * w) ; dn = float(do) ;
+//   dx = bf16( rstd * (dn - n * mean(dn * n)) ) ;  dw = sum_rows bf16(dy * o).
+// One wave per row (strided over rows); dw accumulated per lane in registers, flushed with fp32
+// atomics into dw_acc[cols] (caller zeroes it).
+// ---------------------------------------------------------------------------------------------
+template <int VPL>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy,
+                                                          const bf16_t* __restrict__ x,
+                                                          const bf16_t* __restrict__ w,
+                                                          const bf16_t* __restrict__ res,
+                                                          bf16_t* __restrict__ dx,
+                                                          float* __restrict__ dw_acc, int64_t rows,
+                                                          int cols, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * 4;
+  const int nvec = cols >> 3;
+  float dwl[VPL][8];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dwl[i][j] = 0.f;
+  const u32x4* wr = reinterpret_cast<const u32x4*>(w);
+  for (int64_t row = wave_id; row < rows; row += n_waves) {
+    const u32x4* xr = reinterpret_cast<const u32x4*>(x + row * (int64_t)cols);
+    const u32x4* gr = reinterpret_cast<const u32x4*>(dy + row * (int64_t)cols);
+    u32x4 xv[VPL], gv[VPL];
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int vi = lane + i * 64;
+      if (vi < nvec) {
+        xv[i] = xr[vi];
+        gv[i] = gr[vi];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a = bf16lo_to_f32(xv[i][j]), b = bf16hi_to_f32(xv[i][j]);
+          ss += a * a + b * b;
+        }
+      }
+    }
+    const float rstd = rsqrtf(wave_reduce_sum(ss) / (float)cols + eps);
+    // pass 2: do = bf16(dy*w) ; c = mean(do * n) ; dw += bf16(dy * bf16(n))
+    float dot = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int vi = lane + i * 64;
+      if (vi < nvec) {
+        const u32x4 wv = wr[vi];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float x0 = bf16lo_to_f32(xv[i][j]) * rstd, x1 = bf16hi_to_f32(xv[i][j]) * rstd;
+          const float g0 = bf16lo_to_f32(gv[i][j]), g1 = bf16hi_to_f32(gv[i][j]);
+          const float d0 = bf16_round(g0 * bf16lo_to_f32(wv[j])), d1 = bf16_round(g1 * bf16hi_to_f32(wv[j]));
+          dot += d0 * x0 + d1 * x1;
+          dwl[i][2 * j] += bf16_round(g0 * bf16_round(x0));
+          dwl[i][2 * j + 1] += bf16_round(g1 * bf16_round(x1));
+        }
+      }
+    }
+    const float c = wave_reduce_sum(dot) / (float)cols;
+    u32x4* dxr = reinterpret_cast<u32x4*>(dx + row * (int64_t)cols);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int vi = lane + i * 64;
+      if (vi < nvec) {
+        const u32x4 wv = wr[vi];
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float x0 = bf16lo_to_f32(xv[i][j]) * rstd, x1 = bf16hi_to_f32(xv[i][j]) * rstd;
+          const float d0 = bf16_round(bf16lo_to_f32(gv[i][j]) * bf16lo_to_f32(wv[j]));
+          const float d1 = bf16_round(bf16hi_to_f32(gv[i][j]) * bf16hi_to_f32(wv[j]));
+          float r0 = rstd * (d0 - x0 * c), r1 = rstd * (d1 - x1 * c);
+          if (res) {                                   // residual branch: dx = bf16(res + bf16(dx_norm))
+            const unsigned rw = reinterpret_cast<const unsigned*>(res + row * (int64_t)cols)[vi * 4 + j];
+            r0 = bf16_round(r0) + bf16lo_to_f32(rw);
+            r1 = bf16_round(r1) + bf16hi_to_f32(rw);
+          }
+          o[j] = pack_bf16x2(r0, r1);
+        }
+        dxr[vi] = o;
+      }
+    }
+  }
+  if (dw_acc) {
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int vi = lane + i * 64;
+      if (vi < nvec) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) atomicAdd(dw_acc + vi * 8 + j, dwl[i][j]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// SwiGLU on the unfused fc1 output y = [gate | up]  ([rows, 2F] bf16):
+//   fwd  a  = bf16( bf16(silu(g)) * u )
+//   bwd  du = bf16(da * s), ds = bf16(da * u), dg = bf16(ds * silu'(g)),  s = bf16(silu(g))
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float silu_f(float g) { return g / (1.0f + __expf(-g)); }
+__device__ __forceinline__ float silu_grad_f(float g) {
+  const float sg = 1.0f / (1.0f + __expf(-g));
+  return sg * (1.0f + g * (1.0f - sg));
+}
+
+__global__ __launch_bounds__(256) void swiglu_fwd_kernel(const bf16_t* __restrict__ y,
+                                                         bf16_t* __restrict__ a, int64_t rows, int F) {
+  const int nv = F >> 3;
+  const int64_t total = rows * nv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / nv;
+    const int v = (int)(i - r * nv);
+    const u32x4 g = *reinterpret_cast<const u32x4*>(y + r * 2 * F + v * 8);
+    const u32x4 u = *reinterpret_cast<const u32x4*>(y + r * 2 * F + F + v * 8);
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      o[j] = pack_bf16x2(bf16_round(silu_f(bf16lo_to_f32(g[j]))) * bf16lo_to_f32(u[j]),
+                         bf16_round(silu_f(bf16hi_to_f32(g[j]))) * bf16hi_to_f32(u[j]));
+    *reinterpret_cast<u32x4*>(a + r * F + v * 8) = o;
+  }
+}
+
+__global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restrict__ y,
+                                                         const bf16_t* __restrict__ da,
+                                                         bf16_t* __restrict__ dy, int64_t rows, int F) {
+  const int nv = F >> 3;
+  const int64_t total = rows * nv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / nv;
+    const int v = (int)(i - r * nv);
+    const u32x4 g = *reinterpret_cast<const u32x4*>(y + r * 2 * F + v * 8);
+    const u32x4 u = *reinterpret_cast<const u32x4*>(y + r * 2 * F + F + v * 8);
+    const u32x4 d = *reinterpret_cast<const u32x4*>(da + r * F + v * 8);
+    u32x4 og, ou;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const float g0 = bf16lo_to_f32(g[j]), g1 = bf16hi_to_f32(g[j]);
+      const float u0 = bf16lo_to_f32(u[j]), u1 = bf16hi_to_f32(u[j]);
+      const float d0 = bf16lo_to_f32(d[j]), d1 = bf16hi_to_f32(d[j]);
+      ou[j] = pack_bf16x2(d0 * bf16_round(silu_f(g0)), d1 * bf16_round(silu_f(g1)));
+      og[j] = pack_bf16x2(bf16_round(d0 * u0) * silu_grad_f(g0), bf16_round(d1 * u1) * silu_grad_f(g1));
+    }
+    *reinterpret_cast<u32x4*>(dy + r * 2 * F + v * 8) = og;
+    *reinterpret_cast<u32x4*>(dy + r * 2 * F + F + v * 8) = ou;
+  }
+}
+
+// GELU (erf) backward: dx = bf16(dy * gelu'(x))
+__global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict__ x,
+                                                       const bf16_t* __restrict__ dy,
+                                                       bf16_t* __restrict__ dx, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const u32x4 xv = reinterpret_cast<const u32x4*>(x)[i];
+    const u32x4 gv = reinterpret_cast<const u32x4*>(dy)[i];
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float r[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float xx = h ? bf16hi_to_f32(xv[j]) : bf16lo_to_f32(xv[j]);
+        const float gg = h ? bf16hi_to_f32(gv[j]) : bf16lo_to_f32(gv[j]);
+        const float cdf = 0.5f * (1.0f + erff(xx * 0.70710678118654752440f));
+        const float pdf = 0.39894228040143267794f * __expf(-0.5f * xx * xx);
+        r[h] = gg * (cdf + xx * pdf);
+      }
+      o[j] = pack_bf16x2(r[0], r[1]);
+    }
+    reinterpret_cast<u32x4*>(dx)[i] = o;
+  }
+}
+
+// LayerNorm parameter gradients (the projector pre-norm; its input comes from the frozen ViT, so dx
+// is not needed): dgamma += sum_rows dy * xhat, dbeta += sum_rows dy   (fp32 atomics).
+template <int VPL>
+__global__ __launch_bounds__(256) void layernorm_param_grad_kernel(const bf16_t* __restrict__ dy,
+                                                                   const bf16_t* __restrict__ x,
+                                                                   float* __restrict__ dgamma,
+                                                                   float* __restrict__ dbeta,
+                                                                   int64_t rows, int cols, float eps,
+                                                                   int prenorm) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * 4;
+  const int nvec = cols >> 3;
+  float dg[VPL][8], db[VPL][8];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dg[i][j] = 0.f; db[i][j] = 0.f; }
+  for (int64_t row = wave_id; row < rows; row += n_waves) {
+    const u32x4* xr = reinterpret_cast<const u32x4*>(x + row * (int64_t)cols);
+    const u32x4* gr = reinterpret_cast<const u32x4*>(dy + row * (int64_t)cols);
+    u32x4 xv[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int vi = lane + i * 64;
+      if (vi < nvec) {
+        xv[i] = xr[vi];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += bf16lo_to_f32(xv[i][j]) + bf16hi_to_f32(xv[i][j]);
+      }
+    }
+    float mean = wave_reduce_sum(s) / (float)cols;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int vi = lane + i * 64;
+      if (vi < nvec) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a = bf16lo_to_f32(xv[i][j]) - mean, c = bf16hi_to_f32(xv[i][j]) - mean;
+          ss += a * a + c * c;
+        }
+      }
+    }
+    float rstd = rsqrtf(wave_reduce_sum(ss) / (float)cols + eps);
+    if (prenorm) { mean = 0.f; rstd = 1.f; }            // x already holds xhat
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int vi = lane + i * 64;
+      if (vi < nvec) {
+        const u32x4 gv = gr[vi];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float g0 = bf16lo_to_f32(gv[j]), g1 = bf16hi_to_f32(gv[j]);
+          dg[i][2 * j] += g0 * (bf16lo_to_f32(xv[i][j]) - mean) * rstd;
+          dg[i][2 * j + 1] += g1 * (bf16hi_to_f32(xv[i][j]) - mean) * rstd;
+          db[i][2 * j] += g0;
+          db[i][2 * j + 1] += g1;
+        }
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int vi = lane + i * 64;
+    if (vi < nvec) {
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        atomicAdd(dgamma + vi * 8 + j, dg[i][j]);
+        atomicAdd(dbeta + vi * 8 + j, db[i][j]);
+      }
+    }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Vocabulary cross-entropy on the selected rows (TP = 1 form of Megatron's
+// vocab_parallel_cross_entropy, called at M/core/models/multimodal/gpt_vl_model.py:414):
+//   loss[i] = logsumexp(float(logits[i, :])) - float(logits[i, label[i]])
+//   dlogits[i, v] = bf16( (softmax_v - [v == label]) * grad_scale[i] )     (optional)
+// One workgroup per row.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void ce_loss_kernel(const bf16_t* __restrict__ logits, int64_t ld,
+                                                      const int64_t* __restrict__ labels,
+                                                      float* __restrict__ loss,
+                                                      bf16_t* __restrict__ dlogits, int64_t ldd,
+                                                      const float* __restrict__ grad_scale,
+                                                      int V, int* __restrict__ err_flag) {
+  __shared__ float red[16];
+  const int64_t row = blockIdx.x;
+  const bf16_t* lr = logits + row * ld;
+  float mx = -INFINITY;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) mx = fmaxf(mx, bf16_to_f32(lr[v]));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float se = 0.f;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) se += __expf(bf16_to_f32(lr[v]) - mx);
+  se = block_reduce_sum(se, red);
+  const int64_t lab = labels[row];
+  if (lab < 0 || lab >= V) {
+    if (threadIdx.x == 0 && err_flag) atomicExch(err_flag, 1);
+    return;
+  }
+  const float lse = mx + __logf(se);
+  if (threadIdx.x == 0) loss[row] = lse - bf16_to_f32(lr[lab]);
+  if (dlogits) {
+    const float gs = grad_scale ? grad_scale[row] : 1.0f;
+    const float inv = 1.0f / se;
+    bf16_t* dr = dlogits + row * ldd;
+    for (int v = threadIdx.x; v < V; v += blockDim.x) {
+      float pr = __expf(bf16_to_f32(lr[v]) - mx) * inv;
+      if (v == lab) pr -= 1.0f;
+      dr[v] = f32_to_bf16(pr * gs);
+    }
+  }
+}
+
+// dst_f32[idx[i], :] += float(src_bf16[i, :])   (embedding-weight gradient; atomics)
+__global__ __launch_bounds__(256) void row_scatter_add_kernel(const bf16_t* __restrict__ src,
+                                                              const int64_t* __restrict__ idx,
+                                                              float* __restrict__ dst, int64_t dst_rows,
+                                                              int64_t n, int cols, int* __restrict__ err_flag) {
+  const int nv = cols >> 1;
+  const int64_t total = n * nv;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
+       i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t r = i / nv;
+    const int v = (int)(i - r * nv);
+    const int64_t d = idx[r];
+    if (d < 0) continue;                                   // negative index = "skip this row"
+    if (d >= dst_rows) {
+      if (err_flag && v == 0) atomicExch(err_flag, 1);
+      continue;
+    }
+    const unsigned w = *reinterpret_cast<const unsigned*>(src + r * cols + v * 2);
+    atomicAdd(dst + d * cols + v * 2, bf16lo_to_f32(w));
+    atomicAdd(dst + d * cols + v * 2 + 1, bf16hi_to_f32(w));
+  }
+}
+
+// D[b, h, row] = sum_d float(dO[b,row,h,d]) * float(O[b,row,h,d])  — attention backward pre-pass.
+// one wave per (row, head): 64 lanes x 2 (d=128) or x1 (d=64) elements
+__global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restrict__ o,
+                                                         const bf16_t* __restrict__ d_o,
+                                                         float* __restrict__ delta, int64_t rows,
+                                                         int heads, int D, int64_t o_rs, int64_t o_hs,
+                                                         int64_t do_rs, int64_t do_hs) {
+  const int lane = threadIdx.x & 63;
+  const int64_t item = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (item >= rows * heads) return;
+  const int64_t row = item / heads;
+  const int h = (int)(item - row * heads);
+  const bf16_t* op = o + row * o_rs + (int64_t)h * o_hs;
+  const bf16_t* dp = d_o + row * do_rs + (int64_t)h * do_hs;
+  float s = 0.f;
+  for (int e = lane * 2; e < D; e += 128) {
+    const unsigned a = *reinterpret_cast<const unsigned*>(op + e);
+    const unsigned b = *reinterpret_cast<const unsigned*>(dp + e);
+    s += bf16lo_to_f32(a) * bf16lo_to_f32(b) + bf16hi_to_f32(a) * bf16hi_to_f32(b);
+  }
+  s = wave_reduce_sum(s);
+  if (lane == 0) delta[(int64_t)h * rows + row] = s;
+}
+
+}  // namespace
+
+extern "C" int vita_transpose_bf16(const void* src, int64_t ld_src, void* dst, int64_t ld_dst,
+                                   int64_t rows, int64_t cols, void* stream) {
+  if (!src || !dst || rows < 0 || cols < 0 || ld_src < cols || ld_dst < rows) return VITA_ERR_INVALID_ARG;
+  if (rows == 0 || cols == 0) return VITA_OK;
+  dim3 grid((unsigned)((cols + 63) / 64), (unsigned)((rows + 63) / 64));
+  if (grid.y > 65535) return VITA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(transpose_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const bf16_t*)src,
+                     ld_src, (bf16_t*)dst, ld_dst, rows, cols);
+  return vita_check_launch();
+}
+
+extern "C" int vita_rmsnorm_bwd(const void* dy, const void* x, const void* w, const void* res, void* dx,
+                                float* dw_acc, int64_t rows, int cols, float eps, void* stream) {
+  if (!dy || !x || !w || !dx || rows < 0 || cols <= 0) return VITA_ERR_INVALID_ARG;
+  if ((cols & 7) || cols > 8192) return VITA_ERR_UNSUPPORTED;
+  if (rows == 0) return VITA_OK;
+  const int vpl = (cols + 511) / 512;
+  dim3 grid((unsigned)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define VITA_RB(V) hipLaunchKernelGGL(rmsnorm_bwd_kernel<V>, grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)res, (bf16_t*)dx, dw_acc, rows, cols, eps)
+  if (vpl <= 2) VITA_RB(2); else if (vpl <= 4) VITA_RB(4); else if (vpl <= 8) VITA_RB(8); else if (vpl <= 10) VITA_RB(10); else VITA_RB(16);
+#undef VITA_RB
+  return vita_check_launch();
+}
+
+extern "C" int vita_swiglu_fwd(const void* y, void* a, int64_t rows, int ffn, void* stream) {
+  if (!y || !a || rows < 0 || ffn <= 0) return VITA_ERR_INVALID_ARG;
+  if (ffn & 7) return VITA_ERR_UNSUPPORTED;
+  if (rows == 0) return VITA_OK;
+  hipLaunchKernelGGL(swiglu_fwd_kernel, dim3(grid_for(rows * (ffn / 8), 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)y, (bf16_t*)a, rows, ffn);
+  return vita_check_launch();
+}
+
+extern "C" int vita_swiglu_bwd(const void* y, const void* da, void* dy, int64_t rows, int ffn,
+                               void* stream) {
+  if (!y || !da || !dy || rows < 0 || ffn <= 0) return VITA_ERR_INVALID_ARG;
+  if (ffn & 7) return VITA_ERR_UNSUPPORTED;
+  if (rows == 0) return VITA_OK;
+  hipLaunchKernelGGL(swiglu_bwd_kernel, dim3(grid_for(rows * (ffn / 8), 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)y, (const bf16_t*)da, (bf16_t*)dy, rows, ffn);
+  return vita_check_launch();
+}
+
+extern "C" int vita_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, void* stream) {
+  if (!x || !dy || !dx || n < 0) return VITA_ERR_INVALID_ARG;
+  if (n & 7) return VITA_ERR_UNSUPPORTED;
+  if (n == 0) return VITA_OK;
+  hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n / 8);
+  return vita_check_launch();
+}
+
+extern "C" int vita_layernorm_param_grad(const void* dy, const void* x, float* dgamma, float* dbeta,
+                                         int64_t rows, int cols, float eps, int prenormalized,
+                                         void* stream) {
+  if (!dy || !x || !dgamma || !dbeta || rows < 0 || cols <= 0) return VITA_ERR_INVALID_ARG;
+  if ((cols & 7) || cols > 8192) return VITA_ERR_UNSUPPORTED;
+  if (rows == 0) return VITA_OK;
+  dim3 grid((unsigned)((rows + 3) / 4 < 1024 ? (rows + 3) / 4 : 1024)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+  if (cols <= 4096)
+    hipLaunchKernelGGL(layernorm_param_grad_kernel<8>, grid, block, 0, st, (const bf16_t*)dy,
+                       (const bf16_t*)x, dgamma, dbeta, rows, cols, eps, prenormalized);
+  else
+    hipLaunchKernelGGL(layernorm_param_grad_kernel<16>, grid, block, 0, st, (const bf16_t*)dy,
+                       (const bf16_t*)x, dgamma, dbeta, rows, cols, eps, prenormalized);
+  return vita_check_launch();
+}
+
+extern "C" int vita_ce_loss(const void* logits, int64_t ld, const int64_t* labels, float* loss,
+                            void* dlogits, int64_t ld_d, const float* grad_scale, int64_t rows,
+                            int vocab, int* err_flag, void* stream) {
+  if (!logits || !labels || !loss || rows < 0 || vocab <= 0) return VITA_ERR_INVALID_ARG;
+  if (rows == 0) return VITA_OK;
+  if (rows > 0x7fffffff) return VITA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(ce_loss_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)logits, ld, labels, loss, (bf16_t*)dlogits, ld_d, grad_scale, vocab,
+                     err_flag);
+  return vita_check_launch();
+}
+
+extern "C" int vita_row_scatter_add_f32(const void* src, const int64_t* idx, float* dst,
+                                        int64_t dst_rows, int64_t n, int cols, int* err_flag,
+                                        void* stream) {
+  if (!src || !idx || !dst || n < 0 || cols <= 0 || dst_rows < 0) return VITA_ERR_INVALID_ARG;
+  if (cols & 1) return VITA_ERR_UNSUPPORTED;
+  if (n == 0) return VITA_OK;
+  hipLaunchKernelGGL(row_scatter_add_kernel, dim3(grid_for(n * (cols / 2), 256)), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)src, idx, dst, dst_rows, n, cols, err_flag);
+  return vita_check_launch();
+}
+
+extern "C" int vita_attn_delta(const void* o, const void* d_o, float* delta, int64_t rows, int heads,
+                               int head_dim, int64_t o_row_stride, int64_t o_head_stride,
+                               int64_t do_row_stride, int64_t do_head_stride, void* stream) {
+  if (!o || !d_o || !delta || rows < 0 || heads <= 0 || head_dim <= 0) return VITA_ERR_INVALID_ARG;
+  if (head_dim & 1) return VITA_ERR_UNSUPPORTED;
+  if (rows == 0) return VITA_OK;
+  const int64_t items = rows * heads;
+  hipLaunchKernelGGL(attn_delta_kernel, dim3((unsigned)((items + 3) / 4)), dim3(256), 0,
+                     (hipStream_t)stream, (const bf16_t*)o, (const bf16_t*)d_o, delta, rows, heads,
+                     head_dim, o_row_stride, o_head_stride, do_row_stride, do_head_stride);
+  return vita_check_launch();
+}

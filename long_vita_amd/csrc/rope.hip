@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void rope_qkv_kernel(bf16_t* __restrict__ mixe
                                                        int groups, int qpg, int head_dim,
                                                        const bf16_t* __restrict__ cos_tab,
                                                        const bf16_t* __restrict__ sin_tab,
-                                                       bf16_t* __restrict__ kv_out) {
+                                                       bf16_t* __restrict__ kv_out, float sign) {
   const int half = head_dim >> 1, nv = half >> 3, hpg = qpg + 2;
   const int64_t per_row = (int64_t)groups * hpg * nv;
   const int64_t total = rows * per_row;
@@ -96,7 +96,7 @@ __global__ __launch_bounds__(256) void rope_qkv_kernel(bf16_t* __restrict__ mixe
     if (h <= qpg) {
       const u32x4 c = *reinterpret_cast<const u32x4*>(cos_tab + r * half + vi * 8);
       const u32x4 s = *reinterpret_cast<const u32x4*>(sin_tab + r * half + vi * 8);
-      rope_rotate8(x1, x2, c, s, 1.0f);
+      rope_rotate8(x1, x2, c, s, sign);
       *reinterpret_cast<u32x4*>(p) = x1;
       *reinterpret_cast<u32x4*>(p + half) = x2;
     }
@@ -152,6 +152,19 @@ extern "C" int vita_rope_qkv_fwd(void* mixed_qkv, int64_t rows, int groups, int 
   const int64_t total = rows * groups * (q_per_group + 2) * (head_dim / 16);
   hipLaunchKernelGGL(rope_qkv_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, (bf16_t*)mixed_qkv, rows, groups, q_per_group, head_dim,
-                     (const bf16_t*)cos_tab, (const bf16_t*)sin_tab, (bf16_t*)kv_out);
+                     (const bf16_t*)cos_tab, (const bf16_t*)sin_tab, (bf16_t*)kv_out, 1.0f);
+  return vita_check_launch();
+}
+
+extern "C" int vita_rope_qkv_bwd(void* d_mixed_qkv, int64_t rows, int groups, int q_per_group,
+                                 int head_dim, const void* cos_tab, const void* sin_tab, void* stream) {
+  if (!d_mixed_qkv || !cos_tab || !sin_tab || rows < 0 || groups <= 0 || q_per_group <= 0 || head_dim <= 0)
+    return VITA_ERR_INVALID_ARG;
+  if (head_dim & 15) return VITA_ERR_UNSUPPORTED;
+  if (rows == 0) return VITA_OK;
+  const int64_t total = rows * groups * (q_per_group + 2) * (head_dim / 16);
+  hipLaunchKernelGGL(rope_qkv_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
+                     (bf16_t*)d_mixed_qkv, rows, groups, q_per_group, head_dim, (const bf16_t*)cos_tab,
+                     (const bf16_t*)sin_tab, (bf16_t*)nullptr, -1.0f);
   return vita_check_launch();
 }

@@ -53,6 +53,29 @@ class AttnParams(C.Structure):
     ]
 
 
+class AttnBwdParams(C.Structure):
+    """Mirror of ``vita_attn_bwd_params`` (include/vita_hip.h)."""
+
+    _fields_ = [
+        ("q", C.c_void_p), ("q_row_stride", C.c_int64), ("q_head_stride", C.c_int64), ("q_group_stride", C.c_int64),
+        ("k", C.c_void_p), ("k_row_stride", C.c_int64), ("k_head_stride", C.c_int64),
+        ("v", C.c_void_p), ("v_row_stride", C.c_int64), ("v_head_stride", C.c_int64),
+        ("d_o", C.c_void_p), ("do_row_stride", C.c_int64), ("do_head_stride", C.c_int64),
+        ("lse", C.c_void_p),
+        ("delta", C.c_void_p),
+        ("dq", C.c_void_p), ("dq_row_stride", C.c_int64), ("dq_head_stride", C.c_int64), ("dq_group_stride", C.c_int64),
+        ("dk", C.c_void_p), ("dk_row_stride", C.c_int64), ("dk_head_stride", C.c_int64),
+        ("dv", C.c_void_p), ("dv_row_stride", C.c_int64), ("dv_head_stride", C.c_int64),
+        ("n_q_heads", C.c_int), ("n_kv_heads", C.c_int), ("head_dim", C.c_int),
+        ("chunk_len", C.c_int64),
+        ("n_q_chunks", C.c_int), ("n_kv_chunks", C.c_int),
+        ("q_chunk_gid", C.POINTER(C.c_int32)),
+        ("kv_chunk_gid", C.POINTER(C.c_int32)),
+        ("kv_chunk_row", C.POINTER(C.c_int64)),
+        ("softmax_scale", C.c_float),
+    ]
+
+
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
 # name -> (restype, argtypes); must list EVERY function declared in include/vita_hip.h
@@ -77,6 +100,18 @@ PROTOTYPES = {
     "vita_patchify14": (_i, [_p, _p, _l, _i, _i, _i, _p]),
     "vita_vit_assemble": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _p]),
     "vita_pixel_shuffle_ln": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _f, _p]),
+    # backward
+    "vita_rope_qkv_bwd": (_i, [_p, _l, _i, _i, _i, _p, _p, _p]),
+    "vita_transpose_bf16": (_i, [_p, _l, _p, _l, _l, _l, _p]),
+    "vita_rmsnorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _f, _p]),
+    "vita_swiglu_fwd": (_i, [_p, _p, _l, _i, _p]),
+    "vita_swiglu_bwd": (_i, [_p, _p, _p, _l, _i, _p]),
+    "vita_gelu_bwd": (_i, [_p, _p, _p, _l, _p]),
+    "vita_layernorm_param_grad": (_i, [_p, _p, _p, _p, _l, _i, _f, _i, _p]),
+    "vita_ce_loss": (_i, [_p, _l, _p, _p, _p, _l, _p, _l, _i, _p, _p]),
+    "vita_row_scatter_add_f32": (_i, [_p, _p, _p, _l, _l, _i, _p, _p]),
+    "vita_attn_delta": (_i, [_p, _p, _p, _l, _i, _i, _l, _l, _l, _l, _p]),
+    "vita_flash_attn_bwd": (_i, [C.POINTER(AttnBwdParams), _p]),
 }
 
 _lock = threading.Lock()

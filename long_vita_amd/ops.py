@@ -351,3 +351,144 @@ def pixel_shuffle_ln(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch
                                              _dev(y, "y"), n, grid, hidden, int(has_cls), float(eps), _stream()),
              "vita_pixel_shuffle_ln")
     return y
+
+
+# ------------------------------------------------------------------------------------------------
+# backward
+# ------------------------------------------------------------------------------------------------
+def transpose(x: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """x [R, C] (row stride allowed) -> [C, R] contiguous."""
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("x must be 2-D with contiguous last dim")
+    R, Cc = x.shape
+    y = torch.empty((Cc, R), dtype=BF16, device=x.device) if out is None else out
+    _L.check(_L.load().vita_transpose_bf16(_dev(x, "x", BF16), x.stride(0), _dev(y, "out", BF16), y.stride(0), R, Cc,
+                                           _stream()), "vita_transpose_bf16")
+    return y
+
+
+def rope_qkv_bwd_(d_mixed: torch.Tensor, groups: int, q_per_group: int, head_dim: int, cos, sin) -> torch.Tensor:
+    rows = d_mixed.numel() // (groups * (q_per_group + 2) * head_dim)
+    _L.check(_L.load().vita_rope_qkv_bwd(_dev(d_mixed, "d_mixed", BF16), rows, groups, q_per_group, head_dim,
+                                         _dev(cos, "cos", BF16), _dev(sin, "sin", BF16), _stream()), "vita_rope_qkv_bwd")
+    return d_mixed
+
+
+def rmsnorm_bwd(dy, x, weight, eps: float, dw_acc: Optional[torch.Tensor] = None, out=None,
+                residual: Optional[torch.Tensor] = None) -> torch.Tensor:
+    cols = x.shape[-1]
+    rows = x.numel() // cols
+    dx = torch.empty_like(x) if out is None else out
+    _L.check(_L.load().vita_rmsnorm_bwd(_dev(dy, "dy", BF16), _dev(x, "x", BF16), _dev(weight, "weight", BF16),
+                                        _opt(residual, "residual", BF16), _dev(dx, "dx", BF16), _opt(dw_acc, "dw_acc", torch.float32), rows, cols,
+                                        float(eps), _stream()), "vita_rmsnorm_bwd")
+    return dx
+
+
+def swiglu(y: torch.Tensor, out=None) -> torch.Tensor:
+    rows, two_f = y.shape
+    a = torch.empty((rows, two_f // 2), dtype=BF16, device=y.device) if out is None else out
+    _L.check(_L.load().vita_swiglu_fwd(_dev(y, "y", BF16), _dev(a, "a", BF16), rows, two_f // 2, _stream()),
+             "vita_swiglu_fwd")
+    return a
+
+
+def swiglu_bwd(y: torch.Tensor, da: torch.Tensor, out=None) -> torch.Tensor:
+    rows, two_f = y.shape
+    dy = torch.empty_like(y) if out is None else out
+    _L.check(_L.load().vita_swiglu_bwd(_dev(y, "y", BF16), _dev(da, "da", BF16), _dev(dy, "dy", BF16), rows,
+                                       two_f // 2, _stream()), "vita_swiglu_bwd")
+    return dy
+
+
+def gelu_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+    dx = torch.empty_like(x)
+    _L.check(_L.load().vita_gelu_bwd(_dev(x, "x", BF16), _dev(dy, "dy", BF16), _dev(dx, "dx", BF16), x.numel(),
+                                     _stream()), "vita_gelu_bwd")
+    return dx
+
+
+def layernorm_param_grad(dy, x, dgamma: torch.Tensor, dbeta: torch.Tensor, eps: float,
+                         prenormalized: bool = False) -> None:
+    cols = x.shape[-1]
+    _L.check(_L.load().vita_layernorm_param_grad(_dev(dy, "dy", BF16), _dev(x, "x", BF16),
+                                                 _dev(dgamma, "dgamma", torch.float32),
+                                                 _dev(dbeta, "dbeta", torch.float32), x.numel() // cols, cols,
+                                                 float(eps), int(prenormalized), _stream()),
+             "vita_layernorm_param_grad")
+
+
+def ce_loss(logits: torch.Tensor, labels: torch.Tensor, grad_scale: Optional[torch.Tensor] = None,
+            want_grad: bool = False):
+    """logits [n, V] bf16, labels [n] int64 -> loss [n] fp32 (, dlogits [n, V] bf16)."""
+    n, V = logits.shape
+    loss = torch.empty(n, dtype=torch.float32, device=logits.device)
+    dl = torch.empty_like(logits) if want_grad else None
+    flag = _err_flag(logits.device)
+    _L.check(_L.load().vita_ce_loss(_dev(logits, "logits", BF16), logits.stride(0),
+                                    _dev(labels.contiguous(), "labels", torch.int64), _dev(loss, "loss"),
+                                    _opt(dl, "dlogits"), dl.stride(0) if want_grad else 0,
+                                    _opt(grad_scale, "grad_scale", torch.float32), n, V, _dev(flag, "flag"),
+                                    _stream()), "vita_ce_loss")
+    if int(flag.item()):
+        raise IndexError("vita_ce_loss: label out of range")
+    return (loss, dl) if want_grad else loss
+
+
+def row_scatter_add_f32_(dst: torch.Tensor, idx: torch.Tensor, src: torch.Tensor) -> torch.Tensor:
+    n, cols = src.shape
+    if n == 0:
+        return dst
+    flag = _err_flag(dst.device)
+    _L.check(_L.load().vita_row_scatter_add_f32(_dev(src, "src", BF16), _dev(idx.contiguous(), "idx", torch.int64),
+                                                _dev(dst, "dst", torch.float32), dst.shape[0], n, cols,
+                                                _dev(flag, "flag"), _stream()), "vita_row_scatter_add_f32")
+    if int(flag.item()):
+        raise IndexError("vita_row_scatter_add_f32: index out of range")
+    return dst
+
+
+def flash_attn_bwd(q5, k, v, o, d_o, lse, *, chunk_len=None, q_chunk_gid=None, kv_chunk_gid=None, kv_chunk_row=None,
+                   softmax_scale=None, dq5=None, dk=None, dv=None):
+    """Backward of flash_attn(causal=True) at batch 1, head_dim 128.
+    q5 [1, Sq, Hkv, G, D] (or [1, Sq, Hq, D]); k, v [1, Sk, Hkv, D] views; o, d_o [1, Sq, Hq, D];
+    lse [1, Hq, Sq].  Returns (dq like q5, dk, dv like k/v — dk/dv cover every row of k/v)."""
+    if q5.dim() == 5:
+        _, Sq, Hkv_q, G, D = q5.shape
+        Hq = Hkv_q * G
+        q_rs, q_gs, q_hs = q5.stride(1), q5.stride(2), q5.stride(3)
+    else:
+        _, Sq, Hq, D = q5.shape
+        q_rs, q_hs, q_gs = q5.stride(1), q5.stride(2), 0
+    _, Sk, Hkv, _ = k.shape
+    if chunk_len is None:
+        chunk_len, qg, kg, kr = Sq, [0], [0], [0]
+    else:
+        qg, kg, kr = list(q_chunk_gid), list(kv_chunk_gid), list(kv_chunk_row)
+    dq5 = torch.empty_like(q5) if dq5 is None else dq5
+    dk = torch.empty_like(k) if dk is None else dk
+    dv = torch.empty_like(v) if dv is None else dv
+    delta = torch.empty((Hq, Sq), dtype=torch.float32, device=q5.device)
+    h = _L.load()
+    _L.check(h.vita_attn_delta(_dev(o, "o", BF16), _dev(d_o, "d_o", BF16), _dev(delta, "delta"), Sq, Hq, D,
+                               o.stride(1), o.stride(2), d_o.stride(1), d_o.stride(2), _stream()), "vita_attn_delta")
+    p = _L.AttnBwdParams()
+    p.q, p.q_row_stride, p.q_head_stride, p.q_group_stride = _dev(q5, "q", BF16), q_rs, q_hs, q_gs
+    p.k, p.k_row_stride, p.k_head_stride = _dev(k, "k", BF16), k.stride(1), k.stride(2)
+    p.v, p.v_row_stride, p.v_head_stride = _dev(v, "v", BF16), v.stride(1), v.stride(2)
+    p.d_o, p.do_row_stride, p.do_head_stride = _dev(d_o, "d_o", BF16), d_o.stride(1), d_o.stride(2)
+    p.lse, p.delta = _dev(lse, "lse", torch.float32), _dev(delta, "delta")
+    if dq5.dim() == 5:
+        p.dq, p.dq_row_stride, p.dq_group_stride, p.dq_head_stride = (_dev(dq5, "dq", BF16), dq5.stride(1),
+                                                                       dq5.stride(2), dq5.stride(3))
+    else:
+        p.dq, p.dq_row_stride, p.dq_head_stride, p.dq_group_stride = _dev(dq5, "dq", BF16), dq5.stride(1), dq5.stride(2), 0
+    p.dk, p.dk_row_stride, p.dk_head_stride = _dev(dk, "dk", BF16), dk.stride(1), dk.stride(2)
+    p.dv, p.dv_row_stride, p.dv_head_stride = _dev(dv, "dv", BF16), dv.stride(1), dv.stride(2)
+    p.n_q_heads, p.n_kv_heads, p.head_dim = Hq, Hkv, D
+    p.chunk_len, p.n_q_chunks, p.n_kv_chunks = chunk_len, len(qg), len(kg)
+    qg_a, kg_a, kr_a = (C.c_int32 * len(qg))(*qg), (C.c_int32 * len(kg))(*kg), (C.c_int64 * len(kr))(*kr)
+    p.q_chunk_gid, p.kv_chunk_gid, p.kv_chunk_row = qg_a, kg_a, kr_a
+    p.softmax_scale = float(softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(D))
+    _L.check(h.vita_flash_attn_bwd(C.byref(p), _stream()), "vita_flash_attn_bwd")
+    return dq5, dk, dv

@@ -1,0 +1,301 @@
+"""Training step (forward + backward) of the Long-VITA path — mirror of `forward_step` / `loss_func`
+(M/pretrain_long_vita.py:778-869) with `GPTVLModel.forward(..., labels=, logit_mask=)`
+(M/core/models/multimodal/gpt_vl_model.py:371-416) and the reference's activation-recompute policy
+(`--recompute-granularity full --recompute-method block`, stage3 .sh:152-154).
+
+The reference gets its backward from torch autograd over Megatron modules.  Here the backward is an
+explicit reverse sweep over the same expressions, every arithmetic step a libvita_hip.so kernel:
+
+  forward   the inference fast path (fused epilogues), keeping only each layer's input `h_l`;
+  backward  per layer, recompute the layer from `h_l` with its intermediates, then
+            dgrad = gemm(dY, W^T), wgrad = gemm(dY^T, X^T)  (vita_transpose_bf16 feeds the one NT GEMM),
+            vita_swiglu_bwd, vita_rmsnorm_bwd (+ residual), vita_flash_attn_bwd, vita_rope_qkv_bwd;
+  context parallelism: K/V all-gather in forward (and recompute), ONE reduce-scatter of the
+            gathered-layout dK/dV per layer in backward (what TE's ring does in CP-1 P2P steps);
+  loss      vocabulary cross-entropy on the logit-masked rows, instruction shift
+            (gpt_vl_model.py:389-391), mean over all masked tokens of all CP ranks.
+
+Frozen ViT (`--vision-model-freeze`, stage3 .sh:203): no gradient flows into the encoder; the
+projector (pre-LayerNorm + 2-layer MLP) and the whole decoder are trained.
+
+Gradient convention: `grads` hold d(mean token loss)/d(param) contributions of THIS rank; summing
+them over the CP ranks (`allreduce_grads`) gives the full gradient.  This equals the reference's
+(loss x CP) / tokens followed by Megatron's gradient average over the DPxCP group.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import ops, parallel_state as mpu, training_utils
+from .gpt_vl_model import GPTVLModel
+
+
+def _t(x: torch.Tensor) -> torch.Tensor:
+    return ops.transpose(x)
+
+
+def _dgrad(dy: torch.Tensor, w: torch.Tensor, out=None, epilogue=ops.EPI_NONE, residual=None) -> torch.Tensor:
+    """grad_input = grad_output.matmul(weight)  (layers.py:444):  dy [M, N], w [N, K] -> [M, K]."""
+    return ops.gemm(dy, _t(w), epilogue, residual=residual, out=out)
+
+
+def _wgrad(dy_t: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """grad_weight = grad_output.t().matmul(total_input)  (layers.py:522-523): dy_t [N, M], x [M, K] -> [N, K]."""
+    return ops.gemm(dy_t, _t(x))
+
+
+def _pad_rows(x: torch.Tensor, mult: int = 64) -> torch.Tensor:
+    m = x.shape[0]
+    if m % mult == 0:
+        return x
+    out = torch.zeros((m + mult - m % mult,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    out[:m] = x
+    return out
+
+
+class TrainStep:
+    """forward_backward(tokens, labels, loss_mask, external_inputs) -> (loss, grads)."""
+
+    def __init__(self, model: GPTVLModel, is_instruction_dataset: bool = True):
+        self.m = model
+        self.is_instruction = is_instruction_dataset
+
+    # ------------------------------------------------------------------------------------------
+    def _layer_recompute(self, h, lp, cos, sin):
+        """Forward of one decoder layer from its input, keeping what the backward needs."""
+        m, c = self.m, self.m.cfg
+        s = h.shape[0]
+        cp = mpu.get_context_parallel_world_size()
+        x1 = ops.rmsnorm(h, lp["ln1"], c.eps)
+        qkv = ops.gemm(x1, lp["qkv_w"], ops.EPI_BIAS, lp["qkv_b"])
+        kv_local = torch.empty(2, s, c.kv_groups, c.head_dim, dtype=h.dtype, device=h.device) if cp > 1 else None
+        ops.rope_qkv_(qkv, c.kv_groups, c.qpg, c.head_dim, cos, sin, kv_local)
+        m5 = qkv.view(1, s, c.kv_groups, c.qpg + 2, c.head_dim)
+        q5 = m5[:, :, :, : c.qpg]
+        if cp > 1:
+            k_all, v_all, geo = self._gather_kv(kv_local)
+        else:
+            k_all, v_all, geo = m5[:, :, :, c.qpg], m5[:, :, :, c.qpg + 1], {}
+        ctx, lse = ops.flash_attn(q5, k_all, v_all, causal=True, return_lse=True, **geo)
+        ctx2 = ctx.view(s, c.heads * c.head_dim)
+        h_mid = ops.gemm(ctx2, lp["o_w"], ops.EPI_RESIDUAL, residual=h)
+        x2 = ops.rmsnorm(h_mid, lp["ln2"], c.eps)
+        y = ops.gemm(x2, lp["fc1_w"])                      # unfused: the backward needs gate / up
+        act = ops.swiglu(y)
+        return dict(x1=x1, qkv=qkv, q5=q5, k_all=k_all, v_all=v_all, geo=geo, ctx=ctx, lse=lse, h_mid=h_mid, x2=x2,
+                    y=y, act=act)
+
+    def _gather_kv(self, kv_local):
+        c = self.m.cfg
+        cp, r = mpu.get_context_parallel_world_size(), mpu.get_context_parallel_rank()
+        s_l = kv_local.shape[1]
+        ch = s_l // 2
+        gathered = torch.empty(cp * kv_local.numel(), dtype=kv_local.dtype, device=kv_local.device)
+        dist.all_gather_into_tensor(gathered, kv_local.view(-1), group=mpu.get_context_parallel_group())
+        rows = gathered.view(cp * 2 * s_l, c.kv_groups, c.head_dim)
+        kv_gid, kv_row = [], []
+        for p in range(cp):
+            kv_gid += [p, 2 * cp - 1 - p]
+            kv_row += [p * 2 * s_l, p * 2 * s_l + ch]
+        geo = dict(chunk_len=ch, q_chunk_gid=mpu.zigzag_chunk_ids(cp, r), kv_chunk_gid=kv_gid, kv_chunk_row=kv_row)
+        return rows.unsqueeze(0), rows[s_l:].unsqueeze(0), geo
+
+    def _layer_backward(self, dh, h, lp, cos, sin, g):
+        """dh = dL/d(layer output) [s, hidden]; returns dL/d(layer input); fills g (this layer's grads)."""
+        c = self.m.cfg
+        s = h.shape[0]
+        cp = mpu.get_context_parallel_world_size()
+        a = self._layer_recompute(h, lp, cos, sin)
+        f32 = lambda n: torch.zeros(n, dtype=torch.float32, device=h.device)  # noqa: E731
+        # ---- MLP: out = h_mid + fc2(swiglu(fc1(norm2(h_mid)))) ------------------------------------
+        dh_t = _t(dh)
+        g["fc2_w"] = _wgrad(dh_t, a["act"])
+        d_act = _dgrad(dh, lp["fc2_w"])
+        dy = ops.swiglu_bwd(a["y"], d_act)
+        del d_act
+        dy_t = _t(dy)
+        g["fc1_w"] = _wgrad(dy_t, a["x2"])
+        dx2 = _dgrad(dy, lp["fc1_w"])
+        del dy, dy_t
+        dln2 = f32(c.hidden)
+        dh_mid = ops.rmsnorm_bwd(dx2, a["h_mid"], lp["ln2"], c.eps, dln2, residual=dh)
+        g["ln2"] = dln2
+        del dx2
+        # ---- attention: h_mid = h + proj(attn(rope(qkv(norm1(h))))) -------------------------------
+        g["o_w"] = _wgrad(_t(dh_mid), a["ctx"].view(s, -1))
+        d_ctx = _dgrad(dh_mid, lp["o_w"]).view(1, s, c.heads, c.head_dim)
+        d_mixed = torch.empty_like(a["qkv"])
+        dm5 = d_mixed.view(1, s, c.kv_groups, c.qpg + 2, c.head_dim)
+        if cp > 1:
+            dk_all = torch.empty_like(a["k_all"][0].reshape(-1)).view(cp * 2 * s, c.kv_groups, c.head_dim)
+            # dK rows of rank p start at p*2*s, dV at +s: the layout of the gathered K/V buffer
+            ops.flash_attn_bwd(a["q5"], a["k_all"], a["v_all"], a["ctx"], d_ctx, a["lse"], dq5=dm5[:, :, :, : c.qpg],
+                               dk=dk_all.unsqueeze(0), dv=dk_all[s:].unsqueeze(0), **a["geo"])
+            dkv_local = torch.empty(2 * s * c.kv_groups * c.head_dim, dtype=h.dtype, device=h.device)
+            dist.reduce_scatter_tensor(dkv_local, dk_all.view(-1), group=mpu.get_context_parallel_group())
+            dkv_local = dkv_local.view(2, s, c.kv_groups, c.head_dim)
+            dm5[0, :, :, c.qpg].copy_(dkv_local[0])
+            dm5[0, :, :, c.qpg + 1].copy_(dkv_local[1])
+        else:
+            ops.flash_attn_bwd(a["q5"], a["k_all"], a["v_all"], a["ctx"], d_ctx, a["lse"], dq5=dm5[:, :, :, : c.qpg],
+                               dk=dm5[:, :, :, c.qpg], dv=dm5[:, :, :, c.qpg + 1])
+        ops.rope_qkv_bwd_(d_mixed, c.kv_groups, c.qpg, c.head_dim, cos, sin)
+        dm_t = _t(d_mixed)
+        g["qkv_w"] = _wgrad(dm_t, a["x1"])
+        # grad_bias = grad_output.sum(dim=0) (layers.py:524) as a GEMM against a block of ones
+        ones = torch.ones(4, s, dtype=h.dtype, device=h.device)
+        g["qkv_b"] = ops.gemm(dm_t, ones)[:, 0].contiguous()
+        dx1 = _dgrad(d_mixed, lp["qkv_w"])
+        dln1 = f32(c.hidden)
+        dh_in = ops.rmsnorm_bwd(dx1, h, lp["ln1"], c.eps, dln1, residual=dh_mid)
+        g["ln1"] = dln1
+        return dh_in
+
+    # ------------------------------------------------------------------------------------------
+    @torch.no_grad()
+    def forward_backward(self, tokens: torch.Tensor, labels: torch.Tensor, loss_mask: torch.Tensor,
+                         external_inputs: Optional[dict] = None):
+        """tokens / labels / loss_mask [1, S] (global, on every rank); external_inputs
+        {"images", "indices"} (global).  `--logit-mask` semantics: logit_mask = loss_mask.bool()."""
+        m, c = self.m, self.m.cfg
+        cp = mpu.get_context_parallel_world_size()
+        seq = tokens.shape[1]
+        position_ids = torch.arange(seq, dtype=torch.long, device=tokens.device).unsqueeze(0)
+        batch = {"tokens": tokens, "labels": labels, "loss_mask": loss_mask, "position_ids": position_ids}
+        if external_inputs:
+            batch["external_images"] = external_inputs["images"]
+            batch["external_indices"] = external_inputs["indices"]
+        batch = training_utils.get_batch_on_this_cp_rank(batch, seq_length=seq) if cp > 1 else batch
+        tok, lab, lmask = batch["tokens"], batch["labels"], batch["loss_mask"]
+        logit_mask = lmask.bool()
+        s = tok.shape[1]
+
+        # ---- forward -------------------------------------------------------------------------------
+        proj = None
+        efd = None
+        if external_inputs:
+            vis = m.external_feature_model
+            images = batch["external_images"]
+            vit_out = torch.cat([vis.vit(ch) for ch in torch.split(images, vis.cfg.chunk_frames, dim=0)], 0)
+            proj = self._projector_forward(vis, vit_out)
+            efd = {"features": proj["feats"]}
+            if cp > 1:
+                efd["src_indices"], efd["tgt_indices"] = batch["external_src_indices"], batch["external_tgt_indices"]
+            else:
+                efd["indices"] = batch["external_indices"]
+        h = m.embedding(tok, None, external_feature_dict=efd).view(s, c.hidden)
+        cos, sin = m.rotary_pos_emb(s * cp)
+        ws = m._workspace(s, h.device)
+        saved = []
+        for lp in m.p["layers"]:
+            saved.append(h.clone())
+            m.decoder_layer(h, lp, cos, sin, ws)
+        idx = ops.mask_to_index(logit_mask.transpose(0, 1).reshape(-1))
+        n_sel = idx.numel()
+        rows = ops.row_gather(h, idx)
+        hn = ops.rmsnorm(rows, m.p["final_ln"], c.eps)
+        hn_p = _pad_rows(hn)
+        logits = ops.gemm(hn_p, m.p["lm_head"])                      # [n_sel (padded), V]
+        # labels of the selected rows (masked_select, gpt_vl_model.py:380-382); 16-byte rows for the gather
+        lab_sel = ops.row_gather(lab.reshape(-1, 1).repeat(1, 2).contiguous(), idx)[:, 0]
+        # instruction shift (gpt_vl_model.py:389-391): logits[:-1] vs labels[1:]
+        shift = 1 if self.is_instruction else 0
+        n_loss = max(n_sel - shift, 0)
+        stats = torch.zeros(2, dtype=torch.float32, device=h.device)
+        dlogits = torch.zeros_like(logits)
+        if n_loss > 0:
+            total = torch.tensor([float(n_loss)], dtype=torch.float32, device=h.device)
+            if cp > 1:
+                dist.all_reduce(total, group=mpu.get_context_parallel_group())
+            scale = (1.0 / total).expand(n_loss).contiguous()
+            loss_rows, dl = ops.ce_loss(logits[:n_loss], lab_sel[shift:shift + n_loss].contiguous(), scale, want_grad=True)
+            dlogits[:n_loss] = dl
+            stats[0], stats[1] = loss_rows.sum(), float(n_loss)
+        elif cp > 1:
+            dist.all_reduce(torch.zeros(1, dtype=torch.float32, device=h.device), group=mpu.get_context_parallel_group())
+        if cp > 1:
+            dist.all_reduce(stats, group=mpu.get_context_parallel_group())     # loss_func :801-803
+        loss = stats[0] / stats[1].clamp(min=1.0)
+
+        # ---- backward ------------------------------------------------------------------------------
+        grads = {"layers": [dict() for _ in m.p["layers"]]}
+        grads["lm_head"] = ops.gemm(_t(dlogits), _t(hn_p))              # [V, hidden]
+        d_hn = _dgrad(dlogits, m.p["lm_head"])[:n_sel]
+        dfl = torch.zeros(c.hidden, dtype=torch.float32, device=h.device)
+        d_rows = ops.rmsnorm_bwd(d_hn.contiguous(), rows, m.p["final_ln"], c.eps, dfl)
+        grads["final_ln"] = dfl
+        dh = torch.zeros(s, c.hidden, dtype=h.dtype, device=h.device)
+        ops.row_scatter_(dh, idx, d_rows)                                # zeros.masked_scatter (layers.py:451)
+        for li in range(len(m.p["layers"]) - 1, -1, -1):
+            dh = self._layer_backward(dh, saved[li], m.p["layers"][li], cos, sin, grads["layers"][li])
+            saved[li] = None
+        # ---- embedding / visual-token scatter backward ---------------------------------------------
+        tok_idx = tok.reshape(-1).clone()
+        d_embed = torch.zeros(m.p["embed"].shape, dtype=torch.float32, device=h.device)
+        if efd is not None:
+            feats = proj["feats"]
+            L = feats.shape[1]
+            if "indices" in efd:
+                ib, is_ = efd["indices"].unbind(dim=0)
+                tgt = (ib.reshape(-1) * s + is_.reshape(-1))
+                src = torch.arange(tgt.numel(), device=h.device)
+            else:
+                tgt = efd["tgt_indices"][0] * s + efd["tgt_indices"][1]
+                src = efd["src_indices"][0] * L + efd["src_indices"][1]
+            tok_idx[tgt] = -1                                           # overwritten rows: no embedding grad
+            d_feats = torch.zeros(feats.shape[0] * L, c.hidden, dtype=h.dtype, device=h.device)
+            ops.row_scatter_(d_feats, src, ops.row_gather(dh, tgt))
+            self._projector_backward(m.external_feature_model, proj, d_feats, grads)
+        ops.row_scatter_add_f32_(d_embed, tok_idx, dh)
+        grads["embed"] = d_embed
+        return loss, grads
+
+    # ------------------------------------------------------------------------------------------
+    def _projector_forward(self, vis, vit_out):
+        p, cfg = vis.p, vis.cfg
+        ones = torch.ones_like(p["proj_ln_w"])
+        xhat = ops.pixel_shuffle_ln(vit_out, ones, None, cfg.grid, cfg.add_class_token, cfg.proj_ln_eps)   # normalised, w=1 b=0
+        t = ops.pixel_shuffle_ln(vit_out, p["proj_ln_w"], p["proj_ln_b"], cfg.grid, cfg.add_class_token, cfg.proj_ln_eps)
+        t2 = t.view(-1, t.shape[-1])
+        f1 = ops.gemm(t2, p["proj_fc1"])                                # pre-GELU, unfused
+        a = ops.gemm(t2, p["proj_fc1"], ops.EPI_BIAS_GELU)
+        feats = ops.gemm(a, p["proj_fc2"]).view(vit_out.shape[0], -1, cfg.llm_hidden)
+        return dict(xhat=xhat.view(-1, xhat.shape[-1]), t=t2, f1=f1, a=a, feats=feats)
+
+    def _projector_backward(self, vis, proj, d_feats, grads):
+        p, cfg = vis.p, vis.cfg
+        df_t = _t(_pad_rows(d_feats))
+        g = {}
+        g["proj_fc2"] = ops.gemm(df_t, _t(_pad_rows(proj["a"])))
+        d_a = _dgrad(d_feats, p["proj_fc2"])
+        d_f1 = ops.gelu_bwd(proj["f1"], d_a)
+        g["proj_fc1"] = ops.gemm(_t(_pad_rows(d_f1)), _t(_pad_rows(proj["t"])))
+        d_t = _dgrad(d_f1, p["proj_fc1"])
+        dgam = torch.zeros(p["proj_ln_w"].numel(), dtype=torch.float32, device=d_feats.device)
+        dbet = torch.zeros_like(dgam)
+        ops.layernorm_param_grad(d_t, proj["xhat"], dgam, dbet, cfg.proj_ln_eps, prenormalized=True)
+        g["proj_ln_w"], g["proj_ln_b"] = dgam, dbet
+        grads["projector"] = g
+
+
+def allreduce_grads(grads) -> None:
+    """Sum the per-rank gradient contributions over the context-parallel group (fp32 on the wire)."""
+    if mpu.get_context_parallel_world_size() == 1:
+        return
+    group = mpu.get_context_parallel_group()
+
+    def walk(node):
+        if isinstance(node, dict):
+            for k, v in node.items():
+                node[k] = walk(v)
+            return node
+        if isinstance(node, list):
+            return [walk(v) for v in node]
+        t = node.float()
+        dist.all_reduce(t, group=group)
+        return t.to(node.dtype)
+
+    walk(grads)

@@ -1,0 +1,187 @@
+"""Backward kernels vs torch autograd over the CPU oracle (the reference obtains these gradients from
+autograd over the same forward expressions)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+from oracle import attention as oattn  # noqa: E402
+from oracle import glue  # noqa: E402
+
+DEV = "cuda"
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from long_vita_amd import ops as _ops
+    _ops._L.load(allow_build=False)
+    return _ops
+
+
+def g(seed):
+    return torch.Generator().manual_seed(seed)
+
+
+def rel_l2(a, b):
+    a, b = a.float().cpu(), b.float().cpu()
+    return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+@pytest.mark.parametrize("R,C", [(64, 64), (100, 130), (5120, 7168), (1, 77), (333, 8)])
+def test_transpose_bit_exact(ops, R, C):
+    x = torch.randn(R, C, generator=g(1)).bfloat16()
+    assert torch.equal(ops.transpose(x.to(DEV)).cpu(), x.t().contiguous())
+    big = torch.randn(R, C + 16, generator=g(2)).bfloat16().to(DEV)
+    assert torch.equal(ops.transpose(big[:, 8:8 + C]).cpu(), big[:, 8:8 + C].t().contiguous().cpu())
+
+
+@pytest.mark.parametrize("rows,cols", [(37, 5120), (300, 1024)])
+def test_rmsnorm_bwd(ops, rows, cols):
+    x = (torch.randn(rows, cols, generator=g(3)) * 2).bfloat16().requires_grad_(True)
+    w = (1 + 0.1 * torch.randn(cols, generator=g(4))).bfloat16().requires_grad_(True)
+    dy = torch.randn(rows, cols, generator=g(5)).bfloat16()
+    glue.rmsnorm(x, w, 1e-6).backward(dy)
+    dw = torch.zeros(cols, dtype=torch.float32, device=DEV)
+    dx = ops.rmsnorm_bwd(dy.to(DEV), x.detach().to(DEV), w.detach().to(DEV), 1e-6, dw)
+    assert rel_l2(dx, x.grad) < 4e-3
+    assert rel_l2(dw, w.grad) < 4e-3                     # autograd sums bf16 products in bf16 storage
+
+
+def test_swiglu_fwd_bwd(ops):
+    rows, F = 70, 13824
+    y = torch.randn(rows, 2 * F, generator=g(6)).bfloat16().requires_grad_(True)
+    da = torch.randn(rows, F, generator=g(7)).bfloat16()
+    gate, up = torch.chunk(y, 2, dim=-1)
+    a = torch.nn.functional.silu(gate.float()).to(y.dtype) * up
+    a.backward(da)
+    out = ops.swiglu(y.detach().to(DEV))
+    assert rel_l2(out, a.detach()) < 3e-3
+    dy = ops.swiglu_bwd(y.detach().to(DEV), da.to(DEV))
+    assert rel_l2(dy, y.grad) < 4e-3
+
+
+def test_gelu_bwd_and_layernorm_param_grad(ops):
+    x = torch.randn(64, 1024, generator=g(8)).bfloat16().requires_grad_(True)
+    dy = torch.randn(64, 1024, generator=g(9)).bfloat16()
+    torch.nn.functional.gelu(x.float()).to(x.dtype).backward(dy)
+    assert rel_l2(ops.gelu_bwd(x.detach().to(DEV), dy.to(DEV)), x.grad) < 4e-3
+    rows, cols = 200, 4096
+    xi = (torch.randn(rows, cols, generator=g(10)) + 0.3).bfloat16()
+    gam = torch.ones(cols, requires_grad=True)
+    bet = torch.zeros(cols, requires_grad=True)
+    d2 = torch.randn(rows, cols, generator=g(11)).bfloat16()
+    torch.nn.functional.layer_norm(xi.float(), (cols,), gam, bet, 1e-5).backward(d2.float())
+    dg = torch.zeros(cols, dtype=torch.float32, device=DEV)
+    db = torch.zeros(cols, dtype=torch.float32, device=DEV)
+    ops.layernorm_param_grad(d2.to(DEV), xi.to(DEV), dg, db, 1e-5)
+    torch.testing.assert_close(dg.cpu(), gam.grad, rtol=2e-3, atol=2e-3)
+    torch.testing.assert_close(db.cpu(), bet.grad, rtol=2e-3, atol=2e-3)
+
+
+def test_ce_loss_and_grad(ops):
+    n, V = 9, 152064
+    logits = (torch.randn(n, V, generator=g(12)) * 3).bfloat16()
+    labels = torch.randint(0, V, (n,), generator=g(13))
+    lf = logits.float().requires_grad_(True)
+    ref = torch.nn.functional.cross_entropy(lf, labels, reduction="none")
+    scale = torch.rand(n, generator=g(14)) + 0.5
+    (ref * scale).sum().backward()
+    loss, dl = ops.ce_loss(logits.to(DEV), labels.to(DEV), scale.to(DEV), want_grad=True)
+    torch.testing.assert_close(loss.cpu(), ref.detach(), rtol=1e-5, atol=1e-5)
+    assert rel_l2(dl, lf.grad) < 4e-3
+    with pytest.raises(IndexError):
+        ops.ce_loss(logits.to(DEV), torch.full((n,), V, dtype=torch.int64, device=DEV))
+
+
+def test_row_scatter_add(ops):
+    src = torch.randn(500, 5120, generator=g(15)).bfloat16()
+    idx = torch.randint(0, 64, (500,), generator=g(16))
+    idx[::7] = -1                                                   # skipped rows
+    dst = torch.zeros(64, 5120, dtype=torch.float32, device=DEV)
+    ops.row_scatter_add_f32_(dst, idx.to(DEV), src.to(DEV))
+    keep = idx >= 0
+    ref = torch.zeros(64, 5120).index_add_(0, idx[keep], src[keep].float())
+    torch.testing.assert_close(dst.cpu(), ref, rtol=1e-5, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------
+def _attn_grads_ref(q, k, v, d_o, q_pos=None, k_pos=None):
+    """autograd through the unfused reference math (fp32) on bf16-valued inputs."""
+    qf = q.float().requires_grad_(True)
+    kf = k.float().requires_grad_(True)
+    vf = v.float().requires_grad_(True)
+    o = oattn.core_attention(qf.transpose(0, 1), kf.transpose(0, 1), vf.transpose(0, 1), True, q_pos=q_pos, k_pos=k_pos)
+    B, S, H, Dh = q.shape
+    o = o.view(S, B, H, Dh).transpose(0, 1)
+    o.backward(d_o.float())
+    return o.detach(), qf.grad, kf.grad, vf.grad
+
+
+@pytest.mark.parametrize("S,Hq,Hkv", [(128, 2, 1), (256, 5, 1), (512, 10, 2), (1024, 5, 1)])
+def test_flash_attn_bwd_single_chunk(ops, S, Hq, Hkv):
+    Dh = 128
+    q = torch.randn(1, S, Hq, Dh, generator=g(20)).bfloat16()
+    k = torch.randn(1, S, Hkv, Dh, generator=g(21)).bfloat16()
+    v = torch.randn(1, S, Hkv, Dh, generator=g(22)).bfloat16()
+    d_o = torch.randn(1, S, Hq, Dh, generator=g(23)).bfloat16()
+    _, dq_r, dk_r, dv_r = _attn_grads_ref(q, k, v, d_o)
+    qd, kd, vd = q.to(DEV), k.to(DEV), v.to(DEV)
+    o, lse = ops.flash_attn(qd, kd, vd, causal=True, return_lse=True)
+    dq, dk, dv = ops.flash_attn_bwd(qd, kd, vd, o, d_o.to(DEV), lse)
+    # P and dS are rounded to bf16 before their MFMAs (as flash-attn does): 1.5e-2 relative L2
+    assert rel_l2(dv, dv_r) < 1.5e-2, rel_l2(dv, dv_r)
+    assert rel_l2(dq, dq_r) < 1.5e-2, rel_l2(dq, dq_r)
+    assert rel_l2(dk, dk_r) < 1.5e-2, rel_l2(dk, dk_r)
+
+
+def test_flash_attn_bwd_mixed_qkv_layout(ops):
+    """Gradients written straight into a mixed-QKV-shaped buffer (grouped dq view, dk/dv head slots)."""
+    S, ng, qpg, d = 256, 2, 5, 128
+    mixed = torch.randn(1, S, ng, qpg + 2, d, generator=g(24)).bfloat16().to(DEV)
+    q5, kview, vview = mixed[:, :, :, :qpg], mixed[:, :, :, qpg], mixed[:, :, :, qpg + 1]
+    d_o = torch.randn(1, S, ng * qpg, d, generator=g(25)).bfloat16().to(DEV)
+    o, lse = ops.flash_attn(q5, kview, vview, causal=True, return_lse=True)
+    dmixed = torch.zeros_like(mixed)
+    ops.flash_attn_bwd(q5, kview, vview, o, d_o, lse, dq5=dmixed[:, :, :, :qpg], dk=dmixed[:, :, :, qpg],
+                       dv=dmixed[:, :, :, qpg + 1])
+    _, dq_r, dk_r, dv_r = _attn_grads_ref(q5.reshape(1, S, ng * qpg, d).cpu(), kview.cpu(), vview.cpu(), d_o.cpu())
+    assert rel_l2(dmixed[:, :, :, :qpg].reshape(1, S, ng * qpg, d), dq_r) < 1.5e-2
+    assert rel_l2(dmixed[:, :, :, qpg], dk_r) < 1.5e-2
+    assert rel_l2(dmixed[:, :, :, qpg + 1], dv_r) < 1.5e-2
+
+
+@pytest.mark.parametrize("cp,S", [(2, 1024), (4, 2048)])
+def test_flash_attn_bwd_zigzag(ops, cp, S):
+    """Per-rank backward over the gathered K/V (dk/dv in gathered layout), summed over ranks ==
+    monolithic causal attention gradients (the reduce-scatter of the CP backward)."""
+    Hq, Hkv, Dh = 5, 1, 128
+    C = S // (2 * cp)
+    q = torch.randn(1, S, Hq, Dh, generator=g(30)).bfloat16()
+    k = torch.randn(1, S, Hkv, Dh, generator=g(31)).bfloat16()
+    v = torch.randn(1, S, Hkv, Dh, generator=g(32)).bfloat16()
+    d_o = torch.randn(1, S, Hq, Dh, generator=g(33)).bfloat16()
+    _, dq_r, dk_r, dv_r = _attn_grads_ref(q, k, v, d_o)
+    k_g = torch.cat([glue.zigzag_slice(k, cp, r) for r in range(cp)], 1).to(DEV)
+    v_g = torch.cat([glue.zigzag_slice(v, cp, r) for r in range(cp)], 1).to(DEV)
+    kv_gid, kv_row = [], []
+    for r in range(cp):
+        kv_gid += [r, 2 * cp - 1 - r]
+        kv_row += [2 * r * C, (2 * r + 1) * C]
+    dk_sum = torch.zeros(1, S, Hkv, Dh)
+    dv_sum = torch.zeros(1, S, Hkv, Dh)
+    for r in range(cp):
+        geo = dict(chunk_len=C, q_chunk_gid=[r, 2 * cp - 1 - r], kv_chunk_gid=kv_gid, kv_chunk_row=kv_row)
+        q_l = glue.zigzag_slice(q, cp, r).to(DEV)
+        do_l = glue.zigzag_slice(d_o, cp, r).to(DEV)
+        o, lse = ops.flash_attn(q_l, k_g, v_g, causal=True, return_lse=True, **geo)
+        dq, dk, dv = ops.flash_attn_bwd(q_l, k_g, v_g, o, do_l, lse, **geo)
+        assert rel_l2(dq, glue.zigzag_slice(dq_r, cp, r)) < 1.5e-2
+        dk_sum += dk.float().cpu()
+        dv_sum += dv.float().cpu()
+    # un-zig-zag the gathered layout: buffer rows of rank p = zigzag_slice(., cp, p)
+    dk_ref_g = torch.cat([glue.zigzag_slice(dk_r, cp, r) for r in range(cp)], 1)
+    dv_ref_g = torch.cat([glue.zigzag_slice(dv_r, cp, r) for r in range(cp)], 1)
+    assert rel_l2(dk_sum, dk_ref_g) < 1.5e-2
+    assert rel_l2(dv_sum, dv_ref_g) < 1.5e-2
