@@ -55,7 +55,10 @@ class DotProductAttention:
             raise ValueError("local sequence must hold two zig-zag chunks")
         c = s_l // 2
         gathered = self._gather_buffer(kv_local, cp)
-        dist.all_gather_into_tensor(gathered, kv_local.view(-1), group=mpu.get_context_parallel_group())
+        if cp > 1 or dist.is_initialized():
+            dist.all_gather_into_tensor(gathered, kv_local.view(-1), group=mpu.get_context_parallel_group())
+        else:                                       # forced CP path without a process group
+            gathered.copy_(kv_local.view(-1))
         g = gathered.view(cp, 2, s_l, self.ng, self.hn)
         rows = g.view(cp * 2 * s_l, self.ng, self.hn)          # K rows of rank p start at p*2*s_l, V at +s_l
         k_all = rows.unsqueeze(0)

@@ -12,6 +12,7 @@ is reused across the 48 layers (sized once for the local sequence length).
 """
 from __future__ import annotations
 
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -55,6 +56,7 @@ class GPTVLModel:
         self.core_attention = DotProductAttention(cfg.heads, cfg.kv_groups, cfg.head_dim, causal=True)
         self.output_layer = ColumnParallelLinear(params["lm_head"], bias=None)
         self._ws = {}
+        self.force_cp_path = bool(int(os.environ.get("VITA_FORCE_CP", "0")))   # diagnostics only
         self.attn_events = None      # bench.py: list collecting (start, end) HIP events per attention launch
 
     # ---------------------------------------------------------------------------------------------
@@ -102,15 +104,16 @@ class GPTVLModel:
         c = self.cfg
         s = h.shape[0]
         cp = mpu.get_context_parallel_world_size()
+        use_cp = cp > 1 or self.force_cp_path          # force: exercise pack + all-gather + chunk tables at CP = 1
         x = ops.rmsnorm(h, lp["ln1"], c.eps, out=ws["x"])
         qkv = ops.gemm(x, lp["qkv_w"], ops.EPI_BIAS, lp["qkv_b"], out=ws["qkv"])
-        ops.rope_qkv_(qkv, c.kv_groups, c.qpg, c.head_dim, cos, sin, ws["kv"] if cp > 1 else None)
+        ops.rope_qkv_(qkv, c.kv_groups, c.qpg, c.head_dim, cos, sin, ws["kv"] if use_cp else None)
         m5 = qkv.view(1, s, c.kv_groups, c.qpg + 2, c.head_dim)
         q5 = m5[:, :, :, : c.qpg]                                  # grouped query view, read in place
         ev = None
         if self.attn_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
-        if cp > 1:
+        if use_cp:
             ctx = self.core_attention.forward_cp(q5, ws["kv"], out=ws["ctx"], events=ev)
         else:
             if ev:

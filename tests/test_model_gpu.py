@@ -221,3 +221,37 @@ def test_reference_compat_logit_mask_rule(amd):
             assert m[0].nonzero().flatten().tolist() == pos and blk == b2
     finally:
         mpu.destroy_model_parallel()
+
+
+def test_cp_code_path_on_real_rccl_single_rank(amd):
+    """The context-parallel code path (K/V pack, RCCL all_gather_into_tensor, chunk-table attention,
+    logits all-gather) on a REAL nccl (= RCCL) process group of world size 1, against the plain path."""
+    import os
+    import socket
+
+    import torch.distributed as dist
+    ocfg, p, model = _llm_pair(amd, SMALL)
+    S = 2048
+    tokens = torch.randint(0, SMALL["vocab"], (1, S), generator=torch.Generator().manual_seed(3)).to(DEV)
+    plain = amd["gen"].prefill_step(model, tokens, S - 3, None, reference_compat=False)
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port))
+    dist.init_process_group("nccl", rank=0, world_size=1, device_id=torch.device("cuda:0"))
+    try:
+        amd["mpu"].initialize_model_parallel()
+        assert amd["mpu"].get_context_parallel_world_size() == 1
+        m2 = amd["gpt"].GPTVLModel(model.cfg, model.p)
+        m2.force_cp_path = True
+        forced = amd["gen"].prefill_step(m2, tokens, S - 3, None, reference_compat=False)
+        # one rank: gid table [0, 1] over two half-sequence chunks == plain causal attention
+        assert rel_l2(forced, plain) < 1e-3
+        t = torch.ones(4, device=DEV)
+        dist.all_reduce(t)
+        out = torch.empty(8, device=DEV)
+        dist.all_gather_into_tensor(out, torch.arange(8, dtype=torch.float32, device=DEV))
+        assert out.tolist() == list(range(8))
+    finally:
+        dist.destroy_process_group()
+        amd["mpu"].destroy_model_parallel()

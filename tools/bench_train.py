@@ -1,0 +1,45 @@
+"""Secondary measurement (BASELINE config 5 shape at TP=1): forward + backward step
+time of the 14B decoder with the logits-masked head and full activation recompute, one GPU.
+    python tools/bench_train.py --seq 16384 [--layers 48]
+Prints one JSON line (not the contract line of bench.py)."""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+from long_vita_amd import gpt_vl_model, lib, training
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--seq", type=int, default=16384)
+ap.add_argument("--layers", type=int, default=48)
+ap.add_argument("--answer", type=int, default=512)
+ap.add_argument("--steps", type=int, default=2)
+args = ap.parse_args()
+lib.load(allow_build=False)
+dev = "cuda:0"
+cfg = gpt_vl_model.GPTConfig(num_layers=args.layers)
+model = gpt_vl_model.GPTVLModel.random_init(cfg, seed=1, device=dev)
+g = torch.Generator(device=dev).manual_seed(2)
+S = args.seq
+tokens = torch.randint(0, 151643, (1, S), generator=g, device=dev)
+labels = torch.roll(tokens, -1, 1)
+loss_mask = torch.zeros(1, S, device=dev)
+loss_mask[0, S - args.answer:] = 1
+step = training.TrainStep(model)
+loss, grads = step.forward_backward(tokens, labels, loss_mask)      # warm-up
+del grads
+torch.cuda.synchronize()
+t0 = time.perf_counter()
+for _ in range(args.steps):
+    loss, grads = step.forward_backward(tokens, labels, loss_mask)
+    del grads
+torch.cuda.synchronize()
+dt = (time.perf_counter() - t0) / args.steps
+lin = cfg.num_layers * 2 * (cfg.hidden * cfg.qkv_out + cfg.hidden * cfg.heads * cfg.head_dim + 3 * cfg.hidden * cfg.ffn) * S
+attn = cfg.num_layers * 4 * cfg.head_dim * cfg.heads * (S * (S + 1) // 2)
+fwd = lin + attn
+# fwd + recompute fwd + bwd (2x linears, 2.5x attention: 5 of the 2 forward GEMM-units... counted as 2x)
+alg = 4 * lin + (2 + 2.5) * attn
+print(json.dumps({"what": "train step fwd+bwd (full recompute), TP=1 CP=1", "seq": S, "layers": cfg.num_layers,
+                  "answer_tokens": args.answer, "s_per_step": dt, "loss": float(loss),
+                  "algorithmic_tflop_per_step": alg / 1e12, "tflops": alg / dt / 1e12,
+                  "tokens_per_s": S / dt, "peak_mem_gb": torch.cuda.max_memory_allocated() / 2**30}))
