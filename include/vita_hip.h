@@ -70,10 +70,12 @@ int vita_rope_apply(void* t, int64_t rows, int heads, int head_dim,
 /* Fused RoPE over Megatron's mixed QKV activation [rows, groups, (qpg + 2) * d]
  * (layout: L/core/models/vision/intern_vit_model.py:145-197; weights R/tools/hf2mcore_long_vita.py:597-609):
  * rotates the qpg query heads and the key head of every group in place and, when kv_out != NULL,
- * also packs rotated K and V into kv_out = [2][rows][groups][d] (the all-gather send buffer of
- * the context-parallel attention). */
+ * also packs rotated K and V into kv_out = [kv_split][2][rows][groups / kv_split][d]: kv_split
+ * contiguous all-gather messages of the context-parallel attention (split by kv head so that the
+ * gather of split j+1 overlaps the attention over split j; kv_split = 1: one message). */
 int vita_rope_qkv_fwd(void* mixed_qkv, int64_t rows, int groups, int q_per_group, int head_dim,
-                      const void* cos_tab, const void* sin_tab, void* kv_out, void* stream);
+                      const void* cos_tab, const void* sin_tab, void* kv_out, int kv_split,
+                      void* stream);
 /* Backward of the rotation on the gradient of the mixed QKV activation (in place): applies the
  * transpose rotation to the dQ and dK heads, leaves dV untouched. */
 int vita_rope_qkv_bwd(void* d_mixed_qkv, int64_t rows, int groups, int q_per_group, int head_dim,

@@ -77,11 +77,14 @@ __global__ __launch_bounds__(256) void rope_qkv_kernel(bf16_t* __restrict__ mixe
                                                        int groups, int qpg, int head_dim,
                                                        const bf16_t* __restrict__ cos_tab,
                                                        const bf16_t* __restrict__ sin_tab,
-                                                       bf16_t* __restrict__ kv_out, float sign) {
+                                                       bf16_t* __restrict__ kv_out, float sign,
+                                                       int kv_split) {
   const int half = head_dim >> 1, nv = half >> 3, hpg = qpg + 2;
   const int64_t per_row = (int64_t)groups * hpg * nv;
   const int64_t total = rows * per_row;
-  const int64_t kv_plane = rows * (int64_t)groups * head_dim;  // elements in K (or V) of kv_out
+  // kv_out = [kv_split][2][rows][groups / kv_split][d]: one contiguous all-gather message per split
+  const int hg = groups / kv_split;
+  const int64_t kv_plane = rows * (int64_t)hg * head_dim;       // elements in K (or V) of one split
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total;
        i += (int64_t)gridDim.x * blockDim.x) {
     const int64_t r = i / per_row;
@@ -101,7 +104,7 @@ __global__ __launch_bounds__(256) void rope_qkv_kernel(bf16_t* __restrict__ mixe
       *reinterpret_cast<u32x4*>(p + half) = x2;
     }
     if (kv_out && h >= qpg) {
-      bf16_t* o = kv_out + (h - qpg) * kv_plane + (r * groups + g) * (int64_t)head_dim + vi * 8;
+      bf16_t* o = kv_out + ((g / hg) * 2 + (h - qpg)) * kv_plane + (r * hg + g % hg) * (int64_t)head_dim + vi * 8;
       *reinterpret_cast<u32x4*>(o) = x1;
       *reinterpret_cast<u32x4*>(o + half) = x2;
     }
@@ -143,16 +146,17 @@ extern "C" int vita_rope_apply(void* t, int64_t rows, int heads, int head_dim, i
 
 extern "C" int vita_rope_qkv_fwd(void* mixed_qkv, int64_t rows, int groups, int q_per_group,
                                  int head_dim, const void* cos_tab, const void* sin_tab,
-                                 void* kv_out, void* stream) {
+                                 void* kv_out, int kv_split, void* stream) {
   if (!mixed_qkv || !cos_tab || !sin_tab || rows < 0 || groups <= 0 || q_per_group <= 0 ||
       head_dim <= 0)
     return VITA_ERR_INVALID_ARG;
   if (head_dim & 15) return VITA_ERR_UNSUPPORTED;
+  if (kv_split <= 0 || groups % kv_split) return VITA_ERR_INVALID_ARG;
   if (rows == 0) return VITA_OK;
   const int64_t total = rows * groups * (q_per_group + 2) * (head_dim / 16);
   hipLaunchKernelGGL(rope_qkv_kernel, dim3(grid_for(total, 256)), dim3(256), 0,
                      (hipStream_t)stream, (bf16_t*)mixed_qkv, rows, groups, q_per_group, head_dim,
-                     (const bf16_t*)cos_tab, (const bf16_t*)sin_tab, (bf16_t*)kv_out, 1.0f);
+                     (const bf16_t*)cos_tab, (const bf16_t*)sin_tab, (bf16_t*)kv_out, 1.0f, kv_split);
   return vita_check_launch();
 }
 
@@ -165,6 +169,6 @@ extern "C" int vita_rope_qkv_bwd(void* d_mixed_qkv, int64_t rows, int groups, in
   const int64_t total = rows * groups * (q_per_group + 2) * (head_dim / 16);
   hipLaunchKernelGGL(rope_qkv_kernel, dim3(grid_for(total, 256)), dim3(256), 0, (hipStream_t)stream,
                      (bf16_t*)d_mixed_qkv, rows, groups, q_per_group, head_dim, (const bf16_t*)cos_tab,
-                     (const bf16_t*)sin_tab, (bf16_t*)nullptr, -1.0f);
+                     (const bf16_t*)sin_tab, (bf16_t*)nullptr, -1.0f, 1);
   return vita_check_launch();
 }

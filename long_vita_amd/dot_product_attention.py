@@ -40,41 +40,56 @@ class DotProductAttention:
             if b != 1:
                 raise ValueError("context-parallel attention runs batch 1")
             kv = torch.stack([key.reshape(sq, self.ng, hn), value.reshape(sq, self.ng, hn)]).contiguous()
-            out = self.forward_cp(q, kv)
+            out = self.forward_cp(q.reshape(1, sq, self.ng, np_ // self.ng, hn), kv)
         else:
             out = ops.flash_attn(q, k, v, causal=self.causal, softmax_scale=self.softmax_scale)
         return out.transpose(0, 1).reshape(sq, b, np_ * hn)                           # [sq, b, hp] :285-289
 
     __call__ = forward
 
-    # -- context-parallel core: q [1, S_l, ...] view, kv_local packed [2, S_l, ng, d] ----------------
-    def forward_cp(self, q: torch.Tensor, kv_local: torch.Tensor, out: Optional[torch.Tensor] = None, events=None):
+    # -- context-parallel core ----------------------------------------------------------------------
+    def forward_cp(self, q5: torch.Tensor, kv_local: torch.Tensor, out: Optional[torch.Tensor] = None, events=None):
+        """q5 [1, S_l, ng, qpg, d] grouped query view; kv_local packed [kv_split, 2, S_l, ng/kv_split, d]
+        (vita_rope_qkv_fwd).  One all-gather per kv-head split, all issued up front on RCCL's stream;
+        the attention over split j waits only for gather j, so gather j+1 runs under it."""
         cp, r = mpu.get_context_parallel_world_size(), mpu.get_context_parallel_rank()
-        s_l = kv_local.shape[1]
+        if kv_local.dim() == 4:
+            kv_local = kv_local.unsqueeze(0)
+        n_split, _, s_l, hg, d = kv_local.shape
         if s_l % 2:
             raise ValueError("local sequence must hold two zig-zag chunks")
         c = s_l // 2
-        gathered = self._gather_buffer(kv_local, cp)
-        if cp > 1 or dist.is_initialized():
-            dist.all_gather_into_tensor(gathered, kv_local.view(-1), group=mpu.get_context_parallel_group())
-        else:                                       # forced CP path without a process group
-            gathered.copy_(kv_local.view(-1))
-        g = gathered.view(cp, 2, s_l, self.ng, self.hn)
-        rows = g.view(cp * 2 * s_l, self.ng, self.hn)          # K rows of rank p start at p*2*s_l, V at +s_l
-        k_all = rows.unsqueeze(0)
-        v_all = rows[s_l:].unsqueeze(0)
+        qpg = self.np // self.ng
+        if q5.dim() != 5:
+            q5 = q5.reshape(1, s_l, self.ng, qpg, d)
+        if out is None:
+            out = torch.empty((1, s_l, self.np, d), dtype=q5.dtype, device=q5.device)
+        gathered = self._gather_buffer(kv_local, cp).view(n_split, cp, 2 * s_l * hg * d)
+        group = mpu.get_context_parallel_group()
+        works = []
+        for j in range(n_split):
+            if cp > 1 or dist.is_initialized():
+                works.append(dist.all_gather_into_tensor(gathered[j].view(-1), kv_local[j].reshape(-1), group=group,
+                                                         async_op=True))
+            else:                                   # forced CP path without a process group
+                gathered[j].view(-1).copy_(kv_local[j].reshape(-1))
+                works.append(None)
         kv_gid, kv_row = [], []
         for p in range(cp):
             kv_gid += [p, 2 * cp - 1 - p]
             kv_row += [p * 2 * s_l, p * 2 * s_l + c]
         if events:
             events[0].record()
-        o = ops.flash_attn(q, k_all, v_all, causal=True, softmax_scale=self.softmax_scale, chunk_len=c,
-                           q_chunk_gid=mpu.zigzag_chunk_ids(cp, r), kv_chunk_gid=kv_gid, kv_chunk_row=kv_row,
-                           out=out)
+        for j in range(n_split):
+            if works[j] is not None:
+                works[j].wait()
+            rows = gathered[j].view(cp * 2 * s_l, hg, d)          # K rows of rank p at p*2*s_l, V at +s_l
+            ops.flash_attn(q5[:, :, j * hg:(j + 1) * hg], rows.unsqueeze(0), rows[s_l:].unsqueeze(0), causal=True,
+                           softmax_scale=self.softmax_scale, chunk_len=c, q_chunk_gid=mpu.zigzag_chunk_ids(cp, r),
+                           kv_chunk_gid=kv_gid, kv_chunk_row=kv_row, out=out[:, :, j * hg * qpg:(j + 1) * hg * qpg])
         if events:
             events[1].record()
-        return o
+        return out
 
     def _gather_buffer(self, kv_local, cp):
         n = kv_local.numel() * cp

@@ -56,6 +56,8 @@ class GPTVLModel:
         self.core_attention = DotProductAttention(cfg.heads, cfg.kv_groups, cfg.head_dim, causal=True)
         self.output_layer = ColumnParallelLinear(params["lm_head"], bias=None)
         self._ws = {}
+        # K/V all-gather messages per layer (split by kv head; gather j+1 overlaps attention j)
+        self.kv_split = 4 if cfg.kv_groups % 4 == 0 else (2 if cfg.kv_groups % 2 == 0 else 1)
         self.force_cp_path = bool(int(os.environ.get("VITA_FORCE_CP", "0")))   # diagnostics only
         self.attn_events = None      # bench.py: list collecting (start, end) HIP events per attention launch
 
@@ -95,7 +97,7 @@ class GPTVLModel:
             c = self.cfg
             e = lambda *shape: torch.empty(*shape, dtype=torch.bfloat16, device=device)  # noqa: E731
             ws = {"x": e(s, c.hidden), "qkv": e(s, c.qkv_out), "ctx": e(1, s, c.heads, c.head_dim),
-                  "act": e(s, c.ffn), "kv": e(2, s, c.kv_groups, c.head_dim)}
+                  "act": e(s, c.ffn), "kv": e(self.kv_split, 2, s, c.kv_groups // self.kv_split, c.head_dim)}
             self._ws = {s: ws}          # keep one size only
         return ws
 
@@ -107,7 +109,7 @@ class GPTVLModel:
         use_cp = cp > 1 or self.force_cp_path          # force: exercise pack + all-gather + chunk tables at CP = 1
         x = ops.rmsnorm(h, lp["ln1"], c.eps, out=ws["x"])
         qkv = ops.gemm(x, lp["qkv_w"], ops.EPI_BIAS, lp["qkv_b"], out=ws["qkv"])
-        ops.rope_qkv_(qkv, c.kv_groups, c.qpg, c.head_dim, cos, sin, ws["kv"] if use_cp else None)
+        ops.rope_qkv_(qkv, c.kv_groups, c.qpg, c.head_dim, cos, sin, ws["kv"] if use_cp else None, self.kv_split)
         m5 = qkv.view(1, s, c.kv_groups, c.qpg + 2, c.head_dim)
         q5 = m5[:, :, :, : c.qpg]                                  # grouped query view, read in place
         ev = None

@@ -21,6 +21,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libvita_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "vita_hip.h")
 
+ABI_VERSION = 2
 VITA_OK = 0
 VITA_ERR_INVALID_ARG = -1
 VITA_ERR_UNSUPPORTED = -2
@@ -86,7 +87,7 @@ PROTOTYPES = {
     "vita_layernorm_fwd": (_i, [_p, _p, _p, _p, _l, _i, _f, _p]),
     "vita_rope_table": (_i, [_p, _p, _p, _p, _l, _i, _p]),
     "vita_rope_apply": (_i, [_p, _l, _i, _i, _l, _l, _p, _p, _i, _p]),
-    "vita_rope_qkv_fwd": (_i, [_p, _l, _i, _i, _i, _p, _p, _p, _p]),
+    "vita_rope_qkv_fwd": (_i, [_p, _l, _i, _i, _i, _p, _p, _p, _i, _p]),
     "vita_row_gather": (_i, [_p, _l, _p, _p, _l, _i, _i, _p, _p]),
     "vita_row_scatter": (_i, [_p, _l, _p, _p, _l, _p, _l, _i, _i, _p, _p]),
     "vita_mask_to_index": (_i, [_p, _l, _p, _p, _p]),
@@ -153,7 +154,7 @@ def load(allow_build: bool = True):
                 raise VitaLibraryError(f"{LIB_PATH} does not export {name}") from e
             fn.restype = res
             fn.argtypes = args
-        if lib.vita_abi_version() != 1:
+        if lib.vita_abi_version() != ABI_VERSION:
             raise VitaLibraryError("libvita_hip.so ABI version mismatch")
         _lib = lib
         return _lib

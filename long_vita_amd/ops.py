@@ -98,9 +98,9 @@ def rope_apply_(t: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, sign: int
 
 
 def rope_qkv_(mixed_qkv: torch.Tensor, groups: int, q_per_group: int, head_dim: int, cos: torch.Tensor,
-              sin: torch.Tensor, kv_out: Optional[torch.Tensor] = None) -> torch.Tensor:
+              sin: torch.Tensor, kv_out: Optional[torch.Tensor] = None, kv_split: int = 1) -> torch.Tensor:
     """Rotate Q/K of Megatron's mixed QKV [rows, groups*(qpg+2)*d] in place; optionally pack
-    rotated K and V into kv_out [2, rows, groups, d]."""
+    rotated K and V into kv_out [kv_split, 2, rows, groups / kv_split, d]."""
     if not mixed_qkv.is_contiguous():
         raise ValueError("mixed_qkv must be contiguous")
     rows = mixed_qkv.numel() // (groups * (q_per_group + 2) * head_dim)
@@ -108,7 +108,7 @@ def rope_qkv_(mixed_qkv: torch.Tensor, groups: int, q_per_group: int, head_dim: 
         raise ValueError("kv_out must be contiguous [2, rows, groups, head_dim]")
     _L.check(_L.load().vita_rope_qkv_fwd(_dev(mixed_qkv, "mixed_qkv", BF16), rows, groups, q_per_group, head_dim,
                                          _dev(cos, "cos", BF16), _dev(sin, "sin", BF16), _opt(kv_out, "kv_out", BF16),
-                                         _stream()), "vita_rope_qkv_fwd")
+                                         int(kv_split), _stream()), "vita_rope_qkv_fwd")
     return mixed_qkv
 
 

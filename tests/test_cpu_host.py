@@ -22,7 +22,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     declared -= {"vita_attn_params"}
     assert declared == set(lib.PROTOTYPES), declared ^ set(lib.PROTOTYPES)
     handle = lib.load()                                  # resolves + type-annotates every symbol
-    assert handle.vita_abi_version() == 1
+    assert handle.vita_abi_version() == lib.ABI_VERSION
     assert handle.vita_error_string(-2).decode().startswith("shape")
     out = subprocess.run(["nm", "-D", "--defined-only", lib.LIB_PATH], capture_output=True, text=True).stdout
     exported = set(re.findall(r" T (vita_[a-z0-9_]+)", out))

@@ -106,6 +106,15 @@ def test_rope_qkv_fused(ops):
     ops.rope_qkv_(md, ng, qpg, d, cos, sin, kv)
     assert torch.equal(md.cpu().view(rows, ng, qpg + 2, d), ref)
     assert torch.equal(kv[0].cpu(), ref[:, :, qpg]) and torch.equal(kv[1].cpu(), ref[:, :, qpg + 1])
+    # kv-head split packing: [split][2][rows][ng/split][d] (one all-gather message per split)
+    for split in (2, 4):
+        md2 = mixed.to(DEV).clone()
+        kv2 = torch.empty(split, 2, rows, ng // split, d, dtype=torch.bfloat16, device=DEV)
+        ops.rope_qkv_(md2, ng, qpg, d, cos, sin, kv2, split)
+        hg = ng // split
+        for j in range(split):
+            assert torch.equal(kv2[j, 0].cpu(), ref[:, j * hg:(j + 1) * hg, qpg])
+            assert torch.equal(kv2[j, 1].cpu(), ref[:, j * hg:(j + 1) * hg, qpg + 1])
 
 
 # ---------------------------------------------------------------------------------------------
