@@ -291,6 +291,38 @@ typedef struct {
 
 int vita_flash_attn_bwd(const vita_attn_bwd_params* p, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Single-token decode against a sequence-sharded KV cache.
+ * The decode loop M/inference/text_generation/generation.py:123-205 with --use-kv-cache feeds
+ * tokens[:, prev:ctx] (one token) through the model; under context parallelism the reference turns
+ * the cache off (server_cp .sh:184) and re-prefills.  These three kernels are the per-token path:
+ *
+ * vita_gemv_bf16: y[N] = epilogue(W[N,K] . x[K]) for one token (M = 1) — the linears of
+ *   M/core/tensor_parallel/layers.py:825 at sq = 1.  Epilogues NONE / BIAS / RESIDUAL / SWIGLU
+ *   (W = cat[gate, up], N = ffn) with the rounding chain of vita_gemm_bf16.
+ * vita_decode_attn_partial: the new token's rotated query (qpg heads per kv group, strided view)
+ *   against `len` cached rows k_cache/v_cache[len][groups][128] (row / group strides in elements;
+ *   len_dev != NULL: the row count is min(len, *len_dev), an int32 in device memory, so that a
+ *   captured hipGraph of the token step can be replayed as the cache grows);
+ *   n_splits x groups workgroups each write an un-normalised partial: max and sum in the log2
+ *   domain part_m, part_l [n_splits][heads] and part_o [n_splits][heads][128] (fp32).
+ * vita_decode_attn_merge: merges nparts partials per head (part p at part_m/l + p*part_ml_stride,
+ *   part_o + p*part_o_stride, in floats).  out_bf16 != NULL: normalised context
+ *   [heads][128] bf16; else the merged partial (out_m, out_l [heads], out_o [heads][128]) that the
+ *   ranks exchange (one all-gather of (128+2)*heads floats per layer) and merge again.
+ * Replaces the inference branch of Megatron's Attention.forward (_adjust_key_value_for_inference +
+ * core attention at sq = 1), which M/core/transformer/dot_product_attention.py:153 is called from. */
+int vita_gemv_bf16(const void* x, const void* W, int64_t ldw, void* y, int64_t N, int64_t K,
+                   int epilogue, const void* bias, const void* R, void* stream);
+int vita_decode_attn_partial(const void* q, int64_t q_group_stride, int64_t q_head_stride,
+                             const void* k_cache, const void* v_cache, int64_t kv_row_stride,
+                             int64_t kv_group_stride, int len, const void* len_dev, int n_splits,
+                             int groups, int qpg, int head_dim, float softmax_scale, void* part_m,
+                             void* part_l, void* part_o, void* stream);
+int vita_decode_attn_merge(const void* part_m, const void* part_l, const void* part_o, int nparts,
+                           int64_t part_ml_stride, int64_t part_o_stride, int heads, int head_dim, void* out_m, void* out_l, void* out_o,
+                           void* out_bf16, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -6,6 +6,7 @@ which IS the measured unit of the prefill metric).
   logit-mask position rule                                            :141-165
   sync_output (all-gather of the masked logits + un-zig-zag)          :542-566
   last-token pick                                                     :179-205
+  generate_tokens_probs_and_return_on_first_stage (the loop itself)   :33-280
 """
 from __future__ import annotations
 
@@ -96,3 +97,119 @@ def prefill_step(model, tokens: torch.Tensor, context_length: int, external_inpu
     if block is None:
         return logits[:, -1, :]                                                      # :183-187
     return logits[:, block, :]                                                       # :190
+
+
+# ------------------------------------------------------------------------------------------------
+# the decode loop
+# ------------------------------------------------------------------------------------------------
+def _sample_strategy(logits: torch.Tensor, do_sample=False, top_k=0, top_p=0.0, temperature=1.0):
+    """:569-602 — greedy, or temperature / top-k / top-p sampling.  Sampling policy, not path arithmetic:
+    plain torch on the [b, vocab] row."""
+    if not do_sample:
+        new = torch.argmax(logits, dim=-1)
+        return logits, new
+    logits = logits.float().clone()
+    if temperature != 1.0:
+        logits.div_(temperature)
+    if top_k > 1:
+        kth = torch.topk(logits, top_k)[0][..., -1, None]
+        logits[logits < kth] = float("-inf")
+    if 0.0 < top_p < 1.0:
+        srt, idx = torch.sort(logits, descending=True)
+        cum = torch.softmax(srt, dim=-1).cumsum(dim=-1)
+        drop = cum > top_p
+        drop[..., 1:] = drop[..., :-1].clone()
+        drop[..., 0] = False
+        logits[drop.scatter(1, idx, drop)] = float("-inf")
+    probs = torch.softmax(logits, dim=-1)
+    return logits, torch.multinomial(probs, 1).view(-1)
+
+
+def _cp_prefill_length(prompt_len: int, cp_size: int) -> int:
+    """Tokens a CP prefill is fed: the prompt padded up to a multiple of 2*CP*256 (the attention kernel's
+    q-tile granularity per zig-zag chunk; the reference requires 2*CP, M/training/arguments.py:211-213)."""
+    unit = 2 * cp_size * 256
+    return -(-prompt_len // unit) * unit
+
+
+@torch.no_grad()
+def generate_tokens_probs_and_return_on_first_stage(model, tokens, lengths, return_output_log_probs=False,
+                                                    do_sample=False, top_k=0, top_p=0.0, temperature=1.0,
+                                                    use_eod_token_for_early_termination=True, external_inputs=None,
+                                                    *, use_kv_cache=True, logit_mask=True, termination_id=None,
+                                                    reference_compat=False):
+    """Generator with the reference's contract (:33-280): `tokens` [1, max_sequence_length] holds the prompt
+    (length lengths[0]) followed by padding and is filled in place; yields (tokens[:, :ctx+1], lengths,
+    output_log_probs) per generated token.  args.use_kv_cache / args.logit_mask / the tokenizer's eod are keyword
+    arguments here (the reference reads them from get_args(), :71-76).
+
+    use_kv_cache=False is the reference's CP behaviour: the whole buffer is re-prefilled for every token
+    (:127-135).  use_kv_cache=True prefills once — under CP on the prompt padded to _cp_prefill_length — and then
+    feeds one token per step to the sharded cache; every CP rank gets identical logits, so there is no
+    sync_output on those steps."""
+    from .inference_params import ForwardStep
+    batch_size, max_sequence_length = tokens.shape
+    if batch_size != 1:
+        raise ValueError("the Long-VITA decode loop runs batch 1")
+    min_prompt_length = int(lengths.min().item())
+    if min_prompt_length >= max_sequence_length:
+        raise ValueError("context length + tokens_to_generate too large")                  # :85-86
+    cp_size = mpu.get_context_parallel_world_size()
+    forward_step = ForwardStep(model, batch_size, max_sequence_length, external_inputs=None)
+    ip = forward_step.inference_params
+    ip.use_kv_cache = use_kv_cache
+    output_log_probs = None
+    if return_output_log_probs:
+        output_log_probs = torch.empty((batch_size, max_sequence_length - 1, model.cfg.vocab), dtype=torch.float32,
+                                       device=tokens.device)
+    position_ids = torch.arange(max_sequence_length, dtype=torch.long, device=tokens.device)[None]
+    prev_context_length = 0
+    context_length = min_prompt_length
+    for context_length in range(min_prompt_length, max_sequence_length):
+        first = prev_context_length == 0
+        if use_kv_cache and not first:
+            # cached step: one token, replicated on every rank
+            ip.logit_mask = None
+            logits = forward_step(tokens[:, prev_context_length:context_length],
+                                  position_ids[:, prev_context_length:context_length], None)
+            last_token_logits = logits[:, -1, :]
+        else:
+            if use_kv_cache:
+                fed = context_length if cp_size == 1 else _cp_prefill_length(context_length, cp_size)
+                if fed > max_sequence_length:
+                    tokens_in = torch.nn.functional.pad(tokens[:, :context_length], (0, fed - context_length))
+                else:
+                    tokens_in = tokens[:, :fed]
+                pos_in = torch.arange(fed, dtype=torch.long, device=tokens.device)[None]
+                ip.prefill_valid_tokens = context_length
+            else:
+                tokens_in, pos_in = tokens, position_ids
+            if external_inputs:
+                tokens2use, positions2use, ext2use = get_batch_on_this_cp_rank(tokens_in, pos_in, external_inputs)
+            elif cp_size > 1:
+                r = mpu.get_context_parallel_rank()
+                tokens2use = training_utils.zigzag_slice(tokens_in, cp_size, r)
+                positions2use = training_utils.zigzag_slice(pos_in, cp_size, r)
+                ext2use = None
+            else:
+                tokens2use, positions2use, ext2use = tokens_in, pos_in, None
+            ip.external_inputs = ext2use
+            block = None
+            if logit_mask:
+                ip.logit_mask, block = build_logit_mask(tokens2use, context_length, reference_compat)
+            logits = sync_output(forward_step(tokens2use, positions2use, None))
+            if logit_mask:
+                last_token_logits = logits[:, -1, :] if block is None else logits[:, block, :]
+            else:
+                last_token_logits = logits[:, context_length - 1, :]
+        _, new_sample = _sample_strategy(last_token_logits, do_sample=do_sample, top_k=top_k, top_p=top_p,
+                                         temperature=temperature)
+        started = lengths <= context_length
+        tokens[started, context_length] = new_sample[started]
+        if return_output_log_probs:
+            output_log_probs[:, context_length - 1, :] = torch.log_softmax(last_token_logits.float(), dim=1)
+        prev_context_length = context_length
+        yield tokens[:, : context_length + 1], lengths, output_log_probs
+        if (use_eod_token_for_early_termination and termination_id is not None
+                and bool((new_sample == termination_id).all())):
+            break

@@ -59,6 +59,7 @@ class GPTVLModel:
         # K/V all-gather messages per layer (split by kv head; gather j+1 overlaps attention j)
         self.kv_split = 4 if cfg.kv_groups % 4 == 0 else (2 if cfg.kv_groups % 2 == 0 else 1)
         self.force_cp_path = bool(int(os.environ.get("VITA_FORCE_CP", "0")))   # diagnostics only
+        self.decode_graph = bool(int(os.environ.get("VITA_DECODE_GRAPH", "0")))   # capture the token step (CP = 1)
         self.attn_events = None      # bench.py: list collecting (start, end) HIP events per attention launch
 
     # ---------------------------------------------------------------------------------------------
@@ -98,11 +99,13 @@ class GPTVLModel:
             e = lambda *shape: torch.empty(*shape, dtype=torch.bfloat16, device=device)  # noqa: E731
             ws = {"x": e(s, c.hidden), "qkv": e(s, c.qkv_out), "ctx": e(1, s, c.heads, c.head_dim),
                   "act": e(s, c.ffn), "kv": e(self.kv_split, 2, s, c.kv_groups // self.kv_split, c.head_dim)}
-            self._ws = {s: ws}          # keep one size only
+            self._ws = {k: v for k, v in self._ws.items() if k == "decode"}    # keep one prefill size only
+            self._ws[s] = ws
         return ws
 
-    def decoder_layer(self, h: torch.Tensor, lp: dict, cos, sin, ws) -> torch.Tensor:
-        """h [s, hidden] updated in place."""
+    def decoder_layer(self, h: torch.Tensor, lp: dict, cos, sin, ws, kv_dst: Optional[torch.Tensor] = None) -> torch.Tensor:
+        """h [s, hidden] updated in place.  kv_dst [2, cap, groups, d]: this rank's cache shard for the
+        layer; the rotated K and V rows of the local sequence are stored into rows [0, s)."""
         c = self.cfg
         s = h.shape[0]
         cp = mpu.get_context_parallel_world_size()
@@ -112,6 +115,12 @@ class GPTVLModel:
         ops.rope_qkv_(qkv, c.kv_groups, c.qpg, c.head_dim, cos, sin, ws["kv"] if use_cp else None, self.kv_split)
         m5 = qkv.view(1, s, c.kv_groups, c.qpg + 2, c.head_dim)
         q5 = m5[:, :, :, : c.qpg]                                  # grouped query view, read in place
+        if kv_dst is not None:
+            if use_cp:       # packed send buffer [split, 2, s, groups/split, d] -> [2, s, groups, d]
+                kv_dst[:, :s].view(2, s, self.kv_split, -1, c.head_dim).copy_(ws["kv"].permute(1, 2, 0, 3, 4))
+            else:
+                kv_dst[0, :s].copy_(m5[0, :, :, c.qpg])
+                kv_dst[1, :s].copy_(m5[0, :, :, c.qpg + 1])
         ev = None
         if self.attn_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -138,8 +147,18 @@ class GPTVLModel:
                 tokentype_ids=None, logit_mask: Optional[torch.Tensor] = None) -> torch.Tensor:
         """Returns logits [b, n_sel (or s), vocab] (labels=None branch, gpt_vl_model.py:357-370)."""
         if labels is not None:
-            raise NotImplementedError("loss / backward path is not built yet (SURVEY.md §7 step 6)")
+            raise NotImplementedError("the loss / backward path is long_vita_amd.training.TrainStep")
         assert packed_seq_params is None
+        ip = inference_params
+        if ip is not None:
+            if getattr(ip, "external_inputs", None) is not None and not ip.key_value_memory_dict:   # :261-266
+                external_inputs = ip.external_inputs
+            if getattr(ip, "logit_mask", None) is not None:                                          # :281-283
+                logit_mask = ip.logit_mask
+            if hasattr(ip, "use_kv_cache") and not ip.use_kv_cache:                                  # :285-286
+                ip = None
+        if ip is not None and ip.key_value_memory_dict:
+            return self._decode_forward(input_ids, position_ids, ip)
         if decoder_input is None:                                                         # :252-277
             if external_inputs:
                 feats = self.external_feature_model(**external_inputs)                   # :267
@@ -158,8 +177,12 @@ class GPTVLModel:
         rotary_seq_len = RotaryEmbedding.get_rotary_seq_len(s)                           # :289-293
         cos, sin = self.rotary_pos_emb(rotary_seq_len)                                   # :295
         ws = self._workspace(s, h.device)
-        for lp in self.p["layers"]:                                                       # self.decoder(...) :299
-            self.decoder_layer(h, lp, cos, sin, ws)
+        if ip is not None:
+            self._allocate_cache(ip, s, h.device)
+        for li, lp in enumerate(self.p["layers"]):                                        # self.decoder(...) :299
+            self.decoder_layer(h, lp, cos, sin, ws, None if ip is None else ip.key_value_memory_dict[li + 1])
+        if ip is not None:
+            self._compact_cache(ip, s)
         # final RMSNorm is per-row, so norm only the rows the masked head keeps
         if logit_mask is not None:
             idx = ops.mask_to_index(logit_mask.transpose(0, 1).reshape(-1))
@@ -174,3 +197,153 @@ class GPTVLModel:
         return logits.transpose(0, 1).contiguous()                                        # [s b v] -> [b s v] :370
 
     __call__ = forward
+
+    # ---------------------------------------------------------------------------------------------
+    # decode against the sharded KV cache (inference_params.py)
+    # ---------------------------------------------------------------------------------------------
+    def _allocate_cache(self, ip, s_local: int, device):
+        c = self.cfg
+        cp = mpu.get_context_parallel_world_size()
+        prompt = ip.prefill_valid_tokens if ip.prefill_valid_tokens is not None else s_local * cp
+        if prompt > s_local * cp:
+            raise ValueError("prefill_valid_tokens exceeds the tokens fed")
+        room = max(0, ip.max_sequence_length - prompt)
+        cap = s_local + -(-room // cp) + 1
+        buf = torch.empty(c.num_layers, 2, cap, c.kv_groups, c.head_dim, dtype=torch.bfloat16, device=device)
+        ip.key_value_memory_dict = {li + 1: buf[li] for li in range(c.num_layers)}    # Megatron keys by layer_number
+        ip.prefill_valid_tokens = prompt
+
+    def _compact_cache(self, ip, s_local: int):
+        """Drop the rows of padded prompt positions: keep rows whose global position < prefill_valid_tokens,
+        second zig-zag chunk moved up against the first."""
+        cp, r = mpu.get_context_parallel_world_size(), mpu.get_context_parallel_rank()
+        P = ip.prefill_valid_tokens
+        if cp == 1:
+            ip.local_len = P
+        else:
+            cl = s_local // 2
+            va = min(max(P - r * cl, 0), cl)
+            vb = min(max(P - (2 * cp - 1 - r) * cl, 0), cl)
+            if vb > 0 and va < cl:
+                for kv in ip.key_value_memory_dict.values():
+                    kv[:, va: va + vb].copy_(kv[:, cl: cl + vb].clone())
+            ip.local_len = va + vb
+        ip.decode_steps = 0
+        ip.consumed_tokens = P
+
+    def _decode_workspace(self, device):
+        ws = self._ws.get("decode")
+        if ws is None:
+            c = self.cfg
+            e = lambda *shape, dt=torch.bfloat16: torch.empty(*shape, dtype=dt, device=device)  # noqa: E731
+            cp = mpu.get_context_parallel_world_size()
+            msg = c.heads * c.head_dim + 2 * c.heads
+            ws = {"x": e(1, c.hidden), "qkv": e(1, c.qkv_out), "ctx": e(c.heads, c.head_dim), "act": e(c.ffn),
+                  "h": e(1, c.hidden), "msg": e(msg, dt=torch.float32), "gmsg": e(cp, msg, dt=torch.float32)}
+            self._ws["decode"] = ws
+        return ws
+
+    def _decode_token(self, token: torch.Tensor, position: torch.Tensor, ip, counters=None) -> torch.Tensor:
+        """One token through the 48 layers: token [1] int64, position [1] int64 -> final-normed hidden [1, hidden].
+        counters = (row_dev int64 [1], len_dev int32 [1]): the shard's row count lives on the device (the captured
+        graph of this function is replayed as the cache grows; CP = 1 only)."""
+        import torch.distributed as dist
+        c = self.cfg
+        cp, r = mpu.get_context_parallel_world_size(), mpu.get_context_parallel_rank()
+        ws = self._decode_workspace(token.device)
+        h = ops.row_gather(self.p["embed"], token.reshape(1), out=ws["h"], check_bounds=False)   # [1, hidden]
+        cos, sin = ops.rope_table(position.reshape(1), self.rotary_pos_emb.inv_freq)
+        owner = (ip.decode_steps % cp) == r
+        row = ip.local_len
+        length = row + (1 if owner else 0)
+        for li, lp in enumerate(self.p["layers"]):
+            kv = ip.key_value_memory_dict[li + 1]
+            if length > kv.shape[1]:
+                raise RuntimeError("KV cache shard is full (max_sequence_length reached)")
+            x = ops.rmsnorm(h, lp["ln1"], c.eps, out=ws["x"])
+            qkv = ops.gemv(x.view(-1), lp["qkv_w"], ops.EPI_BIAS, lp["qkv_b"], out=ws["qkv"].view(-1))
+            ops.rope_qkv_(ws["qkv"], c.kv_groups, c.qpg, c.head_dim, cos, sin, None, 1)
+            m4 = qkv.view(c.kv_groups, c.qpg + 2, c.head_dim)
+            if counters is not None:
+                kv[0].index_copy_(0, counters[0], m4[None, :, c.qpg])
+                kv[1].index_copy_(0, counters[0], m4[None, :, c.qpg + 1])
+                pm, pl, po = ops.decode_attn_partial(m4[:, : c.qpg], kv[0], kv[1], kv.shape[1], len_dev=counters[1])
+            else:
+                if owner:
+                    kv[0, row].copy_(m4[:, c.qpg])
+                    kv[1, row].copy_(m4[:, c.qpg + 1])
+                pm, pl, po = ops.decode_attn_partial(m4[:, : c.qpg], kv[0], kv[1], length)
+            if cp == 1:
+                ctx = ops.decode_attn_merge(pm, pl, po, True, out=ws["ctx"])
+            else:
+                ops.decode_attn_merge(pm, pl, po, False, packed_out=ws["msg"])
+                dist.all_gather_into_tensor(ws["gmsg"].view(-1), ws["msg"], group=mpu.get_context_parallel_group())
+                gm, gl, go = ops.unpack_partials(ws["gmsg"], c.heads, c.head_dim)
+                ctx = ops.decode_attn_merge(gm, gl, go, True, out=ws["ctx"])
+            ops.gemv(ctx.view(-1), lp["o_w"], ops.EPI_RESIDUAL, residual=h.view(-1), out=h.view(-1))
+            x = ops.rmsnorm(h, lp["ln2"], c.eps, out=ws["x"])
+            act = ops.gemv(x.view(-1), lp["fc1_w"], ops.EPI_SWIGLU, out=ws["act"])
+            ops.gemv(act, lp["fc2_w"], ops.EPI_RESIDUAL, residual=h.view(-1), out=h.view(-1))
+        if counters is not None:
+            counters[0].add_(1)
+            counters[1].add_(1)
+        else:
+            ip.local_len = length
+            ip.decode_steps += 1
+        return ops.rmsnorm(h, self.p["final_ln"], c.eps)
+
+    def _decode_graphed(self, token: torch.Tensor, position: torch.Tensor, ip) -> torch.Tensor:
+        """CP = 1: the ~450 launches of one token step are captured once per request into a HIP graph (the
+        launch-bound inner loop of decode) and replayed; token id, position and the cache row count are device
+        scalars.  Returns logits [1, vocab] (a static buffer, overwritten by the next step)."""
+        g = getattr(ip, "_graph", None)
+        if g is None:
+            dev = token.device
+            st = {"tok": torch.zeros(1, dtype=torch.int64, device=dev),
+                  "pos": torch.zeros(1, dtype=torch.int64, device=dev),
+                  "row": torch.full((1,), ip.local_len, dtype=torch.int64, device=dev),
+                  "len": torch.full((1,), ip.local_len + 1, dtype=torch.int32, device=dev)}
+
+            def body():
+                rows = self._decode_token(st["tok"], st["pos"], ip, counters=(st["row"], st["len"]))
+                return self.output_layer(rows.view(1, 1, -1), weight=None, logit_mask=None)[0].view(1, -1)
+
+            side = torch.cuda.Stream()
+            side.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(side):                       # warm-up outside capture, on throw-away counters
+                st["tok"].copy_(token.reshape(1)); st["pos"].copy_(position.reshape(1))
+                keep = (st["row"].clone(), st["len"].clone())
+                body()
+                st["row"].copy_(keep[0]); st["len"].copy_(keep[1])
+            torch.cuda.current_stream().wait_stream(side)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                st["out"] = body()
+            g = ip._graph = (graph, st)
+        graph, st = g
+        st["tok"].copy_(token.reshape(1))
+        st["pos"].copy_(position.reshape(1))
+        graph.replay()
+        ip.local_len += 1
+        ip.decode_steps += 1
+        return st["out"]
+
+    def _decode_forward(self, input_ids: torch.Tensor, position_ids: Optional[torch.Tensor], ip) -> torch.Tensor:
+        """tokens[:, prev:ctx] of the cached decode loop (generation.py:127-131): every CP rank is fed the same
+        (unsliced) tokens and returns the same logits [1, t, vocab]."""
+        b, t = input_ids.shape
+        if b != 1:
+            raise ValueError("the Long-VITA decode path runs batch 1")
+        if position_ids is None:
+            position_ids = (torch.arange(t, device=input_ids.device) + ip.sequence_len_offset)[None]
+        ip.consumed_tokens = t
+        if t == 1 and self.decode_graph and mpu.get_context_parallel_world_size() == 1:
+            kv = ip.key_value_memory_dict[1]
+            if ip.local_len + 1 > kv.shape[1]:
+                raise RuntimeError("KV cache shard is full (max_sequence_length reached)")
+            return self._decode_graphed(input_ids[0], position_ids[0], ip).view(1, 1, -1).clone()
+        ip._graph = None                      # eager steps move the python-side counters only
+        rows = [self._decode_token(input_ids[0, j: j + 1], position_ids[0, j: j + 1], ip) for j in range(t)]
+        rows = rows[0] if t == 1 else torch.cat(rows, dim=0)
+        logits, _ = self.output_layer(rows.view(t, 1, -1), weight=None, logit_mask=None)
+        return logits.transpose(0, 1).contiguous()

@@ -492,3 +492,91 @@ def flash_attn_bwd(q5, k, v, o, d_o, lse, *, chunk_len=None, q_chunk_gid=None, k
     p.softmax_scale = float(softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(D))
     _L.check(h.vita_flash_attn_bwd(C.byref(p), _stream()), "vita_flash_attn_bwd")
     return dq5, dk, dv
+
+
+# ------------------------------------------------------------------------------------------------
+# single-token decode against the sharded KV cache
+# ------------------------------------------------------------------------------------------------
+DECODE_KEYS_PER_TILE = 256
+DECODE_MAX_SPLITS = 128
+
+
+def gemv(x: torch.Tensor, w: torch.Tensor, epilogue: int = EPI_NONE, bias: Optional[torch.Tensor] = None,
+         residual: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """y[N] = epilogue(W[N,K] . x[K]) for one token; SWIGLU: W = cat[gate, up] rows, N = W.shape[0] / 2."""
+    K = x.numel()
+    n_rows = w.shape[0]
+    if w.shape[1] != K:
+        raise RuntimeError(f"supplied weight's shape is {tuple(w.shape)}, K = {K} expected")
+    N = n_rows // 2 if epilogue == EPI_SWIGLU else n_rows
+    y = torch.empty(N, dtype=BF16, device=x.device) if out is None else out
+    if y.numel() != N or not y.is_contiguous() or not x.is_contiguous():
+        raise ValueError("gemv needs contiguous x and out of N elements")
+    _L.check(_L.load().vita_gemv_bf16(_dev(x, "x", BF16), _dev(w, "w", BF16), w.stride(0), _dev(y, "out", BF16), N, K,
+                                      epilogue, _opt(bias, "bias", BF16), _opt(residual, "residual", BF16), _stream()),
+             "vita_gemv_bf16")
+    return y
+
+
+def decode_splits(length: int) -> int:
+    return max(1, min(DECODE_MAX_SPLITS, -(-length // DECODE_KEYS_PER_TILE)))
+
+
+def decode_attn_partial(q: torch.Tensor, k_cache: torch.Tensor, v_cache: torch.Tensor, length: int,
+                        softmax_scale: Optional[float] = None, len_dev: Optional[torch.Tensor] = None):
+    """q [groups, qpg, d] (any strides with unit inner stride), caches [cap, groups, d] views; attends to rows
+    [0, length) — or [0, min(length, len_dev[0])) with the count read on the device (int32 [1]; hipGraph replay:
+    pass length = capacity).  Returns the un-normalised partials (m [n, H], l [n, H], o [n, H, d]) fp32, log2
+    domain."""
+    G, qpg, d = q.shape
+    if k_cache.shape[1:] != (G, d) or v_cache.shape != k_cache.shape or q.stride(2) != 1 or k_cache.stride(2) != 1:
+        raise ValueError("decode_attn_partial: q [G, qpg, d], caches [cap, G, d]")
+    if k_cache.stride() != v_cache.stride() or length > k_cache.shape[0]:
+        raise ValueError("k/v cache views must share strides and hold `length` rows")
+    H = G * qpg
+    n = DECODE_MAX_SPLITS if len_dev is not None else decode_splits(length)
+    pm = torch.empty(n, H, dtype=torch.float32, device=q.device)
+    pl = torch.empty(n, H, dtype=torch.float32, device=q.device)
+    po = torch.empty(n, H, d, dtype=torch.float32, device=q.device)
+    if length == 0:
+        pm.fill_(float("-inf")); pl.zero_(); po.zero_()
+        return pm, pl, po
+    scale = 1.0 / math.sqrt(d) if softmax_scale is None else softmax_scale
+    _L.check(_L.load().vita_decode_attn_partial(_dev(q, "q", BF16), q.stride(0), q.stride(1), _dev(k_cache, "k", BF16),
+                                                _dev(v_cache, "v", BF16), k_cache.stride(0), k_cache.stride(1),
+                                                int(length), _opt(len_dev, "len_dev", torch.int32), n, G, qpg, d,
+                                                float(scale), _dev(pm, "pm"), _dev(pl, "pl"), _dev(po, "po"),
+                                                _stream()), "vita_decode_attn_partial")
+    return pm, pl, po
+
+
+def decode_attn_merge(pm: torch.Tensor, pl: torch.Tensor, po: torch.Tensor, final: bool,
+                      out: Optional[torch.Tensor] = None, packed_out: Optional[torch.Tensor] = None):
+    """Merge partials over dim 0 (parts may be strided on dim 0).  final: bf16 context [H, d]; else one merged
+    partial written into packed_out (fp32 [H*d + 2H]: o, then m, then l) — the message the CP ranks exchange."""
+    n, H, d = po.shape
+    for t_ in (pm, pl, po):
+        if t_.dtype != torch.float32 or t_.stride(-1) != 1:
+            raise ValueError("partials must be fp32 with unit inner stride")
+    if pm.stride(0) != pl.stride(0) or (n > 0 and po.stride(1) != d):
+        raise ValueError("partials: m and l must share the part stride, o rows must be dense")
+    L = _L.load()
+    if final:
+        ctx = torch.empty(H, d, dtype=BF16, device=po.device) if out is None else out
+        _L.check(L.vita_decode_attn_merge(_dev(pm, "pm"), _dev(pl, "pl"), _dev(po, "po"), n, pm.stride(0), po.stride(0),
+                                          H, d, None, None, None, _dev(ctx, "out", BF16), _stream()),
+                 "vita_decode_attn_merge")
+        return ctx
+    buf = torch.empty(H * d + 2 * H, dtype=torch.float32, device=po.device) if packed_out is None else packed_out
+    base = _dev(buf, "packed_out", torch.float32)
+    _L.check(L.vita_decode_attn_merge(_dev(pm, "pm"), _dev(pl, "pl"), _dev(po, "po"), n, pm.stride(0), po.stride(0),
+                                      H, d, base + 4 * H * d, base + 4 * (H * d + H), base, None, _stream()),
+             "vita_decode_attn_merge")
+    return buf
+
+
+def unpack_partials(gathered: torch.Tensor, heads: int, d: int):
+    """gathered [n, H*d + 2H] fp32 (decode_attn_merge packed messages) -> strided (m, l, o) views."""
+    n = gathered.shape[0]
+    o = gathered[:, : heads * d].view(n, heads, d)
+    return gathered[:, heads * d: heads * d + heads], gathered[:, heads * d + heads:], o
