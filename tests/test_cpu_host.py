@@ -19,7 +19,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     from long_vita_amd import lib
     lib.build()
     declared = set(re.findall(r"\b(vita_[a-z0-9_]+)\s*\(", open(lib.HEADER_PATH).read()))
-    declared -= {"vita_attn_params"}
+    declared -= {"vita_attn_params", "vita_attn_bwd_params"}
     assert declared == set(lib.PROTOTYPES), declared ^ set(lib.PROTOTYPES)
     handle = lib.load()                                  # resolves + type-annotates every symbol
     assert handle.vita_abi_version() == lib.ABI_VERSION
@@ -40,10 +40,12 @@ def test_product_path_has_no_cpu_fallback_and_does_not_import_oracle():
             assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), fn
 
 
-def test_attn_params_struct_matches_header_field_order():
+@pytest.mark.parametrize("struct", ["vita_attn_params", "vita_attn_bwd_params"])
+def test_attn_params_struct_matches_header_field_order(struct):
     from long_vita_amd import lib
     hdr = open(lib.HEADER_PATH).read()
-    body = hdr[hdr.index("typedef struct {"): hdr.index("} vita_attn_params;")]
+    end = hdr.index("} %s;" % struct)
+    body = hdr[hdr.rindex("typedef struct {", 0, end): end]
     body = re.sub(r"/\*.*?\*/", "", body, flags=re.S)
     names = []
     for decl in body.split(";"):
@@ -53,7 +55,8 @@ def test_attn_params_struct_matches_header_field_order():
         first, *rest = decl.split(",")
         names.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", first)[-1])
         names += [re.findall(r"[A-Za-z_][A-Za-z0-9_]*", r)[-1] for r in rest]
-    assert names == [f[0] for f in lib.AttnParams._fields_]
+    cls = lib.AttnParams if struct == "vita_attn_params" else lib.AttnBwdParams
+    assert names == [f[0] for f in cls._fields_]
 
 
 # ---------------------------------------------------------------------------------------------
@@ -208,3 +211,47 @@ def test_oracle_cp_prefill_equals_cp1():
     outs = ollm.prefill_logits_cp(tokens, p, cfg, cp, [range(S // cp)] * cp)
     for r in range(cp):
         torch.testing.assert_close(outs[r][0], glue.zigzag_slice(full[None], cp, r)[0], rtol=1e-4, atol=1e-4)
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("cp,chunk,P", [(2, 4, 16), (2, 4, 9), (2, 4, 3), (4, 2, 11), (4, 2, 16), (1, 8, 5)])
+def test_kv_cache_compaction_keeps_exactly_the_real_prompt_rows(cp, chunk, P):
+    """After a padded zig-zag prefill the shard keeps the rows whose global position is < P, in position order
+    (gpt_vl_model._compact_cache), and the shards of all ranks partition [0, P)."""
+    from long_vita_amd import parallel_state as mpu
+    from long_vita_amd.gpt_vl_model import GPTVLModel
+    from long_vita_amd.inference_params import InferenceParams
+    from oracle import glue
+    S = 2 * cp * chunk if cp > 1 else chunk
+    seen = []
+    try:
+        for r in range(cp):
+            mpu.set_context_parallel_state(cp, r, None)
+            pos = torch.arange(S)[None]
+            local = glue.zigzag_slice(pos, cp, r)[0] if cp > 1 else pos[0]
+            ip = InferenceParams(1, S + 4)
+            ip.prefill_valid_tokens = P
+            kv = torch.full((2, local.numel() + 3, 1, 1), -1.0)
+            kv[:, : local.numel(), 0, 0] = local.float()
+            ip.key_value_memory_dict = {1: kv}
+            GPTVLModel._compact_cache(object.__new__(GPTVLModel), ip, local.numel())
+            want = [int(x) for x in local if int(x) < P]
+            assert ip.local_len == len(want) and ip.consumed_tokens == P
+            assert kv[0, : ip.local_len, 0, 0].tolist() == want and kv[1, : ip.local_len, 0, 0].tolist() == want
+            seen += want
+    finally:
+        mpu.set_context_parallel_state(1, 0, None)
+    assert sorted(seen) == list(range(P))
+
+
+def test_decode_loop_host_rules():
+    from long_vita_amd import generation as gen
+    assert gen._cp_prefill_length(1500, 2) == 2048 and gen._cp_prefill_length(1024, 2) == 1024
+    assert gen._cp_prefill_length(131072, 8) == 131072 and gen._cp_prefill_length(131073, 8) == 131072 + 4096
+    logits = torch.tensor([[0.1, 3.0, -1.0, 2.9]])
+    assert gen._sample_strategy(logits)[1].tolist() == [1]
+    g = torch.manual_seed(0)                                                  # noqa: F841
+    picks = {int(gen._sample_strategy(logits, do_sample=True, top_k=2)[1]) for _ in range(50)}
+    assert picks <= {1, 3} and len(picks) == 2
+    picks = {int(gen._sample_strategy(logits, do_sample=True, top_p=0.3)[1]) for _ in range(20)}
+    assert picks == {1}                                                       # nucleus keeps the top token only
