@@ -56,13 +56,13 @@ __device__ __forceinline__ int tile_off(int row, int slot) {
 //   <256,256,2,4>: 8 waves, 128 KiB LDS, per-wave tile 128 x 64 -> 0.75 LDS fragment reads and
 //                  0.25 KiB of DMA per MFMA instead of 1.0 / 0.5 (the 128^2 tile is LDS-bound)
 template <int EPI, int BM, int BN, int WM, int WN, bool PIN = true>
-__global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(GemmArgs p) {
+__global__ __launch_bounds__(64 * WM * WN, (BM == 256 && WM * WN == 4) ? 1 : 2) void gemm_bf16_kernel(GemmArgs p) {
   constexpr int NW = WM * WN;
   constexpr int TM = BM / WM, TN = BN / WN;          // per-wave tile
   constexpr int MI = TM / 32, NI = TN / 32;          // 32x32 MFMA blocks per wave
   constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
   constexpr int QA = BM / 8 / NW, QW = BN / 8 / NW;  // 1-KiB DMA pieces per wave per operand
-  static_assert(EPI != VITA_EPI_SWIGLU || TN == 64, "SwiGLU epilogue pairs the two 32-column blocks of a wave");
+  static_assert(EPI != VITA_EPI_SWIGLU || NI % 2 == 0, "SwiGLU epilogue pairs 32-column blocks (gate, up) of a wave");
 
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
@@ -201,25 +201,28 @@ __global__ __launch_bounds__(64 * WM * WN, 2) void gemm_bf16_kernel(GemmArgs p) 
     const int64_t m = m0 + wm * TM + mi * 32 + (lane & 31);
     if (m >= p.M) continue;
     if (EPI == VITA_EPI_SWIGLU) {
-      // the wave's 64 tile rows of W = [gate 32 | up 32] for output columns n0 + wn*32 + 0..31
+      // the wave's tile rows of W = NI/2 x [gate 32 | up 32]; pair pi -> output columns n0 + (wn*NI/2 + pi)*32 + 0..31
 #pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int64_t n = n0 + wn * 32 + rg * 8 + hi * 4;
-        if (n >= p.N) continue;
-        float o[4];
+      for (int pi = 0; pi < NI / 2; ++pi) {
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const float g = bf16_round(acc[0][mi][rg * 4 + j]);
-          const float u = bf16_round(acc[NI - 1][mi][rg * 4 + j]);
-          const float s = bf16_round(g / (1.0f + __expf(-g)));
-          o[j] = s * u;
-        }
-        bf16_t* dst = p.C + m * p.ldc + n;
-        if (n + 3 < p.N) {
-          u32x2 v = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-          *reinterpret_cast<u32x2*>(dst) = v;
-        } else {
-          for (int j = 0; j < 4 && n + j < p.N; ++j) dst[j] = f32_to_bf16(o[j]);
+        for (int rg = 0; rg < 4; ++rg) {
+          const int64_t n = n0 + (wn * (NI / 2) + pi) * 32 + rg * 8 + hi * 4;
+          if (n >= p.N) continue;
+          float o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float g = bf16_round(acc[2 * pi][mi][rg * 4 + j]);
+            const float u = bf16_round(acc[2 * pi + 1][mi][rg * 4 + j]);
+            const float s = bf16_round(g / (1.0f + __expf(-g)));
+            o[j] = s * u;
+          }
+          bf16_t* dst = p.C + m * p.ldc + n;
+          if (n + 3 < p.N) {
+            u32x2 v = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+            *reinterpret_cast<u32x2*>(dst) = v;
+          } else {
+            for (int j = 0; j < 4 && n + j < p.N; ++j) dst[j] = f32_to_bf16(o[j]);
+          }
         }
       }
     } else {
@@ -359,6 +362,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
   if (gemm_tile_override() == 128) big = false;
   if (gemm_tile_override() == 256) big = true;
   static const bool nopin = getenv("VITA_GEMM_NOPIN") != nullptr;     // developer tuning aid
+  if (gemm_tile_override() == 2564) return launch_gemm_cfg<EPI, 256, 256, 2, 2>(a, st);   // 4 waves x (128 x 128)
   if (nopin) return big ? launch_gemm_cfg<EPI, 256, 256, 2, 4, false>(a, st) : launch_gemm_cfg<EPI, 128, 128, 2, 2, false>(a, st);
   return big ? launch_gemm_cfg<EPI, 256, 256, 2, 4>(a, st) : launch_gemm_cfg<EPI, 128, 128, 2, 2>(a, st);
 }
