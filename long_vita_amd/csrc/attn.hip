@@ -94,7 +94,8 @@ struct TileIt {
 //   bits 1-2 = QK_AHEAD: K-fragment reads pinned that many k-steps ahead of their MFMAs.
 // Measured and dropped: a 3-slot "staggered" schedule (waves 4..7 half a tile behind
 // waves 0..3): 0 to -3 %; s_setprio around the MFMA clusters: -2 %; a 4-wave x 64-row variant with
-// one wave per SIMD and compiler-allocated AGPRs: -19 %.
+// one wave per SIMD and compiler-allocated AGPRs: -19 %; an in-wave software-pipelined 4-wave x 32-row kernel
+// (exp of tile t between the MFMAs of tile t+1, 4-slot ring): -35 % (LDS-bound; see DESIGN.md 4.1, git history).
 template <int D, bool CAUSAL, int VARIANT = 0, bool TIMING = false>
 __global__ __launch_bounds__(512, 2) void flash_fwd_kernel(AttnArgs p) {
   constexpr int DS = D / 16;              // QK^T k-steps
@@ -455,661 +456,6 @@ __global__ __launch_bounds__(512, 2) void flash_fwd_kernel(AttnArgs p) {
   }
 }
 
-// =================================================================================================
-// flash_fwd2: d = 128, 4 waves x 64 query rows (one wave per SIMD, 512 registers), LDS-DMA staging.
-// Each wave carries TWO independent 32-row sub-tiles (a, b) that share every K / V^T fragment read
-// (half the LDS traffic per MFMA of the 8 x 32 kernel).  MFMA and VALU only overlap inside one
-// instruction stream on this hardware when they are interleaved at instruction granularity
-// (tools/hwprobe/: ~5 VALU slots per 32x32x16 MFMA are free; two waves on a SIMD barely overlap), so
-// the loop body is ordered to give every softmax an independent MFMA block to hide under:
-//     QK_a | QK_b + softmax_a | PV_a + softmax_b | PV_b
-// PIPE = 0 keeps the plain order (QK_a QK_b | softmax_a softmax_b | PV_a PV_b) for comparison.
-template <bool CAUSAL, int PIPE>
-__global__ __launch_bounds__(256, 1) void flash_fwd2_kernel(AttnArgs p) {
-  constexpr int D = 128, DS = 8, DB = 4, ROWB = 256, NW = 4;
-  constexpr int TILEB = KVT * ROWB, SLOTB = 2 * TILEB, SLOTS = 16;
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | V tile]
-  typedef __attribute__((address_space(3))) char lds_char;
-  typedef __attribute__((address_space(3))) const bf16x8 lds_bf16x8;
-  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5, l31 = lane & 31;
-
-  const int G = p.n_q_heads / p.n_kv_heads;
-  int bid = blockIdx.x;
-  const int kvh = bid % p.n_kv_heads; bid /= p.n_kv_heads;
-  const int hq = bid % G; bid /= G;
-  const int n_q_tiles = p.n_q_chunks * p.tiles_per_q_chunk;
-  const int qt_order = bid % n_q_tiles;
-  const int b = bid / n_q_tiles;
-  const int head = kvh * G + hq;
-  const int qc = p.q_order[qt_order / p.tiles_per_q_chunk];
-  const int qti = p.tiles_per_q_chunk - 1 - qt_order % p.tiles_per_q_chunk;
-  const int gq = p.q_gid[qc];
-  const int q_rows_in_chunk = (qc == p.n_q_chunks - 1) ? p.q_valid : p.chunk_len;
-  const int q_off_wg = qti * QTILE;
-  const int q_off = q_off_wg + wave * 64;            // this wave's first row inside the chunk
-  const int q_last_wg = min(q_off_wg + QTILE, q_rows_in_chunk) - 1;
-  const float scale_log2e = p.scale_log2e;
-  int my_q[2];
-  bool q_live[2];
-  bf16x8 qf[2][DS];
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    my_q[u] = q_off + 32 * u + l31;
-    q_live[u] = my_q[u] < q_rows_in_chunk;
-    const int64_t row = (int64_t)qc * p.chunk_len + (q_live[u] ? my_q[u] : q_rows_in_chunk - 1);
-    const bf16_t* qp = p.q + (int64_t)b * p.q_bs + row * p.q_rs + (int64_t)kvh * p.q_gs + (int64_t)hq * p.q_hs + hi * 8;
-#pragma unroll
-    for (int ds = 0; ds < DS; ++ds) qf[u][ds] = *reinterpret_cast<const bf16x8*>(qp + ds * 16);
-  }
-  unsigned koff[DS];
-#pragma unroll
-  for (int ds = 0; ds < DS; ++ds) koff[ds] = k_lds_off<D>(l31, 2 * ds + hi);
-  unsigned voff[DB];
-  {
-    const int g16 = lane >> 4, i16 = lane & 15;
-    const int key_l = 4 * (g16 >> 1) + (i16 >> 2);
-#pragma unroll
-    for (int db = 0; db < DB; ++db) {
-      const int col = 32 * db + 16 * (g16 & 1) + 4 * (i16 & 3);
-      voff[db] = TILEB + v_lds_off<D>(key_l, col >> 4, (col & 15) * 2);
-    }
-  }
-  f32x16 o_acc[2][DB];
-#pragma unroll
-  for (int u = 0; u < 2; ++u)
-#pragma unroll
-    for (int i = 0; i < DB; ++i)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o_acc[u][i][r] = 0.f;
-  float m_run[2] = {-1.0e30f, -1.0e30f}, l_run[2] = {0.f, 0.f};
-
-  const bf16_t* kbase = p.k + (int64_t)b * p.k_bs + (int64_t)kvh * p.k_hs;
-  const bf16_t* vbase = p.v + (int64_t)b * p.v_bs + (int64_t)kvh * p.v_hs;
-
-  auto enter_chunk = [&](TileIt& t) __attribute__((always_inline)) {
-    while (t.c < p.n_kv_chunks) {
-      t.rows = (t.c == p.n_kv_chunks - 1) ? p.kv_valid : p.chunk_len;
-      const int all = (t.rows + KVT - 1) / KVT;
-      const int gk = p.kv_gid[t.c];
-      t.diag = CAUSAL && gk == gq;
-      t.n = (!CAUSAL || gk < gq) ? all : (gk > gq ? 0 : min(all, q_last_wg / KVT + 1));
-      if (t.n > 0) { t.crow = p.kv_row[t.c]; t.j = 0; return; }
-      ++t.c;
-    }
-  };
-  auto advance = [&](TileIt& t) __attribute__((always_inline)) {
-    if (++t.j == t.n) { ++t.c; enter_chunk(t); }
-  };
-
-  constexpr int PIECES = TILEB / 1024 / NW;            // 4 wave-instructions per operand per wave
-  constexpr int RPP = 1024 / ROWB;
-  typedef __attribute__((address_space(1))) const void gvoid;
-  typedef __attribute__((address_space(3))) void lvoid;
-  unsigned dk_off[PIECES], dv_off[PIECES];
-  int d_row[PIECES], d_ks[PIECES], d_vs[PIECES];
-#pragma unroll
-  for (int q = 0; q < PIECES; ++q) {
-    const int row = (wave * PIECES + q) * RPP + lane / SLOTS;
-    const int ps = lane % SLOTS;
-    d_ks[q] = ps ^ (row & 15);
-    d_vs[q] = (((ps >> 1) ^ ((row & 3) << 1)) << 1) | (ps & 1);
-    d_row[q] = row;
-    dk_off[q] = (unsigned)(row * p.k_rs + d_ks[q] * 8);
-    dv_off[q] = (unsigned)(row * p.v_rs + d_vs[q] * 8);
-  }
-  auto dma_tile = [&](const TileIt& t, unsigned sl) __attribute__((always_inline)) {
-    const int64_t row0 = t.crow + (int64_t)t.j * KVT;
-    const bf16_t* kp = kbase + row0 * p.k_rs;
-    const bf16_t* vp = vbase + row0 * p.v_rs;
-    const int left = t.rows - t.j * KVT;
-    if (left >= KVT) {
-#pragma unroll
-      for (int q = 0; q < PIECES; ++q) {
-        const int piece = wave * PIECES + q;
-        __builtin_amdgcn_global_load_lds((gvoid*)(kp + dk_off[q]), (lvoid*)(uintptr_t)(sl + piece * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gvoid*)(vp + dv_off[q]), (lvoid*)(uintptr_t)(sl + TILEB + piece * 1024), 16, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < PIECES; ++q) {
-        const int piece = wave * PIECES + q;
-        const int row = d_row[q] < left ? d_row[q] : left - 1;
-        __builtin_amdgcn_global_load_lds((gvoid*)(kp + (int64_t)row * p.k_rs + d_ks[q] * 8),
-                                         (lvoid*)(uintptr_t)(sl + piece * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gvoid*)(vp + (int64_t)row * p.v_rs + d_vs[q] * 8),
-                                         (lvoid*)(uintptr_t)(sl + TILEB + piece * 1024), 16, 0, 0);
-      }
-    }
-  };
-
-  // ---- the pieces of one tile --------------------------------------------------------------------
-  f32x16 s0[2], s1[2];
-  bf16x8 ka[DS], kb[DS];
-  bf16x8 pf[2][4];
-  auto load_k = [&](unsigned sl) __attribute__((always_inline)) {
-#pragma unroll
-    for (int ds = 0; ds < DS; ++ds) {
-      const unsigned a = sl + koff[ds];
-      ka[ds] = *(lds_bf16x8*)(uintptr_t)(a);
-      kb[ds] = *(lds_bf16x8*)(uintptr_t)(a + 32 * ROWB);
-    }
-  };
-  auto qk = [&](int u) __attribute__((always_inline)) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { s0[u][r] = 0.f; s1[u][r] = 0.f; }
-#pragma unroll
-    for (int ds = 0; ds < DS; ++ds) {
-      s0[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ds], qf[u][ds], s0[u], 0, 0, 0);
-      s1[u] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[ds], qf[u][ds], s1[u], 0, 0, 0);
-    }
-  };
-  auto softmax = [&](int u, int kv_off, bool diag, int kv_rows) __attribute__((always_inline)) {
-    const bool need_mask = (diag && kv_off + KVT - 1 > q_off + 32 * u) || (kv_off + KVT > kv_rows);
-    if (need_mask) {
-      const int lim_c = diag ? (my_q[u] - kv_off) : 0x7fffffff;
-      const int lim = min(lim_c, kv_rows - kv_off - 1);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (key > lim) s0[u][r] = -INFINITY;
-        if (key + 32 > lim) s1[u][r] = -INFINITY;
-      }
-    }
-    float mx = fmaxf(s0[u][0], s1[u][0]);
-#pragma unroll
-    for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(s0[u][r], s1[u][r]), mx);
-    mx = swap32_max(mx);
-    const float m_new = fmaxf(m_run[u], mx * scale_log2e);
-    const float alpha = __builtin_amdgcn_exp2f(m_run[u] - m_new);
-    m_run[u] = m_new;
-    float psum = 0.f;
-#pragma unroll
-    for (int r = 0; r < 16; ++r) {
-      s0[u][r] = __builtin_amdgcn_exp2f(fmaf(s0[u][r], scale_log2e, -m_new));
-      s1[u][r] = __builtin_amdgcn_exp2f(fmaf(s1[u][r], scale_log2e, -m_new));
-      psum += s0[u][r] + s1[u][r];
-    }
-    l_run[u] = l_run[u] * alpha + psum;
-    if (!__all(alpha == 1.0f)) {
-#pragma unroll
-      for (int i = 0; i < DB; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o_acc[u][i][r] *= alpha;
-    }
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      pf[u][0][j] = (__bf16)s0[u][j];
-      pf[u][1][j] = (__bf16)s0[u][8 + j];
-      pf[u][2][j] = (__bf16)s1[u][j];
-      pf[u][3][j] = (__bf16)s1[u][8 + j];
-    }
-  };
-  typedef __attribute__((ext_vector_type(8))) short s16x8;
-  bf16x8 vf[4][DB];
-  auto load_v = [&](unsigned sl) __attribute__((always_inline)) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int db = 0; db < DB; ++db) {
-        const unsigned vp = sl + voff[db] + 16 * t * ROWB;
-        const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(vp));
-        const s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(vp + 8 * ROWB));
-        vf[t][db] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, c, 0, 1, 2, 3, 4, 5, 6, 7));
-      }
-  };
-  auto pv = [&](int u) __attribute__((always_inline)) {
-#pragma unroll
-    for (int t = 0; t < 4; ++t)
-#pragma unroll
-      for (int db = 0; db < DB; ++db)
-        o_acc[u][db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[t][db], pf[u][t], o_acc[u][db], 0, 0, 0);
-  };
-
-  TileIt cur;
-  cur.c = 0; cur.j = 0; cur.n = 0; cur.rows = 0; cur.diag = 0; cur.crow = 0;
-  enter_chunk(cur);
-  TileIt nx1 = cur;
-  if (cur.c < p.n_kv_chunks) {
-    dma_tile(cur, lds0);
-    advance(nx1);
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-
-  int slot = 0;
-  while (cur.c < p.n_kv_chunks) {
-    const bool has_n1 = nx1.c < p.n_kv_chunks;
-    TileIt nx2 = nx1;
-    if (has_n1) {
-      dma_tile(nx1, lds0 + (slot ^ 1) * SLOTB);
-      advance(nx2);
-    }
-    const unsigned sl = lds0 + slot * SLOTB;
-    const int kv_off = cur.j * KVT;
-    const bool skip = cur.diag && kv_off > q_off + 63;   // the whole tile lies after this wave's last row
-    if (!skip) {
-      load_k(sl);
-      if (PIPE == 0) {
-        qk(0); qk(1);
-        softmax(0, kv_off, cur.diag, cur.rows);
-        softmax(1, kv_off, cur.diag, cur.rows);
-        load_v(sl);
-        pv(0); pv(1);
-      } else {
-        qk(0);
-        qk(1);
-        softmax(0, kv_off, cur.diag, cur.rows);       // independent of qk(1): interleaves with its MFMAs
-        load_v(sl);
-        pv(0);
-        softmax(1, kv_off, cur.diag, cur.rows);       // independent of pv(0)
-        pv(1);
-      }
-    }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    slot ^= 1;
-    cur = nx1;
-    nx1 = nx2;
-  }
-
-#pragma unroll
-  for (int u = 0; u < 2; ++u) {
-    const float l_tot = swap32_sum(l_run[u]);
-    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-    if (q_live[u]) {
-      const int64_t orow = (int64_t)qc * p.chunk_len + my_q[u];
-      bf16_t* op = p.o + (int64_t)b * p.o_bs + orow * p.o_rs + (int64_t)kvh * p.o_gs + (int64_t)hq * p.o_hs;
-#pragma unroll
-      for (int db = 0; db < DB; ++db) {
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const int d = 32 * db + 8 * rg + 4 * hi;
-          u32x2 w = {pack_bf16x2(o_acc[u][db][rg * 4 + 0] * inv, o_acc[u][db][rg * 4 + 1] * inv),
-                     pack_bf16x2(o_acc[u][db][rg * 4 + 2] * inv, o_acc[u][db][rg * 4 + 3] * inv)};
-          *reinterpret_cast<u32x2*>(op + d) = w;
-        }
-      }
-      if (p.lse && hi == 0) {
-        const float lse = l_tot > 0.f ? (m_run[u] + log2f(l_tot)) * 0.69314718055994530942f : -INFINITY;
-        p.lse[((int64_t)b * p.n_q_heads + head) * p.n_q_rows + orow] = lse;
-      }
-    }
-  }
-}
-
-// =================================================================================================
-// flash_fwd3: d = 128, 4 waves x 32 query rows (128-row query tile), one wave per SIMD so each wave
-// has 512 registers, 4-slot LDS ring
-// (tile t+3 is in flight while tiles t and t+1 are read, so no DMA is ever waited for in the step that issued it).  The tile loop is software-pipelined inside the wave:
-//     block A (VALU only): mask (rare), row max of S(t), alpha, rare O rescale
-//     block B (branch-free): exp / row sum / bf16 pack of S(t)  ||  QK^T of tile t+1 -> S(t+1)
-//                            then V^T fragments + P.V of tile t
-// so the softmax VALU work of tile t issues between the MFMAs of tile t+1 (tools/hwprobe/ shows that
-// is the only way VALU and MFMA overlap on this hardware).  The loop is unrolled by two so the two
-// S^T register sets swap roles without copies.
-constexpr int QTILE3 = 128;
-
-template <bool CAUSAL>
-__global__ __launch_bounds__(256, 1) void flash_fwd3_kernel(AttnArgs p) {
-  constexpr int D = 128, DS = 8, DB = 4, ROWB = 256, NW = 4;
-  constexpr int TILEB = KVT * ROWB, SLOTB = 2 * TILEB, SLOTS = 16, NSLOT = 4;
-  extern __shared__ __attribute__((aligned(16))) char smem[];  // [4][K tile | V tile]
-  typedef __attribute__((address_space(3))) char lds_char;
-  typedef __attribute__((address_space(3))) const bf16x8 lds_bf16x8;
-  typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
-  const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int hi = lane >> 5, l31 = lane & 31;
-
-  const int G = p.n_q_heads / p.n_kv_heads;
-  int bid = blockIdx.x;
-  const int kvh = bid % p.n_kv_heads; bid /= p.n_kv_heads;
-  const int hq = bid % G; bid /= G;
-  const int n_q_tiles = p.n_q_chunks * p.tiles_per_q_chunk;
-  const int qt_order = bid % n_q_tiles;
-  const int b = bid / n_q_tiles;
-  const int head = kvh * G + hq;
-  const int qc = p.q_order[qt_order / p.tiles_per_q_chunk];
-  const int qti = p.tiles_per_q_chunk - 1 - qt_order % p.tiles_per_q_chunk;
-  const int gq = p.q_gid[qc];
-  const int q_rows_in_chunk = (qc == p.n_q_chunks - 1) ? p.q_valid : p.chunk_len;
-  const int q_off_wg = qti * QTILE3;
-  const int q_off = q_off_wg + wave * 32;
-  const int my_q = q_off + l31;
-  const bool q_live = my_q < q_rows_in_chunk;
-  const int64_t q_local_row = (int64_t)qc * p.chunk_len + (q_live ? my_q : q_rows_in_chunk - 1);
-  const int q_last_wg = min(q_off_wg + QTILE3, q_rows_in_chunk) - 1;
-  const float scale_log2e = p.scale_log2e;
-
-  bf16x8 qf[DS];
-  {
-    const bf16_t* qp = p.q + (int64_t)b * p.q_bs + q_local_row * p.q_rs + (int64_t)kvh * p.q_gs + (int64_t)hq * p.q_hs + hi * 8;
-#pragma unroll
-    for (int ds = 0; ds < DS; ++ds) qf[ds] = *reinterpret_cast<const bf16x8*>(qp + ds * 16);
-  }
-  unsigned koff[DS];
-#pragma unroll
-  for (int ds = 0; ds < DS; ++ds) koff[ds] = k_lds_off<D>(l31, 2 * ds + hi);
-  unsigned voff[DB];
-  {
-    const int g16 = lane >> 4, i16 = lane & 15;
-    const int key_l = 4 * (g16 >> 1) + (i16 >> 2);
-#pragma unroll
-    for (int db = 0; db < DB; ++db) {
-      const int col = 32 * db + 16 * (g16 & 1) + 4 * (i16 & 3);
-      voff[db] = TILEB + v_lds_off<D>(key_l, col >> 4, (col & 15) * 2);
-    }
-  }
-  f32x16 o_acc[DB];
-#pragma unroll
-  for (int i = 0; i < DB; ++i)
-#pragma unroll
-    for (int r = 0; r < 16; ++r) o_acc[i][r] = 0.f;
-  float m_run = -1.0e30f, l_run = 0.f;
-
-  const bf16_t* kbase = p.k + (int64_t)b * p.k_bs + (int64_t)kvh * p.k_hs;
-  const bf16_t* vbase = p.v + (int64_t)b * p.v_bs + (int64_t)kvh * p.v_hs;
-
-  auto enter_chunk = [&](TileIt& t) __attribute__((always_inline)) {
-    while (t.c < p.n_kv_chunks) {
-      t.rows = (t.c == p.n_kv_chunks - 1) ? p.kv_valid : p.chunk_len;
-      const int all = (t.rows + KVT - 1) / KVT;
-      const int gk = p.kv_gid[t.c];
-      t.diag = CAUSAL && gk == gq;
-      t.n = (!CAUSAL || gk < gq) ? all : (gk > gq ? 0 : min(all, q_last_wg / KVT + 1));
-      if (t.n > 0) { t.crow = p.kv_row[t.c]; t.j = 0; return; }
-      ++t.c;
-    }
-  };
-  auto advance = [&](TileIt& t) __attribute__((always_inline)) {
-    if (++t.j == t.n) { ++t.c; enter_chunk(t); }
-  };
-
-  constexpr int PIECES = TILEB / 1024 / NW;
-  constexpr int RPP = 1024 / ROWB;
-  typedef __attribute__((address_space(1))) const void gvoid;
-  typedef __attribute__((address_space(3))) void lvoid;
-  unsigned dk_off[PIECES], dv_off[PIECES];
-  int d_row[PIECES], d_ks[PIECES], d_vs[PIECES];
-#pragma unroll
-  for (int q = 0; q < PIECES; ++q) {
-    const int row = (wave * PIECES + q) * RPP + lane / SLOTS;
-    const int ps = lane % SLOTS;
-    d_ks[q] = ps ^ (row & 15);
-    d_vs[q] = (((ps >> 1) ^ ((row & 3) << 1)) << 1) | (ps & 1);
-    d_row[q] = row;
-    dk_off[q] = (unsigned)(row * p.k_rs + d_ks[q] * 8);
-    dv_off[q] = (unsigned)(row * p.v_rs + d_vs[q] * 8);
-  }
-  auto dma_tile = [&](const TileIt& t, unsigned sl) __attribute__((always_inline)) {
-    const int64_t row0 = t.crow + (int64_t)t.j * KVT;
-    const bf16_t* kp = kbase + row0 * p.k_rs;
-    const bf16_t* vp = vbase + row0 * p.v_rs;
-    const int left = t.rows - t.j * KVT;
-    if (left >= KVT) {
-#pragma unroll
-      for (int q = 0; q < PIECES; ++q) {
-        const int piece = wave * PIECES + q;
-        __builtin_amdgcn_global_load_lds((gvoid*)(kp + dk_off[q]), (lvoid*)(uintptr_t)(sl + piece * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gvoid*)(vp + dv_off[q]), (lvoid*)(uintptr_t)(sl + TILEB + piece * 1024), 16, 0, 0);
-      }
-    } else {
-#pragma unroll
-      for (int q = 0; q < PIECES; ++q) {
-        const int piece = wave * PIECES + q;
-        const int row = d_row[q] < left ? d_row[q] : left - 1;
-        __builtin_amdgcn_global_load_lds((gvoid*)(kp + (int64_t)row * p.k_rs + d_ks[q] * 8),
-                                         (lvoid*)(uintptr_t)(sl + piece * 1024), 16, 0, 0);
-        __builtin_amdgcn_global_load_lds((gvoid*)(vp + (int64_t)row * p.v_rs + d_vs[q] * 8),
-                                         (lvoid*)(uintptr_t)(sl + TILEB + piece * 1024), 16, 0, 0);
-      }
-    }
-  };
-
-  typedef __attribute__((ext_vector_type(8))) short s16x8;
-  // S^T(t+1) = K(t+1) Q^T from LDS slot `sl`
-  auto qk_into = [&](f32x16& a0, f32x16& a1, unsigned sl) __attribute__((always_inline)) {
-#pragma unroll
-    for (int r = 0; r < 16; ++r) { a0[r] = 0.f; a1[r] = 0.f; }
-#pragma unroll
-    for (int ds = 0; ds < DS; ++ds) {
-      const unsigned a = sl + koff[ds];
-      const bf16x8 ka = *(lds_bf16x8*)(uintptr_t)(a);
-      const bf16x8 kb = *(lds_bf16x8*)(uintptr_t)(a + 32 * ROWB);
-      a0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ds], a0, 0, 0, 0);
-      a1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb, qf[ds], a1, 0, 0, 0);
-    }
-  };
-  // block A (VALU, with the two rare branches): mask S(t) if the tile needs it, finish the row max (mx = in-lane
-  // max of S(t), already computed under the previous tile's P.V unless masked), alpha, O rescale when the max moved.
-  auto block_a = [&](f32x16& a0, f32x16& a1, float mx, const TileIt& t) __attribute__((always_inline)) -> float {
-    const int kv_off = t.j * KVT;
-    const bool need_mask = (t.diag && kv_off + KVT - 1 > q_off) || (kv_off + KVT > t.rows);
-    if (need_mask) {
-      const int lim_c = t.diag ? (my_q - kv_off) : 0x7fffffff;
-      const int lim = min(lim_c, t.rows - kv_off - 1);
-#pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        const int key = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (key > lim) a0[r] = -INFINITY;
-        if (key + 32 > lim) a1[r] = -INFINITY;
-      }
-      mx = fmaxf(a0[0], a1[0]);
-#pragma unroll
-      for (int r = 1; r < 16; ++r) mx = fmaxf(fmaxf(a0[r], a1[r]), mx);
-    }
-    mx = swap32_max(mx);
-    const float m_new = fmaxf(m_run, mx * scale_log2e);
-    const float alpha = __builtin_amdgcn_exp2f(m_run - m_new);
-    m_run = m_new;
-    l_run *= alpha;
-    if (!__all(alpha == 1.0f)) {
-#pragma unroll
-      for (int i = 0; i < DB; ++i)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) o_acc[i][r] *= alpha;
-    }
-    return m_new;
-  };
-  // block B (branch-free).  Phase 1: S(t+1) = K(t+1) Q^T, two MFMAs per k-step, with fma + exp of four S(t)
-  // elements behind each pair.  Phase 2: O += V^T(t) P(t), with the row-sum adds, the bf16 packs and the in-lane
-  // max of S(t+1) spread behind its MFMAs.  Returns the in-lane max of S(t+1).
-  constexpr int KAHEAD = 3;      // K fragment pairs read ahead of their MFMAs (phase 1)
-  constexpr int VAHEAD = 4;      // V^T fragments read ahead of their MFMAs (phase 2); the first ones issue in phase 1
-  auto read_v = [&](unsigned sl_cur, int i) __attribute__((always_inline)) -> bf16x8 {
-    const int t = i >> 2, db = i & 3;
-    const unsigned vp = sl_cur + voff[db] + 16 * t * ROWB;
-    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(vp));
-    const s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(vp + 8 * ROWB));
-    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, c, 0, 1, 2, 3, 4, 5, 6, 7));
-  };
-  auto block_b = [&](f32x16& c0, f32x16& c1, float m_new, unsigned sl_cur, f32x16& n0, f32x16& n1, unsigned sl_next,
-                     auto has_next) __attribute__((always_inline)) -> float {
-    constexpr bool NEXT = decltype(has_next)::value;
-    bf16x8 ka[DS], kb[DS], vfr[16];
-    if (NEXT) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) { n0[r] = 0.f; n1[r] = 0.f; }
-#pragma unroll
-      for (int ds = 0; ds < KAHEAD; ++ds) {
-        ka[ds] = *(lds_bf16x8*)(uintptr_t)(sl_next + koff[ds]);
-        kb[ds] = *(lds_bf16x8*)(uintptr_t)(sl_next + koff[ds] + 32 * ROWB);
-      }
-    }
-#pragma unroll
-    for (int ds = 0; ds < DS; ++ds) {
-      if (NEXT) {
-        n0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka[ds], qf[ds], n0, 0, 0, 0);
-        n1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kb[ds], qf[ds], n1, 0, 0, 0);
-        if (ds + KAHEAD < DS) {
-          ka[ds + KAHEAD] = *(lds_bf16x8*)(uintptr_t)(sl_next + koff[ds + KAHEAD]);
-          kb[ds + KAHEAD] = *(lds_bf16x8*)(uintptr_t)(sl_next + koff[ds + KAHEAD] + 32 * ROWB);
-        }
-      }
-      if (ds >= DS - VAHEAD) vfr[ds - (DS - VAHEAD)] = read_v(sl_cur, ds - (DS - VAHEAD));
-      // elements in the order the P^T operands need them: c0[0..7], c0[8..15] (2 per k-step), same for c1
-#pragma unroll
-      for (int e = 0; e < 2; ++e) {
-        c0[2 * ds + e] = __builtin_amdgcn_exp2f(fmaf(c0[2 * ds + e], scale_log2e, -m_new));
-        c1[2 * ds + e] = __builtin_amdgcn_exp2f(fmaf(c1[2 * ds + e], scale_log2e, -m_new));
-      }
-    }
-    if (NEXT) {
-      // pin: [K reads AHEAD] then per k-step: MFMA, 4 VALU, MFMA, LDS reads (2 K or 2 V), 4 VALU
-      __builtin_amdgcn_sched_group_barrier(0x100, 2 * KAHEAD, 0);
-#pragma unroll
-      for (int ds = 0; ds < DS; ++ds) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (ds + KAHEAD < DS) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        if (ds >= DS - VAHEAD) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-      }
-    }
-    // phase 2
-    bf16x8 pf[4];
-    float psum = 0.f, mxn = -INFINITY;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) pf[0][j] = (__bf16)c0[j];
-#pragma unroll
-    for (int i = 0; i < 16; ++i) {
-      const int t = i >> 2, db = i & 3;
-      f32x16& cs = t < 2 ? c0 : c1;
-      const int base = (t & 1) * 8;
-      o_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vfr[i], pf[t], o_acc[db], 0, 0, 0);
-      if (i + VAHEAD < 16) vfr[i + VAHEAD] = read_v(sl_cur, i + VAHEAD);
-      // behind every MFMA: 2 row-sum adds, one max3 of the next tile, and a quarter of the next P^T pack
-      psum += cs[base + 2 * db] + cs[base + 2 * db + 1];
-      if (NEXT) mxn = fmaxf(fmaxf(n0[i], n1[i]), mxn);
-      if (t < 3) {
-        f32x16& cn = (t + 1) < 2 ? c0 : c1;
-        const int bn = ((t + 1) & 1) * 8;
-        pf[t + 1][2 * db] = (__bf16)cn[bn + 2 * db];
-        pf[t + 1][2 * db + 1] = (__bf16)cn[bn + 2 * db + 1];
-      }
-    }
-    if (NEXT) {
-      __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);          // pack of pf[0]
-#pragma unroll
-      for (int i = 0; i < 16; ++i) {
-        __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
-        if (i + VAHEAD < 16) __builtin_amdgcn_sched_group_barrier(0x100, 2, 0);
-        if (i < 12) __builtin_amdgcn_sched_group_barrier(0x002, 4, 0);
-        else __builtin_amdgcn_sched_group_barrier(0x002, 3, 0);
-      }
-    }
-    l_run += psum;
-    return mxn;
-  };
-
-  // ---- prologue: tiles 0, 1, 2 -> slots 0, 1, 2 (tile t+3 is issued at the top of step t); S(0) ------------
-  TileIt cur;
-  cur.c = 0; cur.j = 0; cur.n = 0; cur.rows = 0; cur.diag = 0; cur.crow = 0;
-  enter_chunk(cur);
-  TileIt nx1 = cur, nx2 = cur, nx3 = cur;
-  f32x16 sa0, sa1, sb0, sb1;
-  if (cur.c < p.n_kv_chunks) {
-    dma_tile(cur, lds0);
-    advance(nx1);
-    nx2 = nx1;
-    if (nx1.c < p.n_kv_chunks) { dma_tile(nx1, lds0 + SLOTB); advance(nx2); }
-    nx3 = nx2;
-    if (nx2.c < p.n_kv_chunks) { dma_tile(nx2, lds0 + 2 * SLOTB); advance(nx3); }
-  }
-  // tiles 0 and 1 must have landed; tile 2 (the newest 2*PIECES DMA instructions) may still be in flight
-  if (nx2.c < p.n_kv_chunks) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
-  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  float mx_cur = -INFINITY;
-  if (cur.c < p.n_kv_chunks) {
-    qk_into(sa0, sa1, lds0);
-    mx_cur = fmaxf(sa0[0], sa1[0]);
-#pragma unroll
-    for (int r = 1; r < 16; ++r) mx_cur = fmaxf(fmaxf(sa0[r], sa1[r]), mx_cur);
-  }
-
-  // one pipelined step: tile `cur` (S in c0/c1, slot sc) -> S of tile nx1 into n0/n1 (slot sc+1); DMA tile nx3 -> slot sc+3
-  auto step = [&](f32x16& c0, f32x16& c1, f32x16& n0, f32x16& n1, int sc) __attribute__((always_inline)) {
-    const int sn = (sc + 1) & 3;
-    const int sd = (sc + 3) & 3;
-    const bool has_n1 = nx1.c < p.n_kv_chunks;
-    const bool issue = nx3.c < p.n_kv_chunks;
-    TileIt nx4 = nx3;
-    if (issue) { dma_tile(nx3, lds0 + sd * SLOTB); advance(nx4); }
-    const float m_new = block_a(c0, c1, mx_cur, cur);
-    if (has_n1) mx_cur = block_b(c0, c1, m_new, lds0 + sc * SLOTB, n0, n1, lds0 + sn * SLOTB, std::true_type{});
-    else mx_cur = block_b(c0, c1, m_new, lds0 + sc * SLOTB, n0, n1, 0u, std::false_type{});
-    // next step reads tiles t+1 (V) and t+2 (K): everything but the DMA issued in THIS step must have landed
-    if (issue) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * PIECES) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
-    cur = nx1; nx1 = nx2; nx2 = nx3; nx3 = nx4;
-    return sn;
-  };
-  int slot = 0;
-  while (cur.c < p.n_kv_chunks) {
-    slot = step(sa0, sa1, sb0, sb1, slot);
-    if (cur.c >= p.n_kv_chunks) break;
-    slot = step(sb0, sb1, sa0, sa1, slot);
-  }
-
-  const float l_tot = swap32_sum(l_run);
-  const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
-  if (q_live) {
-    const int64_t orow = (int64_t)qc * p.chunk_len + my_q;
-    bf16_t* op = p.o + (int64_t)b * p.o_bs + orow * p.o_rs + (int64_t)kvh * p.o_gs + (int64_t)hq * p.o_hs;
-#pragma unroll
-    for (int db = 0; db < DB; ++db) {
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int d = 32 * db + 8 * rg + 4 * hi;
-        u32x2 w = {pack_bf16x2(o_acc[db][rg * 4 + 0] * inv, o_acc[db][rg * 4 + 1] * inv),
-                   pack_bf16x2(o_acc[db][rg * 4 + 2] * inv, o_acc[db][rg * 4 + 3] * inv)};
-        *reinterpret_cast<u32x2*>(op + d) = w;
-      }
-    }
-    if (p.lse && hi == 0) {
-      const float lse = l_tot > 0.f ? (m_run + log2f(l_tot)) * 0.69314718055994530942f : -INFINITY;
-      p.lse[((int64_t)b * p.n_q_heads + head) * p.n_q_rows + orow] = lse;
-    }
-  }
-}
-
-template <bool CAUSAL>
-int launch_attn3(AttnArgs a, hipStream_t st) {
-  constexpr int lds = 4 * 2 * KVT * 128 * 2;
-  a.tiles_per_q_chunk = (a.chunk_len + QTILE3 - 1) / QTILE3;
-  const int64_t nblocks = (int64_t)a.batch * a.n_q_heads * a.n_q_chunks * a.tiles_per_q_chunk;
-  if (nblocks > 0x7fffffff) return VITA_ERR_UNSUPPORTED;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd3_kernel<CAUSAL>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((flash_fwd3_kernel<CAUSAL>), dim3((unsigned)nblocks), dim3(256), lds, st, a);
-  return vita_check_launch();
-}
-
-template <bool CAUSAL, int PIPE>
-int launch_attn2(const AttnArgs& a, int64_t nblocks, hipStream_t st) {
-  constexpr int lds = 2 * 2 * KVT * 128 * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd2_kernel<CAUSAL, PIPE>),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((flash_fwd2_kernel<CAUSAL, PIPE>), dim3((unsigned)nblocks), dim3(256), lds, st, a);
-  return vita_check_launch();
-}
-
 template <int D, bool CAUSAL, int VARIANT, bool TIMING = false>
 int launch_attn_v(const AttnArgs& a, int64_t nblocks, hipStream_t st) {
   constexpr int lds = 2 * 2 * KVT * D * 2;
@@ -1136,9 +482,6 @@ inline int attn_variant() {
 template <int D, bool CAUSAL>
 int launch_attn(const AttnArgs& a, int64_t nblocks, hipStream_t st) {
   const int v = attn_variant();
-  if ((v & 128) && D == 128) return launch_attn3<CAUSAL>(a, st);
-  if ((v & 32) && D == 128)
-    return (v & 64) ? launch_attn2<CAUSAL, 1>(a, nblocks, st) : launch_attn2<CAUSAL, 0>(a, nblocks, st);
   if ((v & 16) && D == 128 && CAUSAL) {
     switch (v & 15) {
       case 1: return launch_attn_v<128, true, 1, true>(a, nblocks, st);
