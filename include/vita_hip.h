@@ -323,6 +323,23 @@ int vita_decode_attn_merge(const void* part_m, const void* part_l, const void* p
                            int64_t part_ml_stride, int64_t part_o_stride, int heads, int head_dim, void* out_m, void* out_l, void* out_o,
                            void* out_bf16, void* stream);
 
+/* ---------------------------------------------------------------------------------------------
+ * Frame preprocessing — ImageProcessor.process_images,
+ * H/data/processor/image_processor.py:180-223, then the bf16 cast of M/tasks/inference/module.py:693:
+ * frames [n][height][width][3] uint8 RGB (frame_stride bytes apart) -> expand2square with pad_rgb
+ * (:189-201) -> Pillow BICUBIC resize to out_size x out_size (:206-208; 22-bit fixed-point separable
+ * passes with a uint8 intermediate, bit-exact) -> (x * 1.0 / 255.0 - mean) / std in float32 (:210-215)
+ * -> images [n][3][out_size][out_size] bf16.
+ * bounds [out_size][2] int32 (first tap, tap count) and coeffs [out_size][ksize] int32 are Pillow's
+ * precompute_coeffs / normalize_coeffs_8bpc tables for max(height, width) -> out_size (the padded
+ * image is square, so one table serves both passes); pad_rgb, mean, std_ are HOST arrays of 3.
+ * tmp: device scratch of n * max(height, width) * out_size * 3 bytes; u8_out (optional): the uint8
+ * resize result [n][out_size][out_size][3]. */
+int vita_frames_resize_norm(const void* frames, int64_t frame_stride, int n, int height, int width,
+                            int out_size, const int* pad_rgb, const void* bounds, const void* coeffs,
+                            int ksize, const float* mean, const float* std_, void* tmp, void* images,
+                            void* u8_out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

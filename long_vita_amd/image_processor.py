@@ -1,0 +1,140 @@
+"""ImageProcessor — mirror of H/data/processor/image_processor.py (process_images :180-223, the per-frame
+hot loop of process_video :136-178) with the arithmetic on the GPU.
+
+The reference pads each frame to a square, resizes it with Pillow (BICUBIC) and normalises it on the rank-0 CPU,
+one frame at a time (4096 frames for a 1M-token video), then broadcasts the float tensor.  Here the decoded
+uint8 frames go to HBM as they are (3 bytes per pixel) and `vita_frames_resize_norm` produces the
+[N, 3, 448, 448] bf16 tensor the ViT consumes.  The only host arithmetic left is Pillow's coefficient table
+(`pil_resample_table`, O(448 * taps) doubles per distinct frame size).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Sequence
+
+import numpy as np
+import torch
+
+from . import lib as _L
+
+# long_vita/constants.py:87-92
+IMAGENET_DEFAULT_MEAN = [0.485, 0.456, 0.406]
+IMAGENET_DEFAULT_STD = [0.229, 0.224, 0.225]
+IMAGENET_STANDARD_MEAN = [0.5, 0.5, 0.5]
+IMAGENET_STANDARD_STD = [0.5, 0.5, 0.5]
+OPENAI_CLIP_MEAN = [0.48145466, 0.4578275, 0.40821073]
+OPENAI_CLIP_STD = [0.26862954, 0.26130258, 0.27577711]
+
+PRECISION_BITS = 32 - 8 - 2
+
+
+def _bicubic(x: float) -> float:
+    """Pillow's bicubic_filter (Resample.c), a = -0.5, support 2."""
+    a = -0.5
+    if x < 0.0:
+        x = -x
+    if x < 1.0:
+        return ((a + 2.0) * x - (a + 3.0)) * x * x + 1
+    if x < 2.0:
+        return (((x - 5) * x + 8) * x - 4) * a
+    return 0.0
+
+
+def pil_resample_table(in_size: int, out_size: int):
+    """Pillow's precompute_coeffs + normalize_coeffs_8bpc for a full-image BICUBIC resize in_size -> out_size:
+    (bounds [out, 2] int32, coeffs [out, ksize] int32, ksize).  Same double-precision operations in the same order,
+    so the 22-bit fixed-point taps are identical to Pillow's."""
+    scale = filterscale = float(in_size) / out_size
+    if filterscale < 1.0:
+        filterscale = 1.0
+    support = 2.0 * filterscale
+    ksize = int(math.ceil(support)) * 2 + 1
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    coeffs = np.zeros((out_size, ksize), dtype=np.int32)
+    ss = 1.0 / filterscale
+    for xx in range(out_size):
+        center = 0 + (xx + 0.5) * scale
+        xmin = int(center - support + 0.5)
+        if xmin < 0:
+            xmin = 0
+        xmax = int(center + support + 0.5)
+        if xmax > in_size:
+            xmax = in_size
+        xmax -= xmin
+        ws = [_bicubic((x + xmin - center + 0.5) * ss) for x in range(xmax)]
+        ww = 0.0
+        for w in ws:
+            ww += w
+        for x in range(xmax):
+            k = ws[x] / ww if ww != 0.0 else ws[x]
+            coeffs[xx, x] = int(-0.5 + k * (1 << PRECISION_BITS)) if k < 0 else int(0.5 + k * (1 << PRECISION_BITS))
+        bounds[xx, 0], bounds[xx, 1] = xmin, xmax
+    return bounds, coeffs, ksize
+
+
+class ImageProcessor:
+    def __init__(self, process_type="", image_size=448, normalize_type="imagenet", min_patch_grid=1, max_patch_grid=6,
+                 device="cuda"):
+        self.process_type = process_type
+        self.image_size = image_size
+        if normalize_type == "imagenet":
+            mean, std = IMAGENET_DEFAULT_MEAN, IMAGENET_DEFAULT_STD
+        elif normalize_type == "clip":
+            mean, std = OPENAI_CLIP_MEAN, OPENAI_CLIP_STD
+        elif normalize_type == "siglip":
+            mean, std = IMAGENET_STANDARD_MEAN, IMAGENET_STANDARD_STD
+        else:
+            raise NotImplementedError
+        self.mean, self.std = mean, std
+        self.patch_size = image_size
+        self.min_patch_grid, self.max_patch_grid = min_patch_grid, max_patch_grid
+        self.device = device
+        self._tables = {}
+        if process_type in ("anyres", "dynamic"):
+            raise NotImplementedError("sub-patch tiling (process_anyres / process_dynamic) is not on the video path")
+
+    def _table(self, side: int):
+        t = self._tables.get(side)
+        if t is None:
+            b, c, k = pil_resample_table(side, self.image_size)
+            t = (torch.from_numpy(b).to(self.device), torch.from_numpy(c).to(self.device), k)
+            self._tables[side] = t
+        return t
+
+    def process_frames(self, frames: torch.Tensor, return_u8: bool = False):
+        """frames [N, H, W, 3] uint8 on the device -> [N, 3, S, S] bf16 (and optionally the uint8 resize)."""
+        if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3 or not frames.is_cuda:
+            raise ValueError("frames must be a [N, H, W, 3] uint8 HIP device tensor (no CPU fallback)")
+        frames = frames.contiguous()
+        n, h, w, _ = frames.shape
+        S, P = self.image_size, max(h, w)
+        bounds, coeffs, ksize = self._table(P)
+        out = torch.empty(n, 3, S, S, dtype=torch.bfloat16, device=frames.device)
+        u8 = torch.empty(n, S, S, 3, dtype=torch.uint8, device=frames.device) if return_u8 else None
+        pad = (C.c_int * 3)(*[int(x * 255) for x in self.mean])             # tuple(int(x * 255) for x in mean) :204
+        mean = (C.c_float * 3)(*[float(np.float32(x)) for x in self.mean])
+        std = (C.c_float * 3)(*[float(np.float32(x)) for x in self.std])
+        chunk = max(1, min(n, 65535, (1 << 30) // (P * S * 3)))            # bound the uint8 scratch to 1 GiB
+        tmp = torch.empty(chunk * P * S * 3, dtype=torch.uint8, device=frames.device)
+        st = torch.cuda.current_stream().cuda_stream
+        for i in range(0, n, chunk):
+            m = min(chunk, n - i)
+            _L.check(_L.load().vita_frames_resize_norm(frames[i].data_ptr(), h * w * 3, m, h, w, S, pad, bounds.data_ptr(),
+                                                       coeffs.data_ptr(), ksize, mean, std, tmp.data_ptr(),
+                                                       out[i].data_ptr(), None if u8 is None else u8[i].data_ptr(), st),
+                     "vita_frames_resize_norm")
+        return (out, u8) if return_u8 else out
+
+    def process_images(self, img_or_array_list: Sequence):
+        """:180-223.  Accepts decoded frames (PIL images or [H, W, 3] uint8 arrays); frames of equal size are batched
+        into one launch.  Returns [N, 3, S, S] bf16 on the device (the dtype module.py:693 casts to)."""
+        arrays = [np.asarray(x.convert("RGB") if hasattr(x, "convert") else x, dtype=np.uint8) for x in img_or_array_list]
+        out = torch.empty(len(arrays), 3, self.image_size, self.image_size, dtype=torch.bfloat16, device=self.device)
+        groups = {}
+        for i, a in enumerate(arrays):
+            groups.setdefault(a.shape, []).append(i)
+        for shape, idx in groups.items():
+            batch = torch.from_numpy(np.stack([arrays[i] for i in idx])).to(self.device)
+            out[torch.tensor(idx, device=self.device)] = self.process_frames(batch)
+        return out

@@ -340,6 +340,47 @@ def golden_hf_vit():
     torch.save(out, os.path.join(OUT, "hf_vit.pt"))
 
 
+def golden_image_processor():
+    """The reference's own ImageProcessor.process_images (H/data/processor/image_processor.py:180-223) run on small
+    synthetic frames (image_size 56 keeps the fixture small; the resize arithmetic does not depend on the size).
+    cv2 / natsort / decord are imported at module level but not used by process_images: stubbed."""
+    import types
+
+    import numpy as np
+    from PIL import Image
+    for n in ("cv2", "natsort", "decord"):
+        if n not in sys.modules:
+            sys.modules[n] = types.ModuleType(n)
+    # load the two reference files directly: the long_vita.data package __init__ pulls in torchvision / datasets
+    import importlib.util
+
+    def load(name, path):
+        spec = importlib.util.spec_from_file_location(name, path)
+        mod = importlib.util.module_from_spec(spec)
+        sys.modules[name] = mod
+        spec.loader.exec_module(mod)
+        return mod
+    if "long_vita" not in sys.modules:
+        sys.modules["long_vita"] = types.ModuleType("long_vita")
+    load("long_vita.constants", os.path.join(REF, "long_vita", "constants.py"))
+    ImageProcessor = load("long_vita_image_processor",
+                          os.path.join(REF, "long_vita", "data", "processor", "image_processor.py")).ImageProcessor
+    rng = np.random.default_rng(77)
+    out = {"cases": []}
+    for norm, size, shapes in [("imagenet", 56, [(100, 37), (64, 64), (90, 160), (56, 56), (23, 41)]),
+                               ("siglip", 28, [(75, 120)]), ("clip", 28, [(40, 30)])]:
+        proc = ImageProcessor("", image_size=size, normalize_type=norm)
+        frames = [rng.integers(0, 256, (h, w, 3), dtype=np.uint8) for h, w in shapes]
+        # a smooth frame as well: bicubic over/undershoot on edges exercises clip8
+        frames.append((np.indices((48, 80)).sum(0)[..., None] * np.array([3, 2, 1]) % 256).astype(np.uint8))
+        ref = proc.process_images([Image.fromarray(f) for f in frames])             # [N, 3, size, size] float32
+        out["cases"].append({"normalize_type": norm, "image_size": size, "frames": [torch.from_numpy(f) for f in frames],
+                             "output": ref.clone(), "output_bf16": torch.tensor(ref, dtype=torch.bfloat16)})
+    import PIL
+    out["pillow_version"] = PIL.__version__
+    torch.save(out, os.path.join(OUT, "image_processor.pt"))
+
+
 def _tree_map(p, f):
     if isinstance(p, dict):
         return {k: _tree_map(v, f) for k, v in p.items()}
@@ -361,6 +402,8 @@ def main():
     print("masked_linear ok")
     golden_hf_vit()
     print("hf_vit ok")
+    golden_image_processor()
+    print("image_processor ok")
 
 
 if __name__ == "__main__":

@@ -1,0 +1,85 @@
+"""Frame preprocessing: oracle vs the fixture made by the reference's own ImageProcessor, the
+host-side Pillow coefficient table, and (gpu) the HIP kernels — all bit-exact (integer resize, float32 normalise,
+round-to-nearest-even bf16)."""
+import numpy as np
+import pytest
+import torch
+
+from conftest import load_golden
+from oracle import preprocess as opre
+
+SHAPES = [(720, 1280, 448), (480, 640, 448), (100, 37, 56), (448, 448, 448), (300, 300, 448), (33, 500, 56),
+          (449, 447, 448), (1080, 1920, 448)]
+
+
+def test_oracle_matches_reference_fixture():
+    g = load_golden("image_processor.pt")
+    for case in g["cases"]:
+        frames = [f.numpy() for f in case["frames"]]
+        out = opre.process_images(frames, case["image_size"], case["normalize_type"])
+        assert torch.equal(out, case["output"])
+        assert torch.equal(opre.to_model_dtype(out), case["output_bf16"])
+
+
+@pytest.mark.parametrize("H,W,S", SHAPES[:7])
+def test_host_coefficient_table_reproduces_pillow(H, W, S):
+    """pil_resample_table + the two integer passes (numpy restatement of the kernels) == Pillow's resize."""
+    from long_vita_amd.image_processor import IMAGENET_DEFAULT_MEAN, pil_resample_table
+    rng = np.random.default_rng(H * 7 + W)
+    img = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    P = max(H, W)
+    sq = np.empty((P, P, 3), np.uint8)
+    sq[:] = np.array([int(x * 255) for x in IMAGENET_DEFAULT_MEAN], dtype=np.uint8)
+    oy, ox = (P - H) // 2, (P - W) // 2
+    sq[oy: oy + H, ox: ox + W] = img
+    b, c, k = pil_resample_table(P, S)
+    assert c.shape == (S, k) and int(b[:, 1].max()) <= k
+    tmp = np.empty((P, S, 3), np.uint8)
+    for xx in range(S):
+        x0, n = b[xx]
+        acc = (1 << 21) + (sq[:, x0: x0 + n].astype(np.int64) * c[xx, :n, None]).sum(1)
+        tmp[:, xx] = np.clip(acc >> 22, 0, 255)
+    res = np.empty((S, S, 3), np.uint8)
+    for yy in range(S):
+        y0, n = b[yy]
+        acc = (1 << 21) + (tmp[y0: y0 + n].astype(np.int64) * c[yy, :n, None, None]).sum(0)
+        res[yy] = np.clip(acc >> 22, 0, 255)
+    assert np.array_equal(res, opre.resize_u8(img, S, IMAGENET_DEFAULT_MEAN))
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.fixture(scope="module")
+def proc_mod():
+    from long_vita_amd import image_processor, lib
+    lib.load(allow_build=False)
+    return image_processor
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("H,W,S", SHAPES)
+@pytest.mark.parametrize("norm", ["imagenet", "clip"])
+def test_hip_frames_bit_exact_vs_oracle(proc_mod, H, W, S, norm):
+    if norm == "clip" and S == 448 and H > 500:
+        pytest.skip("one normalisation is enough for the large frames")
+    rng = np.random.default_rng(H + W)
+    n = 3
+    frames = rng.integers(0, 256, (n, H, W, 3), dtype=np.uint8)
+    frames[1] = (np.indices((H, W)).sum(0)[..., None] * np.array([3, 2, 1]) % 256).astype(np.uint8)   # smooth ramps
+    proc = proc_mod.ImageProcessor("", image_size=S, normalize_type=norm)
+    out, u8 = proc.process_frames(torch.from_numpy(frames).cuda(), return_u8=True)
+    mean = opre.MEANS[norm][0]
+    ref_u8 = np.stack([opre.resize_u8(f, S, mean) for f in frames])
+    assert np.array_equal(u8.cpu().numpy(), ref_u8)                                   # integer resize: bit-exact
+    ref = opre.to_model_dtype(opre.process_images(list(frames), S, norm))
+    assert out.shape == ref.shape and torch.equal(out.cpu(), ref)                     # fp32 normalise + RNE bf16: bit-exact
+
+
+@pytest.mark.gpu
+def test_hip_process_images_on_reference_fixture_and_mixed_sizes(proc_mod):
+    g = load_golden("image_processor.pt")
+    for case in g["cases"]:
+        proc = proc_mod.ImageProcessor("", image_size=case["image_size"], normalize_type=case["normalize_type"])
+        out = proc.process_images([f.numpy() for f in case["frames"]])                # frames of different sizes
+        assert torch.equal(out.cpu(), case["output_bf16"])
+    with pytest.raises(ValueError):
+        proc.process_frames(torch.zeros(1, 8, 8, 3, dtype=torch.uint8))               # CPU tensor: no fallback
