@@ -323,6 +323,34 @@ int vita_decode_attn_merge(const void* part_m, const void* part_l, const void* p
                            int64_t part_ml_stride, int64_t part_o_stride, int heads, int head_dim, void* out_m, void* out_l, void* out_o,
                            void* out_bf16, void* stream);
 
+/* One decoder layer for one token, launched from C: vita_decode_layer_attn = RMSNorm (fused into the
+ * GEMV) + QKV GEMV + bias -> RoPE + K/V append -> decode attention partial -> merge; vita_decode_layer_mlp
+ * = [merge of the CP ranks' partials] -> o-proj GEMV + residual -> RMSNorm + fc1 GEMV + SwiGLU -> fc2 GEMV
+ * + residual.  Same kernels and rounding chains as the separate entry points; the split is where the
+ * context-parallel all-gather of the packed partial (msg: heads*head_dim + 2*heads floats) sits.
+ * Replaces TransformerLayer.forward at sq = 1 (the TE layer spec of M/core/models/gpt/gpt_layer_specs.py:35-49
+ * under the decode loop M/inference/text_generation/generation.py:127-131). */
+typedef struct {
+  const void *ln1, *qkv_w, *qkv_b, *o_w, *ln2, *fc1_w, *fc2_w; /* one layer, Megatron layout, bf16 */
+  int hidden, heads, kv_groups, head_dim, ffn;
+  float eps, softmax_scale;
+  void* h;                       /* [hidden] residual stream, updated in place */
+  const void *cos, *sin;         /* [head_dim / 2] bf16 for this token's position */
+  void *k_cache, *v_cache;       /* this rank's shard [capacity][kv_groups][head_dim] (strides in elements) */
+  int64_t kv_row_stride, kv_group_stride;
+  int capacity;
+  int append_row;                /* >= 0: row that receives this token's K / V; < 0: another rank owns the token */
+  int len;                       /* rows attended to (including the appended one) */
+  int n_splits;
+  void *qkv, *ctx, *act;         /* scratch: [(heads + 2 kv_groups) head_dim], [heads head_dim], [ffn] bf16 */
+  void *part_m, *part_l, *part_o; /* scratch fp32: [n_splits][heads] x 2, [n_splits][heads][head_dim] */
+  void* msg;                     /* attn entry, CP > 1: packed partial written here instead of ctx */
+  const void* gathered;          /* mlp entry, CP > 1: [n_ranks][heads head_dim + 2 heads] fp32 */
+  int n_ranks;
+} vita_decode_layer_params;
+int vita_decode_layer_attn(const vita_decode_layer_params* p, void* stream);
+int vita_decode_layer_mlp(const vita_decode_layer_params* p, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Frame preprocessing — ImageProcessor.process_images,
  * H/data/processor/image_processor.py:180-223, then the bf16 cast of M/tasks/inference/module.py:693:

@@ -57,6 +57,29 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* red) {
   return t;
 }
 
+// RoPE (non-interleaved halves), bf16 rounding chain of rotary_pos_embedding.py:200-203 — shared by rope.hip and decode.hip
+// rotate one pair of 8-wide vectors (x1 = first half, x2 = second half) with cos/sin vectors.
+__device__ __forceinline__ void rope_rotate8(u32x4& x1, u32x4& x2, const u32x4& c, const u32x4& s,
+                                             float sign) {
+  u32x4 o1, o2;
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float a0 = bf16lo_to_f32(x1[j]), a1 = bf16hi_to_f32(x1[j]);
+    const float b0 = bf16lo_to_f32(x2[j]), b1 = bf16hi_to_f32(x2[j]);
+    const float c0 = bf16lo_to_f32(c[j]), c1 = bf16hi_to_f32(c[j]);
+    const float s0 = sign * bf16lo_to_f32(s[j]), s1 = sign * bf16hi_to_f32(s[j]);
+    // out1 = x1*cos + (-x2)*sin ; out2 = x2*cos + x1*sin
+    const float r10 = bf16_round(a0 * c0) + bf16_round(-b0 * s0);
+    const float r11 = bf16_round(a1 * c1) + bf16_round(-b1 * s1);
+    const float r20 = bf16_round(b0 * c0) + bf16_round(a0 * s0);
+    const float r21 = bf16_round(b1 * c1) + bf16_round(a1 * s1);
+    o1[j] = pack_bf16x2(r10, r11);
+    o2[j] = pack_bf16x2(r20, r21);
+  }
+  x1 = o1;
+  x2 = o2;
+}
+
 static inline int vita_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? VITA_OK : VITA_ERR_LAUNCH;

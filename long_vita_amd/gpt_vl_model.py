@@ -59,6 +59,7 @@ class GPTVLModel:
         # K/V all-gather messages per layer (split by kv head; gather j+1 overlaps attention j)
         self.kv_split = 4 if cfg.kv_groups % 4 == 0 else (2 if cfg.kv_groups % 2 == 0 else 1)
         self.force_cp_path = bool(int(os.environ.get("VITA_FORCE_CP", "0")))   # diagnostics only
+        self.decode_fused = bool(int(os.environ.get("VITA_DECODE_FUSED", "1")))   # one C call per half layer (decode)
         self.decode_graph = bool(int(os.environ.get("VITA_DECODE_GRAPH", "0")))   # capture the token step (CP = 1)
         self.attn_events = None      # bench.py: list collecting (start, end) HIP events per attention launch
 
@@ -292,6 +293,66 @@ class GPTVLModel:
             ip.decode_steps += 1
         return ops.rmsnorm(h, self.p["final_ln"], c.eps)
 
+    def _decode_token_fused(self, token: torch.Tensor, position: torch.Tensor, ip) -> torch.Tensor:
+        """Same arithmetic as _decode_token, 2 C calls per layer (vita_decode_layer_attn / _mlp: 7 kernel launches
+        issued from C, RMSNorm folded into the GEMVs, RoPE + cache append in one kernel) instead of ~13 launches
+        from Python.  The per-layer parameter structs are built once per request."""
+        import ctypes as C
+
+        import torch.distributed as dist
+
+        from . import lib as _L
+        c = self.cfg
+        cp, r = mpu.get_context_parallel_world_size(), mpu.get_context_parallel_rank()
+        ws = self._decode_workspace(token.device)
+        st = getattr(ip, "_layer_structs", None)
+        if st is None:
+            n, H, D = ops.DECODE_MAX_SPLITS, c.heads, c.head_dim
+            f32 = lambda *shape: torch.empty(*shape, dtype=torch.float32, device=token.device)  # noqa: E731
+            extra = {"pm": f32(n, H), "pl": f32(n, H), "po": f32(n, H, D),
+                     "cos": torch.empty(1, D // 2, dtype=torch.bfloat16, device=token.device),
+                     "sin": torch.empty(1, D // 2, dtype=torch.bfloat16, device=token.device)}
+            structs = []
+            for li, lp in enumerate(self.p["layers"]):
+                kv = ip.key_value_memory_dict[li + 1]
+                s = _L.DecodeLayerParams()
+                for name in ("ln1", "qkv_w", "qkv_b", "o_w", "ln2", "fc1_w", "fc2_w"):
+                    setattr(s, name, lp[name].data_ptr())
+                s.hidden, s.heads, s.kv_groups, s.head_dim, s.ffn = c.hidden, c.heads, c.kv_groups, c.head_dim, c.ffn
+                s.eps, s.softmax_scale = c.eps, 1.0 / (c.head_dim ** 0.5)
+                s.h = ws["h"].data_ptr()
+                s.cos, s.sin = extra["cos"].data_ptr(), extra["sin"].data_ptr()
+                s.k_cache, s.v_cache = kv[0].data_ptr(), kv[1].data_ptr()
+                s.kv_row_stride, s.kv_group_stride, s.capacity = kv.stride(1), kv.stride(2), kv.shape[1]
+                s.qkv, s.ctx, s.act = ws["qkv"].data_ptr(), ws["ctx"].data_ptr(), ws["act"].data_ptr()
+                s.part_m, s.part_l, s.part_o = extra["pm"].data_ptr(), extra["pl"].data_ptr(), extra["po"].data_ptr()
+                if cp > 1:
+                    s.msg, s.gathered, s.n_ranks = ws["msg"].data_ptr(), ws["gmsg"].data_ptr(), cp
+                structs.append(s)
+            st = ip._layer_structs = (structs, extra)
+        structs, extra = st
+        h = ops.row_gather(self.p["embed"], token.reshape(1), out=ws["h"], check_bounds=False)
+        cos, sin = ops.rope_table(position.reshape(1), self.rotary_pos_emb.inv_freq)
+        extra["cos"].copy_(cos)
+        extra["sin"].copy_(sin)
+        owner = (ip.decode_steps % cp) == r
+        row = ip.local_len
+        length = row + (1 if owner else 0)
+        if length > structs[0].capacity:
+            raise RuntimeError("KV cache shard is full (max_sequence_length reached)")
+        n_splits = ops.decode_splits(length)
+        lib, stream = _L.load(), torch.cuda.current_stream().cuda_stream
+        group = mpu.get_context_parallel_group() if cp > 1 else None
+        for s in structs:
+            s.append_row, s.len, s.n_splits = (row if owner else -1), length, n_splits
+            _L.check(lib.vita_decode_layer_attn(C.byref(s), stream), "vita_decode_layer_attn")
+            if cp > 1:
+                dist.all_gather_into_tensor(ws["gmsg"].view(-1), ws["msg"], group=group)
+            _L.check(lib.vita_decode_layer_mlp(C.byref(s), stream), "vita_decode_layer_mlp")
+        ip.local_len = length
+        ip.decode_steps += 1
+        return ops.rmsnorm(h, self.p["final_ln"], c.eps)
+
     def _decode_graphed(self, token: torch.Tensor, position: torch.Tensor, ip) -> torch.Tensor:
         """CP = 1: the ~450 launches of one token step are captured once per request into a HIP graph (the
         launch-bound inner loop of decode) and replayed; token id, position and the cache row count are device
@@ -343,7 +404,8 @@ class GPTVLModel:
                 raise RuntimeError("KV cache shard is full (max_sequence_length reached)")
             return self._decode_graphed(input_ids[0], position_ids[0], ip).view(1, 1, -1).clone()
         ip._graph = None                      # eager steps move the python-side counters only
-        rows = [self._decode_token(input_ids[0, j: j + 1], position_ids[0, j: j + 1], ip) for j in range(t)]
+        step = self._decode_token_fused if self.decode_fused else self._decode_token
+        rows = [step(input_ids[0, j: j + 1], position_ids[0, j: j + 1], ip) for j in range(t)]
         rows = rows[0] if t == 1 else torch.cat(rows, dim=0)
         logits, _ = self.output_layer(rows.view(t, 1, -1), weight=None, logit_mask=None)
         return logits.transpose(0, 1).contiguous()

@@ -21,7 +21,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libvita_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "vita_hip.h")
 
-ABI_VERSION = 4
+ABI_VERSION = 5
 VITA_OK = 0
 VITA_ERR_INVALID_ARG = -1
 VITA_ERR_UNSUPPORTED = -2
@@ -77,6 +77,30 @@ class AttnBwdParams(C.Structure):
     ]
 
 
+class DecodeLayerParams(C.Structure):
+    """Mirror of ``vita_decode_layer_params`` (include/vita_hip.h)."""
+
+    _fields_ = [
+        ("ln1", C.c_void_p), ("qkv_w", C.c_void_p), ("qkv_b", C.c_void_p), ("o_w", C.c_void_p), ("ln2", C.c_void_p),
+        ("fc1_w", C.c_void_p), ("fc2_w", C.c_void_p),
+        ("hidden", C.c_int), ("heads", C.c_int), ("kv_groups", C.c_int), ("head_dim", C.c_int), ("ffn", C.c_int),
+        ("eps", C.c_float), ("softmax_scale", C.c_float),
+        ("h", C.c_void_p),
+        ("cos", C.c_void_p), ("sin", C.c_void_p),
+        ("k_cache", C.c_void_p), ("v_cache", C.c_void_p),
+        ("kv_row_stride", C.c_int64), ("kv_group_stride", C.c_int64),
+        ("capacity", C.c_int),
+        ("append_row", C.c_int),
+        ("len", C.c_int),
+        ("n_splits", C.c_int),
+        ("qkv", C.c_void_p), ("ctx", C.c_void_p), ("act", C.c_void_p),
+        ("part_m", C.c_void_p), ("part_l", C.c_void_p), ("part_o", C.c_void_p),
+        ("msg", C.c_void_p),
+        ("gathered", C.c_void_p),
+        ("n_ranks", C.c_int),
+    ]
+
+
 _p, _i, _l, _f = C.c_void_p, C.c_int, C.c_int64, C.c_float
 
 # name -> (restype, argtypes); must list EVERY function declared in include/vita_hip.h
@@ -115,6 +139,8 @@ PROTOTYPES = {
     "vita_flash_attn_bwd": (_i, [C.POINTER(AttnBwdParams), _p]),
     "vita_gemv_bf16": (_i, [_p, _p, _l, _p, _l, _l, _i, _p, _p, _p]),
     "vita_decode_attn_partial": (_i, [_p, _l, _l, _p, _p, _l, _l, _i, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p]),
+    "vita_decode_layer_attn": (_i, [C.POINTER(DecodeLayerParams), _p]),
+    "vita_decode_layer_mlp": (_i, [C.POINTER(DecodeLayerParams), _p]),
     "vita_frames_resize_norm": (_i, [_p, _l, _i, _i, _i, _i, C.POINTER(C.c_int), _p, _p, _i, C.POINTER(C.c_float),
                                       C.POINTER(C.c_float), _p, _p, _p, _p]),
     "vita_decode_attn_merge": (_i, [_p, _p, _p, _i, _l, _l, _i, _i, _p, _p, _p, _p, _p]),

@@ -497,7 +497,7 @@ def flash_attn_bwd(q5, k, v, o, d_o, lse, *, chunk_len=None, q_chunk_gid=None, k
 # ------------------------------------------------------------------------------------------------
 # single-token decode against the sharded KV cache
 # ------------------------------------------------------------------------------------------------
-DECODE_KEYS_PER_TILE = 256
+DECODE_KEYS_PER_TILE = 128
 DECODE_MAX_SPLITS = 128
 
 

@@ -128,14 +128,15 @@ def _decode_run(amd, model, prompt, n_new, max_len, use_kv_cache, ext=None):
     return tokens[:, : P + n_new].clone(), lps[:, P - 1: P - 1 + n_new].clone()
 
 
-@pytest.mark.parametrize("graph", [True, False])
-def test_cached_decode_matches_reprefill_and_oracle(amd, graph):
+@pytest.mark.parametrize("graph,fused", [(True, False), (False, False), (False, True)])
+def test_cached_decode_matches_reprefill_and_oracle(amd, graph, fused):
     """Greedy decode of 6 tokens: the cached loop (token step replayed from a captured HIP graph, or launched
     eagerly) produces the log-probs the reference's re-prefill loop produces on the same tokens, and the oracle's
     full-sequence logits at those positions."""
     cfgd = SMALL
     ocfg, p, model = _llm_pair(amd, cfgd)
     model.decode_graph = graph
+    model.decode_fused = fused
     P, n_new, max_len = 300, 6, 512
     prompt = torch.randint(0, cfgd["vocab"], (1, P), generator=torch.Generator().manual_seed(12)).to(DEV)
     toks_c, lp_c = _decode_run(amd, model, prompt, n_new, max_len, True)
@@ -173,8 +174,8 @@ def test_cached_decode_with_visual_prompt(amd):
         assert lp_err(lp_c, lp_r) < 1.5e-2
 
 
-@pytest.mark.parametrize("cp,P", [(2, 1500), (2, 1024), (4, 2300)])
-def test_cached_decode_context_parallel(amd, monkeypatch, cp, P):
+@pytest.mark.parametrize("cp,P,fused", [(2, 1500, True), (2, 1024, False), (4, 2300, True)])
+def test_cached_decode_context_parallel(amd, monkeypatch, cp, P, fused):
     """Simulated CP ranks: padded zig-zag prefill fills the cache shards (pad rows dropped), generated tokens
     are appended round-robin, per-rank partials merged after the all-gather == CP = 1 cached decode."""
     cfgd = SMALL
@@ -186,6 +187,7 @@ def test_cached_decode_context_parallel(amd, monkeypatch, cp, P):
 
     def rank_fn(r):
         m = G.GPTVLModel(model1.cfg, model1.p)
+        m.decode_fused = fused
         return _decode_run(amd, m, prompt, n_new, max_len, True)
 
     outs = _run_ranks(cp, rank_fn, amd, monkeypatch)
@@ -196,3 +198,18 @@ def test_cached_decode_context_parallel(amd, monkeypatch, cp, P):
         assert lp_err(outs[0][1], lp1) < 1.5e-2
     ora = ollm.prefill_logits(outs[0][0].cpu(), p, ocfg, list(range(P - 1, P - 1 + n_new)))[0]
     assert lp_err(outs[0][1][0], torch.log_softmax(ora.float(), dim=1)) < 2.5e-2
+
+
+def test_fused_decode_layer_equals_separate_kernels(amd):
+    """vita_decode_layer_attn / _mlp run the same kernels with the same rounding chains: logits of the fused and the
+    kernel-by-kernel token step agree to the last bf16 bit for almost every element."""
+    cfgd = SMALL
+    ocfg, p, model = _llm_pair(amd, cfgd)
+    P, n_new, max_len = 700, 4, 1024
+    prompt = torch.randint(0, cfgd["vocab"], (1, P), generator=torch.Generator().manual_seed(3)).to(DEV)
+    model.decode_fused = True
+    toks_f, lp_f = _decode_run(amd, model, prompt, n_new, max_len, True)
+    model.decode_fused = False
+    toks_s, lp_s = _decode_run(amd, model, prompt, n_new, max_len, True)
+    assert torch.equal(toks_f, toks_s)
+    assert lp_err(lp_f, lp_s) < 2e-3
