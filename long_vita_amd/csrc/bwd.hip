@@ -127,12 +127,21 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
     }
   }
   if (dw_acc) {
+    // reduce the workgroup's 4 waves through LDS first: one fp32 atomic per column and workgroup
+    // (8192 waves x 5120 atomics on 5120 addresses made this kernel 20x slower than its HBM time)
+    __shared__ float red[4][64][8];
+    const int wv = threadIdx.x >> 6;
 #pragma unroll
     for (int i = 0; i < VPL; ++i) {
       const int vi = lane + i * 64;
-      if (vi < nvec) {
+      __syncthreads();
 #pragma unroll
-        for (int j = 0; j < 8; ++j) atomicAdd(dw_acc + vi * 8 + j, dwl[i][j]);
+      for (int j = 0; j < 8; ++j) red[wv][lane][j] = dwl[i][j];
+      __syncthreads();
+      if (wv == 0 && vi < nvec) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j)
+          atomicAdd(dw_acc + vi * 8 + j, (red[0][lane][j] + red[1][lane][j]) + (red[2][lane][j] + red[3][lane][j]));
       }
     }
   }
@@ -408,7 +417,7 @@ extern "C" int vita_rmsnorm_bwd(const void* dy, const void* x, const void* w, co
   if ((cols & 7) || cols > 8192) return VITA_ERR_UNSUPPORTED;
   if (rows == 0) return VITA_OK;
   const int vpl = (cols + 511) / 512;
-  dim3 grid((unsigned)((rows + 3) / 4 < 2048 ? (rows + 3) / 4 : 2048)), block(256);
+  dim3 grid((unsigned)((rows + 3) / 4 < 512 ? (rows + 3) / 4 : 512)), block(256);   // 2 workgroups per CU
   hipStream_t st = (hipStream_t)stream;
 #define VITA_RB(V) hipLaunchKernelGGL(rmsnorm_bwd_kernel<V>, grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)res, (bf16_t*)dx, dw_acc, rows, cols, eps)
   if (vpl <= 2) VITA_RB(2); else if (vpl <= 4) VITA_RB(4); else if (vpl <= 8) VITA_RB(8); else if (vpl <= 10) VITA_RB(10); else VITA_RB(16);
