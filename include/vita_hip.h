@@ -193,6 +193,10 @@ typedef struct {
   const int64_t* kv_chunk_row;     /* host [n_kv_chunks] */
   int causal;
   float softmax_scale;
+  const int32_t* q_seg_start;      /* DEVICE [rows] or NULL: packed sequences (flash_attn_varlen_func with
+                                      cu_seqlens, M/core/transformer/dot_product_attention.py:334-367): first row of
+                                      the segment each query row belongs to; keys before it are masked.  Needs
+                                      batch 1, causal, single-chunk geometry. */
 } vita_attn_params;
 
 int vita_flash_attn_fwd(const vita_attn_params* p, void* stream);
@@ -287,6 +291,8 @@ typedef struct {
   const int32_t* kv_chunk_gid;     /* host */
   const int64_t* kv_chunk_row;     /* host */
   float softmax_scale;
+  const int32_t* q_seg_start;      /* DEVICE [rows] or NULL: packed sequences, as in vita_attn_params */
+  const int32_t* k_seg_end;        /* DEVICE [rows] or NULL: one past the last row of each key row's segment */
 } vita_attn_bwd_params;
 
 int vita_flash_attn_bwd(const vita_attn_bwd_params* p, void* stream);

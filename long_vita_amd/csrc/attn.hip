@@ -48,6 +48,7 @@ struct AttnArgs {
   int tiles_per_q_chunk;                 // ceil(chunk_len / 256)
   int n_q_rows;                          // total local q rows (for lse indexing)
   float scale_log2e;                     // softmax_scale * log2(e)
+  const int* seg_start;                  // packed sequences: first key row of each query row's segment (or null)
   int q_order[kMaxChunks];               // q chunks sorted by gid descending
   int q_gid[kMaxChunks];
   int kv_gid[kMaxChunks];
@@ -140,6 +141,12 @@ __global__ __launch_bounds__(512, 2) void flash_fwd_kernel(AttnArgs p) {
   const int64_t q_local_row = (int64_t)qc * p.chunk_len + (q_live ? my_q : q_rows_in_chunk - 1);
   const int q_last_wg = min(q_off_wg + QTILE, q_rows_in_chunk) - 1;  // last valid row of the WG
   const float scale_log2e = p.scale_log2e;
+  // packed sequences (block-diagonal causal, single chunk): a query only sees keys >= the first row of its segment.
+  // seg_start is non-decreasing, so the workgroup starts at the tile of its first row's segment and only the tiles
+  // below its last row's segment start need the extra element mask.
+  const int my_start = p.seg_start ? p.seg_start[q_local_row] : 0;
+  const int wg_first_start = p.seg_start ? p.seg_start[(int64_t)qc * p.chunk_len + q_off_wg] : 0;
+  const int wg_last_start = p.seg_start ? p.seg_start[(int64_t)qc * p.chunk_len + q_last_wg] : 0;
 
   // ---- Q fragments (B operand of S^T = K Q^T): lane = (query row l31, k-slot half hi) --------
   bf16x8 qf[DS];
@@ -197,7 +204,7 @@ __global__ __launch_bounds__(512, 2) void flash_fwd_kernel(AttnArgs p) {
       const int gk = p.kv_gid[t.c];
       t.diag = CAUSAL && gk == gq;
       t.n = (!CAUSAL || gk < gq) ? all : (gk > gq ? 0 : min(all, q_last_wg / KVT + 1));
-      if (t.n > 0) { t.crow = p.kv_row[t.c]; t.j = 0; return; }
+      if (t.n > 0) { t.crow = p.kv_row[t.c]; t.j = wg_first_start / KVT; return; }
       ++t.c;
     }
   };
@@ -309,15 +316,16 @@ __global__ __launch_bounds__(512, 2) void flash_fwd_kernel(AttnArgs p) {
   };
   auto sm_pv_phase = [&](unsigned sl, int kv_off, bool diag, int kv_rows) __attribute__((always_inline)) {
     // key index (inside the tile) of accumulator register r: (r&3) + 8*(r>>2) + 4*hi (+32 for s1)
-    const bool need_mask = (diag && kv_off + KVT - 1 > q_off) || (kv_off + KVT > kv_rows);
+    const bool need_mask = (diag && kv_off + KVT - 1 > q_off) || (kv_off + KVT > kv_rows) || (kv_off < wg_last_start);
     if (need_mask) {
       const int lim_c = diag ? (my_q - kv_off) : 0x7fffffff;        // key <= lim_c visible
       const int lim = min(lim_c, kv_rows - kv_off - 1);              // key <= .. valid
+      const int lo = my_start - kv_off;                              // key >= lo: same packed segment
 #pragma unroll
       for (int r = 0; r < 16; ++r) {
         const int key = (r & 3) + 8 * (r >> 2) + 4 * hi;
-        if (key > lim) s0[r] = -INFINITY;
-        if (key + 32 > lim) s1[r] = -INFINITY;
+        if (key > lim || key < lo) s0[r] = -INFINITY;
+        if (key + 32 > lim || key + 32 < lo) s1[r] = -INFINITY;
       }
     }
     // online softmax, log2 domain
@@ -545,6 +553,8 @@ extern "C" int vita_flash_attn_fwd(const vita_attn_params* p, void* stream) {
   a.tiles_per_q_chunk = (int)((p->chunk_len + QTILE - 1) / QTILE);
   a.n_q_rows = (int)((int64_t)(p->n_q_chunks - 1) * p->chunk_len + p->q_valid);
   a.scale_log2e = p->softmax_scale * 1.44269504088896340736f;
+  a.seg_start = p->q_seg_start;
+  if (p->q_seg_start && (p->n_q_chunks != 1 || p->n_kv_chunks != 1 || !p->causal || p->batch != 1)) return VITA_ERR_UNSUPPORTED;
   for (int i = 0; i < p->n_q_chunks; ++i) { a.q_gid[i] = p->q_chunk_gid[i]; a.q_order[i] = i; }
   // heaviest (largest global chunk id) first
   for (int i = 1; i < p->n_q_chunks; ++i)

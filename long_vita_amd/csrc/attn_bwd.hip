@@ -37,6 +37,8 @@ struct BwdArgs {
   int n_q_heads, n_kv_heads;
   int chunk_len, n_q_chunks, n_kv_chunks, n_q_rows;
   float scale, scale_log2e;
+  const int* seg_start;   // packed sequences (single chunk): first row of each query row's segment, or null
+  const int* seg_end;     // one past the last row of each key row's segment, or null
   int q_gid[kMaxChunks];
   int kv_gid[kMaxChunks];
   int64_t kv_row[kMaxChunks];
@@ -117,6 +119,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
   const int my_q = q_off + l31;
   const int64_t q_row = (int64_t)qc * p.chunk_len + my_q;
   const int q_last_wg = qti * QT_DQ + QT_DQ - 1;
+  // packed sequences: keys before the row's segment are invisible; the workgroup starts at its first row's segment
+  const int my_start = p.seg_start ? p.seg_start[q_row] : 0;
+  const int wg_first_start = p.seg_start ? p.seg_start[(int64_t)qc * p.chunk_len + qti * QT_DQ] : 0;
+  const int wg_last_start = p.seg_start ? p.seg_start[(int64_t)qc * p.chunk_len + q_last_wg] : 0;
 
   bf16x8 qf[8], dof[8];
   {
@@ -160,9 +166,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
     }
   };
 
-  int c_cur = 0, j_cur = 0, n_cur = 0;
+  int c_cur = 0, j_cur = wg_first_start / KT_DQ, n_cur = 0;
   while (c_cur < p.n_kv_chunks && (n_cur = chunk_tiles(c_cur)) == 0) ++c_cur;
-  if (c_cur < p.n_kv_chunks) stage_tile(c_cur, 0, lds0);
+  if (c_cur < p.n_kv_chunks) stage_tile(c_cur, j_cur, lds0);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
@@ -194,11 +200,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[ds], dp, 0, 0, 0);    // dP^T[key, q]
         }
         const bool need_mask = diag && kv_off + 32 * h + 31 > q_off;
+        const bool seg_mask = kv_off + 32 * h < wg_last_start;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
           const int key = kv_off + 32 * h + (r & 3) + 8 * (r >> 2) + 4 * hi;
           float pr = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale_log2e, -lse2));
-          if (need_mask && key > my_q) pr = 0.f;
+          if ((need_mask && key > my_q) || (seg_mask && key < my_start)) pr = 0.f;
           s[r] = pr * (dp[r] - dlt) * p.scale;           // dS^T
         }
 #pragma unroll
@@ -237,7 +244,7 @@ constexpr int KT_KV = 128;      // keys per workgroup (4 waves x 32)
 constexpr int QT_KV = 32;       // query rows per step
 // LDS: K frag (32 KiB) | V frag (32 KiB) | 2 stages x [Q frag 8 | Q tr 8 | dO frag 8 | dO tr 8 | lse 128 B | delta 128 B]
 constexpr int KV_FIXED = 2 * KT_KV * ROWB;
-constexpr int KV_STAGE = 4 * QT_KV * ROWB + 256;
+constexpr int KV_STAGE = 4 * QT_KV * ROWB + 384;   // + lse, delta, segment start of the 32 rows
 
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -276,7 +283,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
     for (int r = 0; r < 16; ++r) { dk_acc[i][r] = 0.f; dv_acc[i][r] = 0.f; }
 
   // ---- iteration space: (query head of the group, local query chunk, 32-row tile) ----------------
-  const int qt_per_chunk = p.chunk_len / QT_KV;
+  // packed sequences: the last key of the workgroup bounds the query rows that can see any of its keys
+  const int qt_per_chunk = p.seg_end ? (p.seg_end[k_row0 + KT_KV - 1] + QT_KV - 1) / QT_KV : p.chunk_len / QT_KV;
   auto first_tile = [&](int qc) __attribute__((always_inline)) -> int {   // first visible tile of chunk qc, or qt_per_chunk
     const int gq = p.q_gid[qc];
     if (gq > gk) return 0;
@@ -302,6 +310,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
       const float val = hi == 0 ? p.lse[sidx] * 1.44269504088896340736f : p.delta[sidx];
       *(__attribute__((address_space(3))) float*)(uintptr_t)(sl + 4 * QT_KV * ROWB + hi * 128 + l31 * 4) = val;
     }
+    if (wave == 1 && hi == 0)
+      *(__attribute__((address_space(3))) int*)(uintptr_t)(sl + 4 * QT_KV * ROWB + 256 + l31 * 4) =
+          p.seg_start ? p.seg_start[row0 + l31] : 0;
   };
 
   int hq_c = 0, qc_c = 0, qt_c = 0;
@@ -356,12 +367,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
       for (int rg = 0; rg < 4; ++rg) {
         const f32x4 l4 = *(lds_f32x4*)(uintptr_t)(stat + (8 * rg + 4 * hi) * 4);
         const f32x4 d4 = *(lds_f32x4*)(uintptr_t)(stat + 128 + (8 * rg + 4 * hi) * 4);
+        typedef __attribute__((ext_vector_type(4))) int i32x4;
+        const i32x4 st4 = *(__attribute__((address_space(3))) const i32x4*)(uintptr_t)(stat + 256 + (8 * rg + 4 * hi) * 4);
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int r = rg * 4 + j;
           const int qrow = q_off + 8 * rg + 4 * hi + j;
           float e = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale_log2e, -l4[j]));
-          if (need_mask && my_key > qrow) e = 0.f;
+          if ((need_mask && my_key > qrow) || my_key < st4[j]) e = 0.f;
           pr[r] = e;
           s[r] = e * (dp[r] - d4[j]) * p.scale;          // dS[q, key]
         }
@@ -434,6 +447,9 @@ extern "C" int vita_flash_attn_bwd(const vita_attn_bwd_params* p, void* stream) 
   a.chunk_len = (int)p->chunk_len; a.n_q_chunks = p->n_q_chunks; a.n_kv_chunks = p->n_kv_chunks;
   a.n_q_rows = (int)(p->n_q_chunks * p->chunk_len);
   a.scale = p->softmax_scale; a.scale_log2e = p->softmax_scale * 1.44269504088896340736f;
+  a.seg_start = p->q_seg_start; a.seg_end = p->k_seg_end;
+  if ((p->q_seg_start != nullptr) != (p->k_seg_end != nullptr)) return VITA_ERR_INVALID_ARG;
+  if (p->q_seg_start && (p->n_q_chunks != 1 || p->n_kv_chunks != 1)) return VITA_ERR_UNSUPPORTED;
   for (int i = 0; i < p->n_q_chunks; ++i) a.q_gid[i] = p->q_chunk_gid[i];
   for (int i = 0; i < p->n_kv_chunks; ++i) { a.kv_gid[i] = p->kv_chunk_gid[i]; a.kv_row[i] = p->kv_chunk_row[i]; }
 

@@ -18,7 +18,7 @@ from typing import Optional
 
 import torch
 
-from . import ops, parallel_state as mpu
+from . import ops, parallel_state as mpu, training_utils
 from .dot_product_attention import DotProductAttention
 from .language_model_embedding import LanguageModelEmbedding
 from .layers import ColumnParallelLinear
@@ -126,11 +126,15 @@ class GPTVLModel:
         if self.attn_events is not None:
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
         if use_cp:
+            if training_utils.get_packed_segments() is not None:
+                raise NotImplementedError("packed samples under context parallelism are not built")
             ctx = self.core_attention.forward_cp(q5, ws["kv"], out=ws["ctx"], events=ev)
         else:
             if ev:
                 ev[0].record()
-            ctx = ops.flash_attn(q5, m5[:, :, :, c.qpg], m5[:, :, :, c.qpg + 1], causal=True, out=ws["ctx"])
+            seg = training_utils.get_packed_segments()       # position ids with resets -> packed samples
+            ctx = ops.flash_attn(q5, m5[:, :, :, c.qpg], m5[:, :, :, c.qpg + 1], causal=True, out=ws["ctx"],
+                                 seg_start=None if seg is None else seg[0])
             if ev:
                 ev[1].record()
         if ev:

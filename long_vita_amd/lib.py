@@ -21,7 +21,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libvita_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "vita_hip.h")
 
-ABI_VERSION = 5
+ABI_VERSION = 6
 VITA_OK = 0
 VITA_ERR_INVALID_ARG = -1
 VITA_ERR_UNSUPPORTED = -2
@@ -51,6 +51,7 @@ class AttnParams(C.Structure):
         ("kv_chunk_row", C.POINTER(C.c_int64)),
         ("causal", C.c_int),
         ("softmax_scale", C.c_float),
+        ("q_seg_start", C.c_void_p),
     ]
 
 
@@ -74,6 +75,7 @@ class AttnBwdParams(C.Structure):
         ("kv_chunk_gid", C.POINTER(C.c_int32)),
         ("kv_chunk_row", C.POINTER(C.c_int64)),
         ("softmax_scale", C.c_float),
+        ("q_seg_start", C.c_void_p), ("k_seg_end", C.c_void_p),
     ]
 
 

@@ -263,7 +263,7 @@ def gemm_skinny(a: torch.Tensor, w: torch.Tensor, out_f32: bool = False) -> torc
 def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, causal: bool, softmax_scale: Optional[float] = None,
                chunk_len: Optional[int] = None, q_chunk_gid: Optional[Sequence[int]] = None,
                kv_chunk_gid: Optional[Sequence[int]] = None, kv_chunk_row: Optional[Sequence[int]] = None,
-               out: Optional[torch.Tensor] = None, return_lse: bool = False):
+               out: Optional[torch.Tensor] = None, return_lse: bool = False, seg_start: Optional[torch.Tensor] = None):
     """q [B, Sq, Hq, D] or grouped [B, Sq, Hkv, G, D]; k/v [B, Sk, Hkv, D] — *views* (any batch / row /
     head / group stride, D contiguous).  Returns o [B, Sq, Hq, D] (contiguous unless `out` given).
 
@@ -312,6 +312,8 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, causal: boo
     p.q_chunk_gid, p.kv_chunk_gid, p.kv_chunk_row = qg_a, kg_a, kr_a
     p.causal = int(causal)
     p.softmax_scale = float(softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(D))
+    if seg_start is not None:           # packed sequences: int32 [rows], first row of each query row's segment
+        p.q_seg_start = _dev(seg_start, "seg_start", torch.int32)
     _L.check(_L.load().vita_flash_attn_fwd(C.byref(p), _stream()), "vita_flash_attn_fwd")
     return (o, lse) if return_lse else o
 
@@ -449,8 +451,8 @@ def row_scatter_add_f32_(dst: torch.Tensor, idx: torch.Tensor, src: torch.Tensor
 
 
 def flash_attn_bwd(q5, k, v, o, d_o, lse, *, chunk_len=None, q_chunk_gid=None, kv_chunk_gid=None, kv_chunk_row=None,
-                   softmax_scale=None, dq5=None, dk=None, dv=None):
-    """Backward of flash_attn(causal=True) at batch 1, head_dim 128.
+                   softmax_scale=None, dq5=None, dk=None, dv=None, seg_start=None, seg_end=None):
+    """Backward of flash_attn(causal=True) at batch 1, head_dim 128 (seg_start / seg_end int32 [rows]: packed sequences).
     q5 [1, Sq, Hkv, G, D] (or [1, Sq, Hq, D]); k, v [1, Sk, Hkv, D] views; o, d_o [1, Sq, Hq, D];
     lse [1, Hq, Sq].  Returns (dq like q5, dk, dv like k/v — dk/dv cover every row of k/v)."""
     if q5.dim() == 5:
@@ -490,6 +492,8 @@ def flash_attn_bwd(q5, k, v, o, d_o, lse, *, chunk_len=None, q_chunk_gid=None, k
     qg_a, kg_a, kr_a = (C.c_int32 * len(qg))(*qg), (C.c_int32 * len(kg))(*kg), (C.c_int64 * len(kr))(*kr)
     p.q_chunk_gid, p.kv_chunk_gid, p.kv_chunk_row = qg_a, kg_a, kr_a
     p.softmax_scale = float(softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(D))
+    if seg_start is not None:
+        p.q_seg_start, p.k_seg_end = _dev(seg_start, "seg_start", torch.int32), _dev(seg_end, "seg_end", torch.int32)
     _L.check(h.vita_flash_attn_bwd(C.byref(p), _stream()), "vita_flash_attn_bwd")
     return dq5, dk, dv
 
@@ -580,3 +584,16 @@ def unpack_partials(gathered: torch.Tensor, heads: int, d: int):
     n = gathered.shape[0]
     o = gathered[:, : heads * d].view(n, heads, d)
     return gathered[:, heads * d: heads * d + heads], gathered[:, heads * d + heads:], o
+
+
+def segments_from_cu_seqlens(cu_seqlens: torch.Tensor, total: int):
+    """cu_seqlens [n + 1] (PackedSeqParams.cu_seqlens_q, M/training/utils.py:31-57) -> (seg_start, seg_end) int32 [total]:
+    for every row the first row and one-past-the-last row of its packed sample (rows past cu_seqlens[-1] form a last
+    segment of their own, as the reference appends seq_length to actual_seq_len).  Index plumbing, plain torch."""
+    cu = cu_seqlens.to(torch.int64).reshape(-1)
+    if int(cu[-1]) < total:
+        cu = torch.cat([cu, cu.new_tensor([total])])
+    lens = cu[1:] - cu[:-1]
+    start = torch.repeat_interleave(cu[:-1], lens).to(torch.int32)
+    end = torch.repeat_interleave(cu[1:], lens).to(torch.int32)
+    return start.contiguous(), end.contiguous()

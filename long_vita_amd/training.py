@@ -79,7 +79,11 @@ class TrainStep:
             k_all, v_all, geo = self._gather_kv(kv_local)
         else:
             k_all, v_all, geo = m5[:, :, :, c.qpg], m5[:, :, :, c.qpg + 1], {}
-        ctx, lse = ops.flash_attn(q5, k_all, v_all, causal=True, return_lse=True, **geo)
+        seg = training_utils.get_packed_segments()
+        if seg is not None and cp > 1:
+            raise NotImplementedError("packed samples under context parallelism are not built")
+        ctx, lse = ops.flash_attn(q5, k_all, v_all, causal=True, return_lse=True, seg_start=None if seg is None else seg[0],
+                                  **geo)
         ctx2 = ctx.view(s, c.heads * c.head_dim)
         h_mid = ops.gemm(ctx2, lp["o_w"], ops.EPI_RESIDUAL, residual=h)
         x2 = ops.rmsnorm(h_mid, lp["ln2"], c.eps)
@@ -140,8 +144,10 @@ class TrainStep:
             dm5[0, :, :, c.qpg].copy_(dkv_local[0])
             dm5[0, :, :, c.qpg + 1].copy_(dkv_local[1])
         else:
+            seg = training_utils.get_packed_segments()
             ops.flash_attn_bwd(a["q5"], a["k_all"], a["v_all"], a["ctx"], d_ctx, a["lse"], dq5=dm5[:, :, :, : c.qpg],
-                               dk=dm5[:, :, :, c.qpg], dv=dm5[:, :, :, c.qpg + 1])
+                               dk=dm5[:, :, :, c.qpg], dv=dm5[:, :, :, c.qpg + 1],
+                               seg_start=None if seg is None else seg[0], seg_end=None if seg is None else seg[1])
         ops.rope_qkv_bwd_(d_mixed, c.kv_groups, c.qpg, c.head_dim, cos, sin)
         dm_t = _t(d_mixed)
         g["qkv_w"] = _wgrad(dm_t, a["x1"])
@@ -157,13 +163,24 @@ class TrainStep:
     # ------------------------------------------------------------------------------------------
     @torch.no_grad()
     def forward_backward(self, tokens: torch.Tensor, labels: torch.Tensor, loss_mask: torch.Tensor,
-                         external_inputs: Optional[dict] = None):
+                         external_inputs: Optional[dict] = None, position_ids: Optional[torch.Tensor] = None):
+        try:
+            return self._forward_backward(tokens, labels, loss_mask, external_inputs, position_ids)
+        finally:
+            training_utils.set_position_ids(None)         # the reference's global (utils.py:44-50) must not leak
+
+    def _forward_backward(self, tokens: torch.Tensor, labels: torch.Tensor, loss_mask: torch.Tensor,
+                          external_inputs: Optional[dict] = None, position_ids: Optional[torch.Tensor] = None):
         """tokens / labels / loss_mask [1, S] (global, on every rank); external_inputs
-        {"images", "indices"} (global).  `--logit-mask` semantics: logit_mask = loss_mask.bool()."""
+        {"images", "indices"} (global).  `--logit-mask` semantics: logit_mask = loss_mask.bool().
+        position_ids [1, S] with resets (--reset-position-ids): stage-2 packed samples — RoPE restarts and attention is
+        block-diagonal (M/training/utils.py:267-270; CP = 1)."""
         m, c = self.m, self.m.cfg
         cp = mpu.get_context_parallel_world_size()
         seq = tokens.shape[1]
-        position_ids = torch.arange(seq, dtype=torch.long, device=tokens.device).unsqueeze(0)
+        training_utils.set_position_ids(None if position_ids is None else position_ids.transpose(0, 1).contiguous())
+        if position_ids is None:
+            position_ids = torch.arange(seq, dtype=torch.long, device=tokens.device).unsqueeze(0)
         batch = {"tokens": tokens, "labels": labels, "loss_mask": loss_mask, "position_ids": position_ids}
         if external_inputs:
             batch["external_images"] = external_inputs["images"]

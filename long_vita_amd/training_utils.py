@@ -92,3 +92,26 @@ def get_batch_on_this_cp_rank(batch: dict, seq_length: Optional[int] = None, cp_
             continue
         batch[key] = zigzag_slice(val, cp_size, cp_rank, seq_dim=1)
     return batch
+
+
+def get_packed_segments():
+    """Packed samples as the reference's GPU path detects them: transformers' _flash_attention_forward
+    (called at M/core/transformer/dot_product_attention.py:374-390 with position_ids=get_position_ids()) switches to
+    flash_attn_varlen when the position ids are not monotonic, with cu_seqlens at the zeros of position_ids.
+    Returns (seg_start, seg_end) int32 [s] on the device, or None.  CP = 1 only."""
+    pid = _POSITION_IDS
+    if pid is None:
+        return None
+    cached = getattr(get_packed_segments, "_cache", None)
+    if cached is not None and cached[0] is pid:
+        return cached[1]
+    pos = pid.reshape(pid.shape[0], -1)[:, 0]                              # stored [s, b] (:268-270), b == 1
+    seg = None
+    if pos.numel() > 1 and not bool((torch.diff(pos) >= 0).all()):
+        from . import ops
+        cu = (pos == 0).nonzero().flatten()
+        if cu.numel() == 0 or int(cu[0]) != 0:
+            cu = torch.cat([cu.new_zeros(1), cu])
+        seg = ops.segments_from_cu_seqlens(cu, pos.numel())
+    get_packed_segments._cache = (pid, seg)
+    return seg

@@ -9,11 +9,12 @@ from .glue import zigzag_chunk_ids
 
 
 def core_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool, scale: float = None,
-                   q_pos: torch.Tensor = None, k_pos: torch.Tensor = None) -> torch.Tensor:
+                   q_pos: torch.Tensor = None, k_pos: torch.Tensor = None, cu_seqlens: torch.Tensor = None) -> torch.Tensor:
     """M/core/transformer/dot_product_attention.py:171-175 (GQA repeat_interleave) + :186-289
     (baddbmm / softmax / bmm).  q [sq, b, np, hn], k/v [sk, b, ng, hn] -> [sq, b, np*hn].
     Computed in fp32 (attention_softmax_in_fp32), result cast to q.dtype.
-    q_pos / k_pos: global positions for the causal rule (default arange)."""
+    q_pos / k_pos: global positions for the causal rule (default arange).
+    cu_seqlens: packed samples (flash_attn_varlen_func branch, :334-367) — a query only sees keys of its own sample."""
     sq, b, np_, hn = q.shape
     sk, _, ng, _ = k.shape
     rep = np_ // ng
@@ -30,6 +31,10 @@ def core_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bo
         kp = torch.arange(sk) if k_pos is None else k_pos
         mask = kp[None, :] > qp[:, None]
         scores = scores.masked_fill(mask[None, None], float("-inf"))
+    if cu_seqlens is not None:
+        assert causal and sq == sk
+        seg = torch.bucketize(torch.arange(sq), cu_seqlens.to(torch.int64)[1:], right=True)     # sample id of every row
+        scores = scores.masked_fill((seg[:, None] != seg[None, :])[None, None], float("-inf"))
     probs = torch.softmax(scores, dim=-1)
     ctx = torch.matmul(probs, vf)                                   # [b, np, sq, hn]
     return ctx.permute(2, 0, 1, 3).reshape(sq, b, np_ * hn).to(q.dtype)

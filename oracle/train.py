@@ -28,12 +28,15 @@ def _grads(p):
 
 
 def loss_and_grads(tokens, labels, loss_mask, params, cfg: ollm.LLMConfig, cp_size: int = 1,
-                   is_instruction: bool = True, feature_fn=None, indices=None):
+                   is_instruction: bool = True, feature_fn=None, indices=None, position_ids=None):
     """Mean cross-entropy over the logit-masked rows, with the reference's per-rank selection and
     instruction shift: rank r keeps the masked positions among ITS zig-zag positions (local order),
     pairs logits[k] with labels[k+1] of that selection (gpt_vl_model.py:380-391), all ranks' pairs are
     averaged together (pretrain_long_vita.py:793-803).  cp_size = 1 is the plain case.
-    feature_fn(params) -> features [N, L, hidden] (differentiable) scattered at `indices` [2, N, L]."""
+    feature_fn(params) -> features [N, L, hidden] (differentiable) scattered at `indices` [2, N, L].
+    position_ids [1, S] with resets (--reset-position-ids, M/training/utils.py:221-245): RoPE follows them
+    (rotary_pos_embedding.py:114-117) and, being non-monotonic, they make transformers' _flash_attention_forward treat
+    the row as packed samples — cu_seqlens = positions of the zeros (dot_product_attention.py:374-390)."""
     p = _leafify(params)
     S = tokens.shape[1]
     we = p["embed"][tokens]
@@ -41,9 +44,17 @@ def loss_and_grads(tokens, labels, loss_mask, params, cfg: ollm.LLMConfig, cp_si
     if feature_fn is not None:
         efd = {"features": feature_fn(p), "indices": indices}
     h = glue.embedding_scatter(we, efd)
-    freqs = glue.rope_emb(S, glue.rope_inv_freq(cfg.head_dim, cfg.rope_theta))
+    cu = None
+    pos_sb = None
+    if position_ids is not None:
+        pos_sb = position_ids.transpose(0, 1)
+        flat = position_ids[0]
+        if not bool((torch.diff(flat) >= 0).all()):
+            cu = torch.cat([(flat == 0).nonzero().flatten(), torch.tensor([S])]).to(torch.int32)
+    freqs = glue.rope_emb(S, glue.rope_inv_freq(cfg.head_dim, cfg.rope_theta), pos_sb)
     for lp in p["layers"]:
-        h, _ = ollm.decoder_layer(h, lp, cfg, freqs, lambda q, k, v: core_attention(q, k, v, causal=True))
+        h, _ = ollm.decoder_layer(h, lp, cfg, freqs,
+                                  lambda q, k, v: core_attention(q, k, v, causal=True, cu_seqlens=cu))
     h = glue.rmsnorm(h, p["final_ln"], cfg.eps)                               # [S, 1, hidden]
     losses = []
     for r in range(cp_size):

@@ -256,3 +256,25 @@ def test_decode_loop_host_rules():
     assert picks <= {1, 3} and len(picks) == 2
     picks = {int(gen._sample_strategy(logits, do_sample=True, top_p=0.3)[1]) for _ in range(20)}
     assert picks == {1}                                                       # nucleus keeps the top token only
+
+
+def test_packed_segments_from_position_ids():
+    """Packed samples are recognised the way the reference's GPU path does it (non-monotonic position ids, cu_seqlens at
+    their zeros) and turned into per-row segment bounds."""
+    from long_vita_amd import ops, training_utils as tu
+    cuts, S = [0, 5, 6, 20], 32
+    pos = torch.cat([torch.arange(b - a) for a, b in zip(cuts, cuts[1:] + [S])])
+    try:
+        tu.set_position_ids(pos[:, None])
+        start, end = tu.get_packed_segments()
+        want_start = [max(c for c in cuts if c <= i) for i in range(S)]
+        want_end = [min(c for c in cuts[1:] + [S] if c > i) for i in range(S)]
+        assert start.tolist() == want_start and end.tolist() == want_end and start.dtype == torch.int32
+        tu.set_position_ids(torch.arange(S)[:, None])
+        assert tu.get_packed_segments() is None                       # monotonic ids: one sample
+        tu.set_position_ids(None)
+        assert tu.get_packed_segments() is None
+    finally:
+        tu.set_position_ids(None)
+    s2, e2 = ops.segments_from_cu_seqlens(torch.tensor([0, 10, 25]), 32)   # tail rows form their own segment
+    assert s2.tolist() == [0] * 10 + [10] * 15 + [25] * 7 and e2.tolist() == [10] * 10 + [25] * 15 + [32] * 7

@@ -347,3 +347,38 @@ def test_vit_front_back_kernels(ops):
     t = glue.pixel_shuffle(xr[:, 1:].reshape(2, 32, 32, -1), 0.5).reshape(2, 256, 4096)
     yr = torch.nn.functional.layer_norm(t.float(), (4096,), p["proj_ln_w"].float(), p["proj_ln_b"].float(), 1e-5).bfloat16()
     assert bf16_ulp_diff(y, yr) <= 1
+
+
+# ---------------------------------------------------------------------------------------------
+# packed sequences: block-diagonal causal attention, forward and backward
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("S,cu", [(1024, [0, 300, 301, 777, 1024]), (2048, [0, 2048]), (1536, [0, 64, 128, 900]),
+                                  (512, [0, 255, 256, 257, 512])])
+def test_flash_attn_packed_sequences_fwd_bwd(ops, S, cu):
+    from oracle import attention as oattn
+    Hq, Hkv, D = 10, 2, 128
+    g = torch.Generator().manual_seed(S + len(cu))
+    q = (torch.randn(S, 1, Hq, D, generator=g) * 0.5).bfloat16()
+    k = (torch.randn(S, 1, Hkv, D, generator=g) * 0.5).bfloat16()
+    v = (torch.randn(S, 1, Hkv, D, generator=g) * 0.5).bfloat16()
+    d_o = (torch.randn(S, 1, Hq * D, generator=g) * 0.1).bfloat16()
+    cu_t = torch.tensor(cu, dtype=torch.int32)
+    cu_full = cu_t if cu[-1] == S else torch.cat([cu_t, torch.tensor([S], dtype=torch.int32)])   # tail = its own sample
+    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    ref = oattn.core_attention(qf, kf, vf, causal=True, cu_seqlens=cu_full)
+    ref.backward(d_o.float())
+    seg_start, seg_end = ops.segments_from_cu_seqlens(cu_t.to(DEV), S)
+    assert seg_start.tolist() == [max(c for c in cu_full.tolist() if c <= i) for i in range(S)]
+    qd, kd, vd = (t.permute(1, 0, 2, 3).contiguous().to(DEV) for t in (q, k, v))          # [1, S, H, D]
+    out, lse = ops.flash_attn(qd, kd, vd, causal=True, return_lse=True, seg_start=seg_start)
+    assert rel_l2(out.reshape(S, -1), ref.detach().reshape(S, -1)) < 1.2e-2
+    # rows that start a sample attend to themselves only: output == their own V (GQA: head h uses kv head h // 5)
+    for r in [c for c in cu_full.tolist()[:-1]]:
+        want = vd[0, r].repeat_interleave(Hq // Hkv, dim=0)
+        assert rel_l2(out[0, r], want) < 1e-2
+    if S % 128 == 0:
+        dod = d_o.view(S, Hq, D)[None].contiguous().to(DEV)
+        dq, dk, dv = ops.flash_attn_bwd(qd, kd, vd, out, dod, lse, seg_start=seg_start, seg_end=seg_end)
+        assert rel_l2(dq[0], qf.grad[:, 0]) < 2.5e-2
+        assert rel_l2(dk[0], kf.grad[:, 0]) < 2.5e-2
+        assert rel_l2(dv[0], vf.grad[:, 0]) < 2.5e-2

@@ -188,3 +188,26 @@ def test_train_step_with_projector(amd):
     _check_grads(g, g_ref, 5e-2)
     for k in proj_keys:
         assert rel_l2(g["projector"][k], g_ref[k]) < 6e-2, (k, rel_l2(g["projector"][k], g_ref[k]))
+
+
+def test_train_step_packed_samples_vs_autograd(amd):
+    """Stage-2 packing (--reset-position-ids): three samples in one 1024-token row.  RoPE restarts per sample and the
+    attention is block-diagonal, forward and backward; the same model without the resets gives a
+    different loss, so the test would notice a mask that is silently ignored."""
+    S = 1024
+    ocfg = ollm.LLMConfig(**SMALL)
+    p = ollm.init_llm_params(ocfg, seed=3)
+    tokens, labels, loss_mask = _data(S, SMALL["vocab"], 120, 9)
+    loss_mask[0, 300:340] = 1
+    cuts = [0, 333, 334, 801]                                         # sample starts (one sample of length 1)
+    position_ids = torch.cat([torch.arange(b - a) for a, b in zip(cuts, cuts[1:] + [S])])[None]
+    loss_ref, g_ref = otrain.loss_and_grads(tokens, labels, loss_mask, p, ocfg, position_ids=position_ids)
+    loss_plain, _ = otrain.loss_and_grads(tokens, labels, loss_mask, p, ocfg)
+    assert abs(float(loss_ref) - float(loss_plain)) > 1e-4
+    model = amd["gpt"].GPTVLModel.from_oracle_layout(amd["gpt"].GPTConfig(**SMALL), p, None, DEV)
+    step = amd["train"].TrainStep(model)
+    loss, g = step.forward_backward(tokens.to(DEV), labels.to(DEV), loss_mask.to(DEV), position_ids=position_ids.to(DEV))
+    assert abs(float(loss) - float(loss_ref)) < 2e-2 * abs(float(loss_ref))
+    _check_grads(g, g_ref, 4e-2)
+    from long_vita_amd import training_utils
+    assert training_utils.get_position_ids() is None                  # the global does not leak out of the step
