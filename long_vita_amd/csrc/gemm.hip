@@ -51,6 +51,98 @@ __device__ __forceinline__ int tile_off(int row, int slot) {
   return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
 }
 
+// ---- epilogue shared by the tile kernels: lane holds D^T: row m = ... + (lane & 31), columns 8*rg + 4*(lane>>5) + 0..3 --
+template <int EPI, int MI, int NI, int TM, int TN>
+__device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[NI][MI], int64_t m0, int64_t n0, int wm,
+                                              int wn, int lane) {
+  const int hi = lane >> 5;
+#pragma unroll
+  for (int mi = 0; mi < MI; ++mi) {
+    const int64_t m = m0 + wm * TM + mi * 32 + (lane & 31);
+    if (m >= p.M) continue;
+    if (EPI == VITA_EPI_SWIGLU) {
+      // the wave's tile rows of W = NI/2 x [gate 32 | up 32]; pair pi -> output columns n0 + (wn*NI/2 + pi)*32 + 0..31
+#pragma unroll
+      for (int pi = 0; pi < NI / 2; ++pi) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int64_t n = n0 + (wn * (NI / 2) + pi) * 32 + rg * 8 + hi * 4;
+          if (n >= p.N) continue;
+          float o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float g = bf16_round(acc[2 * pi][mi][rg * 4 + j]);
+            const float u = bf16_round(acc[2 * pi + 1][mi][rg * 4 + j]);
+            const float s = bf16_round(g / (1.0f + __expf(-g)));
+            o[j] = s * u;
+          }
+          bf16_t* dst = p.C + m * p.ldc + n;
+          if (n + 3 < p.N) {
+            u32x2 v = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+            *reinterpret_cast<u32x2*>(dst) = v;
+          } else {
+            for (int j = 0; j < 4 && n + j < p.N; ++j) dst[j] = f32_to_bf16(o[j]);
+          }
+        }
+      }
+    } else {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni) {
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int64_t n = n0 + wn * TN + ni * 32 + rg * 8 + hi * 4;
+          if (n >= p.N) continue;
+          const bool full = n + 3 < p.N;
+          float o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = acc[ni][mi][rg * 4 + j];
+          if (EPI != VITA_EPI_NONE && p.bias) {
+            if (full) {
+              const u32x2 b = *reinterpret_cast<const u32x2*>(p.bias + n);
+              o[0] += bf16lo_to_f32(b[0]); o[1] += bf16hi_to_f32(b[0]);
+              o[2] += bf16lo_to_f32(b[1]); o[3] += bf16hi_to_f32(b[1]);
+            } else {
+              for (int j = 0; j < 4 && n + j < p.N; ++j) o[j] += bf16_to_f32(p.bias[n + j]);
+            }
+          }
+          if (EPI == VITA_EPI_BIAS_GELU) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = gelu_erf(bf16_round(o[j]));
+          }
+          if (EPI == VITA_EPI_BIAS_SCALE_RES) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              const int64_t nn = (n + j < p.N) ? n + j : p.N - 1;
+              o[j] = bf16_round(bf16_round(o[j]) * bf16_to_f32(p.scale[nn]));
+            }
+          }
+          if (EPI == VITA_EPI_RESIDUAL || EPI == VITA_EPI_BIAS_SCALE_RES) {
+            const bf16_t* rsrc = p.R + m * p.ldr + n;
+            if (EPI == VITA_EPI_RESIDUAL) {
+#pragma unroll
+              for (int j = 0; j < 4; ++j) o[j] = bf16_round(o[j]);
+            }
+            if (full) {
+              const u32x2 rv = *reinterpret_cast<const u32x2*>(rsrc);
+              o[0] += bf16lo_to_f32(rv[0]); o[1] += bf16hi_to_f32(rv[0]);
+              o[2] += bf16lo_to_f32(rv[1]); o[3] += bf16hi_to_f32(rv[1]);
+            } else {
+              for (int j = 0; j < 4 && n + j < p.N; ++j) o[j] += bf16_to_f32(rsrc[j]);
+            }
+          }
+          bf16_t* dst = p.C + m * p.ldc + n;
+          if (full) {
+            u32x2 v = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+            *reinterpret_cast<u32x2*>(dst) = v;
+          } else {
+            for (int j = 0; j < 4 && n + j < p.N; ++j) dst[j] = f32_to_bf16(o[j]);
+          }
+        }
+      }
+    }
+  }
+}
+
 // One workgroup = WM x WN waves = one BM x BN output tile; each wave owns (BM/WM) x (BN/WN).
 //   <128,128,2,2>: 4 waves, 64 KiB LDS, 2 workgroups per CU (small / ragged problems)
 //   <256,256,2,4>: 8 waves, 128 KiB LDS, per-wave tile 128 x 64 -> 0.75 LDS fragment reads and
@@ -194,93 +286,7 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 256 && WM * WN == 4) ? 1 : 2) 
     __syncthreads();
   }
 
-  // ---- epilogue: lane holds D^T: row m = ... + (lane & 31), columns 8*rg + 4*(lane>>5) + 0..3 --
-  const int hi = lane >> 5;
-#pragma unroll
-  for (int mi = 0; mi < MI; ++mi) {
-    const int64_t m = m0 + wm * TM + mi * 32 + (lane & 31);
-    if (m >= p.M) continue;
-    if (EPI == VITA_EPI_SWIGLU) {
-      // the wave's tile rows of W = NI/2 x [gate 32 | up 32]; pair pi -> output columns n0 + (wn*NI/2 + pi)*32 + 0..31
-#pragma unroll
-      for (int pi = 0; pi < NI / 2; ++pi) {
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const int64_t n = n0 + (wn * (NI / 2) + pi) * 32 + rg * 8 + hi * 4;
-          if (n >= p.N) continue;
-          float o[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float g = bf16_round(acc[2 * pi][mi][rg * 4 + j]);
-            const float u = bf16_round(acc[2 * pi + 1][mi][rg * 4 + j]);
-            const float s = bf16_round(g / (1.0f + __expf(-g)));
-            o[j] = s * u;
-          }
-          bf16_t* dst = p.C + m * p.ldc + n;
-          if (n + 3 < p.N) {
-            u32x2 v = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-            *reinterpret_cast<u32x2*>(dst) = v;
-          } else {
-            for (int j = 0; j < 4 && n + j < p.N; ++j) dst[j] = f32_to_bf16(o[j]);
-          }
-        }
-      }
-    } else {
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni) {
-#pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const int64_t n = n0 + wn * TN + ni * 32 + rg * 8 + hi * 4;
-          if (n >= p.N) continue;
-          const bool full = n + 3 < p.N;
-          float o[4];
-#pragma unroll
-          for (int j = 0; j < 4; ++j) o[j] = acc[ni][mi][rg * 4 + j];
-          if (EPI != VITA_EPI_NONE && p.bias) {
-            if (full) {
-              const u32x2 b = *reinterpret_cast<const u32x2*>(p.bias + n);
-              o[0] += bf16lo_to_f32(b[0]); o[1] += bf16hi_to_f32(b[0]);
-              o[2] += bf16lo_to_f32(b[1]); o[3] += bf16hi_to_f32(b[1]);
-            } else {
-              for (int j = 0; j < 4 && n + j < p.N; ++j) o[j] += bf16_to_f32(p.bias[n + j]);
-            }
-          }
-          if (EPI == VITA_EPI_BIAS_GELU) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = gelu_erf(bf16_round(o[j]));
-          }
-          if (EPI == VITA_EPI_BIAS_SCALE_RES) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int64_t nn = (n + j < p.N) ? n + j : p.N - 1;
-              o[j] = bf16_round(bf16_round(o[j]) * bf16_to_f32(p.scale[nn]));
-            }
-          }
-          if (EPI == VITA_EPI_RESIDUAL || EPI == VITA_EPI_BIAS_SCALE_RES) {
-            const bf16_t* rsrc = p.R + m * p.ldr + n;
-            if (EPI == VITA_EPI_RESIDUAL) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) o[j] = bf16_round(o[j]);
-            }
-            if (full) {
-              const u32x2 rv = *reinterpret_cast<const u32x2*>(rsrc);
-              o[0] += bf16lo_to_f32(rv[0]); o[1] += bf16hi_to_f32(rv[0]);
-              o[2] += bf16lo_to_f32(rv[1]); o[3] += bf16hi_to_f32(rv[1]);
-            } else {
-              for (int j = 0; j < 4 && n + j < p.N; ++j) o[j] += bf16_to_f32(rsrc[j]);
-            }
-          }
-          bf16_t* dst = p.C + m * p.ldc + n;
-          if (full) {
-            u32x2 v = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-            *reinterpret_cast<u32x2*>(dst) = v;
-          } else {
-            for (int j = 0; j < 4 && n + j < p.N; ++j) dst[j] = f32_to_bf16(o[j]);
-          }
-        }
-      }
-    }
-  }
+  gemm_epilogue<EPI, MI, NI, TM, TN>(p, acc, m0, n0, wm, wn, lane);
 }
 
 // ---- skinny-M (M <= 16): one wave per output column, x rows cached in LDS ------------------
