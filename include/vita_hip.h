@@ -329,6 +329,11 @@ int vita_decode_attn_merge(const void* part_m, const void* part_l, const void* p
                            int64_t part_ml_stride, int64_t part_o_stride, int heads, int head_dim, void* out_m, void* out_l, void* out_o,
                            void* out_bf16, void* stream);
 
+/* out[n] = bf16(a[n] + b[n]) (n % 8 == 0): the residual add that follows the tensor-parallel all-reduce of a
+ * row-parallel linear's output (RowParallelLinear + bias_dropout_add, TP > 1 only; at TP = 1 the add is the GEMM's
+ * RESIDUAL epilogue). */
+int vita_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
+
 /* One decoder layer for one token, launched from C: vita_decode_layer_attn = RMSNorm (fused into the
  * GEMV) + QKV GEMV + bias -> RoPE + K/V append -> decode attention partial -> merge; vita_decode_layer_mlp
  * = [merge of the CP ranks' partials] -> o-proj GEMV + residual -> RMSNorm + fc1 GEMV + SwiGLU -> fc2 GEMV

@@ -398,6 +398,19 @@ __global__ __launch_bounds__(256) void attn_delta_kernel(const bf16_t* __restric
   if (lane == 0) delta[(int64_t)h * rows + row] = s;
 }
 
+// out = bf16(a + b): the residual add behind a tensor-parallel all-reduce (bias_dropout_add with bias None, p = 0)
+__global__ __launch_bounds__(256) void add_bf16_kernel(const u32x4* __restrict__ a, const u32x4* __restrict__ b,
+                                                       u32x4* __restrict__ out, int64_t n8) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const u32x4 x = a[i], y = b[i];
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      o[j] = pack_bf16x2(bf16lo_to_f32(x[j]) + bf16lo_to_f32(y[j]), bf16hi_to_f32(x[j]) + bf16hi_to_f32(y[j]));
+    out[i] = o;
+  }
+}
+
 }  // namespace
 
 extern "C" int vita_transpose_bf16(const void* src, int64_t ld_src, void* dst, int64_t ld_dst,
@@ -422,6 +435,15 @@ extern "C" int vita_rmsnorm_bwd(const void* dy, const void* x, const void* w, co
 #define VITA_RB(V) hipLaunchKernelGGL(rmsnorm_bwd_kernel<V>, grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)res, (bf16_t*)dx, dw_acc, rows, cols, eps)
   if (vpl <= 2) VITA_RB(2); else if (vpl <= 4) VITA_RB(4); else if (vpl <= 8) VITA_RB(8); else if (vpl <= 10) VITA_RB(10); else VITA_RB(16);
 #undef VITA_RB
+  return vita_check_launch();
+}
+
+extern "C" int vita_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream) {
+  if (!a || !b || !out || n < 0) return VITA_ERR_INVALID_ARG;
+  if (n & 7) return VITA_ERR_UNSUPPORTED;
+  if (n == 0) return VITA_OK;
+  hipLaunchKernelGGL(add_bf16_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const u32x4*)a,
+                     (const u32x4*)b, (u32x4*)out, n / 8);
   return vita_check_launch();
 }
 

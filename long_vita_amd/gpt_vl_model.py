@@ -139,11 +139,26 @@ class GPTVLModel:
                 ev[1].record()
         if ev:
             self.attn_events.append(ev)
-        ops.gemm(ctx.view(s, c.heads * c.head_dim), lp["o_w"], ops.EPI_RESIDUAL, residual=h, out=h)
+        tp = mpu.get_tensor_model_parallel_world_size()
+        if tp == 1:
+            ops.gemm(ctx.view(s, c.heads * c.head_dim), lp["o_w"], ops.EPI_RESIDUAL, residual=h, out=h)
+        else:       # row-parallel: partial sums over the rank's heads -> bf16 all-reduce -> residual add
+            self._row_parallel(ctx.view(s, c.heads * c.head_dim), lp["o_w"], h, ws["x"])
         x = ops.rmsnorm(h, lp["ln2"], c.eps, out=ws["x"])
         act = ops.gemm(x, lp["fc1_w"], ops.EPI_SWIGLU, out=ws["act"])
-        ops.gemm(act, lp["fc2_w"], ops.EPI_RESIDUAL, residual=h, out=h)
+        if tp == 1:
+            ops.gemm(act, lp["fc2_w"], ops.EPI_RESIDUAL, residual=h, out=h)
+        else:
+            self._row_parallel(act, lp["fc2_w"], h, ws["x"])
         return h
+
+    @staticmethod
+    def _row_parallel(x: torch.Tensor, w: torch.Tensor, h: torch.Tensor, scratch: torch.Tensor) -> torch.Tensor:
+        """h += all_reduce_TP(x @ w^T)  (RowParallelLinear.forward + bias_dropout_add, M/core/tensor_parallel/layers.py)."""
+        import torch.distributed as dist
+        part = ops.gemm(x, w, ops.EPI_NONE, out=scratch)
+        dist.all_reduce(part, group=mpu.get_tensor_model_parallel_group())
+        return ops.add_(h, part)
 
     # ---------------------------------------------------------------------------------------------
     def forward(self, input_ids: torch.Tensor, position_ids: Optional[torch.Tensor] = None, attention_mask=None,
@@ -162,6 +177,8 @@ class GPTVLModel:
                 logit_mask = ip.logit_mask
             if hasattr(ip, "use_kv_cache") and not ip.use_kv_cache:                                  # :285-286
                 ip = None
+        if ip is not None and mpu.get_tensor_model_parallel_world_size() > 1:
+            raise NotImplementedError("the KV-cache decode path is not tensor-parallel")
         if ip is not None and ip.key_value_memory_dict:
             return self._decode_forward(input_ids, position_ids, ip)
         if decoder_input is None:                                                         # :252-277
@@ -197,9 +214,21 @@ class GPTVLModel:
             rows, sel_mask = h, None
         rows = ops.rmsnorm(rows, self.p["final_ln"], self.cfg.eps)
         logits, _ = self.output_layer(rows.view(rows.shape[0], 1, hdim), weight=None, logit_mask=sel_mask)   # :339
+        logits = self._gather_vocab_parallel(logits)
         if bool(torch.isnan(logits.float().sum())):                                       # :393-396
             raise ValueError("found NaN in local forward logits calculation")
         return logits.transpose(0, 1).contiguous()                                        # [s b v] -> [b s v] :370
+
+    @staticmethod
+    def _gather_vocab_parallel(logits: torch.Tensor) -> torch.Tensor:
+        """[..., V/TP] per rank -> [..., V] (gather_from_tensor_model_parallel_region of the vocab-parallel output layer)."""
+        tp = mpu.get_tensor_model_parallel_world_size()
+        if tp == 1:
+            return logits
+        import torch.distributed as dist
+        flat = torch.empty((tp,) + tuple(logits.shape), dtype=logits.dtype, device=logits.device)
+        dist.all_gather_into_tensor(flat.view(-1), logits.contiguous().view(-1), group=mpu.get_tensor_model_parallel_group())
+        return flat.movedim(0, -2).reshape(*logits.shape[:-1], tp * logits.shape[-1])
 
     __call__ = forward
 

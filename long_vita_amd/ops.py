@@ -597,3 +597,12 @@ def segments_from_cu_seqlens(cu_seqlens: torch.Tensor, total: int):
     start = torch.repeat_interleave(cu[:-1], lens).to(torch.int32)
     end = torch.repeat_interleave(cu[1:], lens).to(torch.int32)
     return start.contiguous(), end.contiguous()
+
+
+def add_(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
+    """a = bf16(a + b) in place (residual add behind a tensor-parallel all-reduce)."""
+    if a.shape != b.shape or not a.is_contiguous() or not b.is_contiguous():
+        raise ValueError("add_: contiguous tensors of equal shape")
+    _L.check(_L.load().vita_add_bf16(_dev(a, "a", BF16), _dev(b, "b", BF16), _dev(a, "a", BF16), a.numel(), _stream()),
+             "vita_add_bf16")
+    return a

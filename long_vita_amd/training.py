@@ -47,6 +47,13 @@ def _wgrad(dy_t: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return ops.gemm(dy_t, _t(x))
 
 
+def _tp_sum(t: torch.Tensor) -> torch.Tensor:
+    """Input gradient of a column-parallel linear: summed over the tensor-parallel group (layers.py:467-469)."""
+    if mpu.get_tensor_model_parallel_world_size() > 1:
+        dist.all_reduce(t, group=mpu.get_tensor_model_parallel_group())
+    return t
+
+
 def _pad_rows(x: torch.Tensor, mult: int = 64) -> torch.Tensor:
     m = x.shape[0]
     if m % mult == 0:
@@ -85,7 +92,11 @@ class TrainStep:
         ctx, lse = ops.flash_attn(q5, k_all, v_all, causal=True, return_lse=True, seg_start=None if seg is None else seg[0],
                                   **geo)
         ctx2 = ctx.view(s, c.heads * c.head_dim)
-        h_mid = ops.gemm(ctx2, lp["o_w"], ops.EPI_RESIDUAL, residual=h)
+        tp = mpu.get_tensor_model_parallel_world_size()
+        if tp == 1:
+            h_mid = ops.gemm(ctx2, lp["o_w"], ops.EPI_RESIDUAL, residual=h)
+        else:
+            h_mid = m._row_parallel(ctx2, lp["o_w"], h.clone(), torch.empty_like(h))
         x2 = ops.rmsnorm(h_mid, lp["ln2"], c.eps)
         y = ops.gemm(x2, lp["fc1_w"])                      # unfused: the backward needs gate / up
         act = ops.swiglu(y)
@@ -122,7 +133,7 @@ class TrainStep:
         del d_act
         dy_t = _t(dy)
         g["fc1_w"] = _wgrad(dy_t, a["x2"])
-        dx2 = _dgrad(dy, lp["fc1_w"])
+        dx2 = _tp_sum(_dgrad(dy, lp["fc1_w"]))
         del dy, dy_t
         dln2 = f32(c.hidden)
         dh_mid = ops.rmsnorm_bwd(dx2, a["h_mid"], lp["ln2"], c.eps, dln2, residual=dh)
@@ -154,7 +165,7 @@ class TrainStep:
         # grad_bias = grad_output.sum(dim=0) (layers.py:524) as a GEMM against a block of ones
         ones = torch.ones(4, s, dtype=h.dtype, device=h.device)
         g["qkv_b"] = ops.gemm(dm_t, ones)[:, 0].contiguous()
-        dx1 = _dgrad(d_mixed, lp["qkv_w"])
+        dx1 = _tp_sum(_dgrad(d_mixed, lp["qkv_w"]))
         dln1 = f32(c.hidden)
         dh_in = ops.rmsnorm_bwd(dx1, h, lp["ln1"], c.eps, dln1, residual=dh_mid)
         g["ln1"] = dln1
@@ -215,7 +226,9 @@ class TrainStep:
         rows = ops.row_gather(h, idx)
         hn = ops.rmsnorm(rows, m.p["final_ln"], c.eps)
         hn_p = _pad_rows(hn)
-        logits = ops.gemm(hn_p, m.p["lm_head"])                      # [n_sel (padded), V]
+        tp, tp_rank = mpu.get_tensor_model_parallel_world_size(), mpu.get_tensor_model_parallel_rank()
+        logits_local = ops.gemm(hn_p, m.p["lm_head"])                # [n_sel (padded), V / TP]
+        logits = m._gather_vocab_parallel(logits_local).contiguous() # [n_sel (padded), V]
         # labels of the selected rows (masked_select, gpt_vl_model.py:380-382); 16-byte rows for the gather
         lab_sel = ops.row_gather(lab.reshape(-1, 1).repeat(1, 2).contiguous(), idx)[:, 0]
         # instruction shift (gpt_vl_model.py:389-391): logits[:-1] vs labels[1:]
@@ -239,8 +252,11 @@ class TrainStep:
 
         # ---- backward ------------------------------------------------------------------------------
         grads = {"layers": [dict() for _ in m.p["layers"]]}
-        grads["lm_head"] = ops.gemm(_t(dlogits), _t(hn_p))              # [V, hidden]
-        d_hn = _dgrad(dlogits, m.p["lm_head"])[:n_sel]
+        if tp > 1:      # this rank's vocabulary slice of dlogits
+            v_l = logits_local.shape[1]
+            dlogits = dlogits[:, tp_rank * v_l: (tp_rank + 1) * v_l].contiguous()
+        grads["lm_head"] = ops.gemm(_t(dlogits), _t(hn_p))              # [V / TP, hidden]
+        d_hn = _tp_sum(_dgrad(dlogits, m.p["lm_head"]))[:n_sel]
         dfl = torch.zeros(c.hidden, dtype=torch.float32, device=h.device)
         d_rows = ops.rmsnorm_bwd(d_hn.contiguous(), rows, m.p["final_ln"], c.eps, dfl)
         grads["final_ln"] = dfl

@@ -278,3 +278,58 @@ def test_packed_segments_from_position_ids():
         tu.set_position_ids(None)
     s2, e2 = ops.segments_from_cu_seqlens(torch.tensor([0, 10, 25]), 32)   # tail rows form their own segment
     assert s2.tolist() == [0] * 10 + [10] * 15 + [25] * 7 and e2.tolist() == [10] * 10 + [25] * 15 + [32] * 7
+
+
+_TPCP_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["VITA_ROOT"])
+from long_vita_amd import parallel_state as mpu
+dist.init_process_group("gloo", rank=int(os.environ["RANK"]), world_size=int(os.environ["WORLD_SIZE"]))
+mpu.initialize_model_parallel(tensor_model_parallel_size=2)          # world 4 -> TP 2 x CP 2, TP ranks adjacent
+me = dist.get_rank()
+assert (mpu.get_tensor_model_parallel_world_size(), mpu.get_context_parallel_world_size()) == (2, 2)
+assert mpu.get_tensor_model_parallel_rank() == me % 2 and mpu.get_context_parallel_rank() == me // 2
+t = torch.tensor([float(me)])
+dist.all_reduce(t, group=mpu.get_tensor_model_parallel_group())
+assert t.item() == {0: 1.0, 1: 1.0, 2: 5.0, 3: 5.0}[me]                # {0,1} and {2,3}
+c = torch.tensor([float(me)])
+dist.all_reduce(c, group=mpu.get_context_parallel_group())
+assert c.item() == {0: 2.0, 2: 2.0, 1: 4.0, 3: 4.0}[me]                # {0,2} and {1,3}
+dist.barrier()
+dist.destroy_process_group()
+print("OK", me)
+"""
+
+
+def test_tensor_x_context_parallel_groups_gloo_world4(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_TPCP_WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(4):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE="4", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), VITA_ROOT=ROOT)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    for p in procs:
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0 and "OK" in out, out
+
+
+def test_tensor_parallel_shards_roundtrip():
+    from long_vita_amd import tensor_parallel as tpar
+    from oracle import llm as ollm
+    cfg = ollm.LLMConfig(num_layers=2, hidden=256, heads=8, kv_groups=4, head_dim=32, ffn=512, vocab=320)
+    p = ollm.init_llm_params(cfg, seed=2)
+    shards = [tpar.shard_llm_params(p, cfg, 2, r) for r in range(2)]
+    assert shards[0][1].heads == 4 and shards[0][1].kv_groups == 2 and shards[0][1].ffn == 256
+    full = tpar.unshard_llm_grads([s[0] for s in shards], cfg, 2)
+    for k in ("embed", "final_ln", "lm_head"):
+        assert torch.equal(full[k], p[k])
+    for a, b in zip(full["layers"], p["layers"]):
+        assert all(torch.equal(a[k], b[k]) for k in b)
+    # the shards compute the same function: column-parallel qkv rows are whole kv groups, fc1 keeps gate / up pairing
+    x = torch.randn(5, 256)
+    y_full = torch.nn.functional.silu(x @ p["layers"][0]["fc1_w"].float()[:512].T) * (x @ p["layers"][0]["fc1_w"].float()[512:].T)
+    y_sh = torch.cat([torch.nn.functional.silu(x @ s[0]["layers"][0]["fc1_w"].float()[:256].T)
+                      * (x @ s[0]["layers"][0]["fc1_w"].float()[256:].T) for s in shards], dim=1)
+    torch.testing.assert_close(y_sh, y_full)

@@ -211,3 +211,126 @@ def test_train_step_packed_samples_vs_autograd(amd):
     _check_grads(g, g_ref, 4e-2)
     from long_vita_amd import training_utils
     assert training_utils.get_position_ids() is None                  # the global does not leak out of the step
+
+
+# ---------------------------------------------------------------------------------------------
+# tensor parallelism (BASELINE config 5: TP x CP), simulated ranks: world rank = cp_rank * TP + tp_rank
+# ---------------------------------------------------------------------------------------------
+class _Group2D:
+    """Fake process group: `size` threads rendezvous; `my_rank()` tells a member its rank inside the group."""
+
+    def __init__(self, size, my_rank):
+        self.size, self.my_rank, self.slots, self.barrier = size, my_rank, {}, threading.Barrier(size)
+
+
+def _run_grid(tp, cp, fn, amd, monkeypatch):
+    import torch.distributed as dist
+    mpu = amd["mpu"]
+    tp_groups = [_Group2D(tp, mpu.get_tensor_model_parallel_rank) for _ in range(cp)]
+    cp_groups = [_Group2D(cp, mpu.get_context_parallel_rank) for _ in range(tp)]
+
+    def rendezvous(grp, inp):
+        r = grp.my_rank()
+        grp.slots[r] = inp
+        grp.barrier.wait()
+        vals = [grp.slots[q] for q in range(grp.size)]
+        grp.barrier.wait()
+        return r, vals
+
+    def all_gather_into_tensor(out, inp, group=None, async_op=False):
+        _, vals = rendezvous(group, inp)
+        flat = out.view(group.size, -1)
+        for q, v in enumerate(vals):
+            flat[q].copy_(v.reshape(-1))
+
+    def reduce_scatter_tensor(out, inp, group=None, async_op=False, op=None):
+        r, vals = rendezvous(group, inp)
+        out.view(-1).copy_(sum(v.view(group.size, -1)[r].float() for v in vals).to(out.dtype))
+        group.barrier.wait()
+
+    def all_reduce(t, group=None, op=None, async_op=False):
+        _, vals = rendezvous(group, t.clone())
+        if t.dtype == torch.bfloat16:                       # RCCL sums bf16 in bf16: pairwise, rounded
+            acc = vals[0]
+            for v in vals[1:]:
+                acc = acc + v
+            t.copy_(acc)
+        else:
+            t.copy_(sum(v.float() for v in vals).to(t.dtype))
+        group.barrier.wait()
+
+    monkeypatch.setattr(dist, "all_gather_into_tensor", all_gather_into_tensor)
+    monkeypatch.setattr(dist, "reduce_scatter_tensor", reduce_scatter_tensor)
+    monkeypatch.setattr(dist, "all_reduce", all_reduce)
+    results, errors = {}, []
+
+    def worker(ci, ti):
+        try:
+            torch.cuda.set_device(0)
+            mpu.set_context_parallel_state(cp, ci, cp_groups[ti])
+            mpu.set_tensor_parallel_state(tp, ti, tp_groups[ci])
+            results[(ci, ti)] = fn(ci, ti)
+        except BaseException as e:  # noqa: BLE001
+            errors.append(((ci, ti), e))
+            for g in tp_groups + cp_groups:
+                g.barrier.abort()
+
+    ts = [threading.Thread(target=worker, args=(ci, ti)) for ci in range(cp) for ti in range(tp)]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    if errors:
+        raise errors[0][1]
+    return results
+
+
+@pytest.mark.parametrize("tp,cp", [(2, 1), (2, 2)])
+def test_train_step_tensor_parallel(amd, monkeypatch, tp, cp):
+    """TP = 2 (x CP = 2): column / row-parallel shards, bf16 all-reduce of the row-parallel outputs and of the
+    column-parallel input gradients, vocab-parallel head with gathered logits == autograd over the unsharded model."""
+    from long_vita_amd import tensor_parallel as tpar
+    S = 1024
+    ocfg = ollm.LLMConfig(**SMALL)
+    p = ollm.init_llm_params(ocfg, seed=8)
+    tokens, labels, loss_mask = _data(S, SMALL["vocab"], 130, 4)
+    loss_ref, g_ref = otrain.loss_and_grads(tokens, labels, loss_mask, p, ocfg, cp_size=cp)
+    G = amd["gpt"]
+    full_cfg = G.GPTConfig(**SMALL)
+
+    def rank_fn(ci, ti):
+        shard, cfg_l = tpar.shard_llm_params(p, full_cfg, tp, ti)
+        m = G.GPTVLModel.from_oracle_layout(cfg_l, shard, None, DEV)
+        loss, g = amd["train"].TrainStep(m).forward_backward(tokens.to(DEV), labels.to(DEV), loss_mask.to(DEV))
+        amd["train"].allreduce_grads(g)                       # over the CP group
+        return loss, g
+
+    outs = _run_grid(tp, cp, rank_fn, amd, monkeypatch)
+    losses = {float(v[0]) for v in outs.values()}
+    assert len(losses) == 1                                    # every rank reports the same loss
+    assert abs(losses.pop() - float(loss_ref)) < 2e-2 * abs(float(loss_ref))
+    full = tpar.unshard_llm_grads([outs[(0, ti)][1] for ti in range(tp)], full_cfg, tp)
+    _check_grads(full, g_ref, 5e-2)
+    # replicated parameters get the same gradients on the TP ranks (fp32 atomics: equal up to summation order)
+    assert rel_l2(outs[(0, 0)][1]["final_ln"], outs[(0, 1)][1]["final_ln"]) < 1e-5
+    assert rel_l2(outs[(0, 0)][1]["embed"], outs[(0, 1)][1]["embed"]) < 1e-5
+
+
+def test_prefill_tensor_parallel(amd, monkeypatch):
+    """Inference with TP = 2: sharded decoder + gathered vocab-parallel logits == TP = 1."""
+    from long_vita_amd import generation, tensor_parallel as tpar
+    ocfg = ollm.LLMConfig(**SMALL)
+    p = ollm.init_llm_params(ocfg, seed=8)
+    G = amd["gpt"]
+    full_cfg = G.GPTConfig(**SMALL)
+    S = 768
+    tokens = torch.randint(0, SMALL["vocab"], (1, S), generator=torch.Generator().manual_seed(3)).to(DEV)
+    base = G.GPTVLModel.from_oracle_layout(full_cfg, p, None, DEV)
+    single = generation.prefill_step(base, tokens, S - 9, None, reference_compat=False)
+
+    def rank_fn(ci, ti):
+        shard, cfg_l = tpar.shard_llm_params(p, full_cfg, 2, ti)
+        m = G.GPTVLModel.from_oracle_layout(cfg_l, shard, None, DEV)
+        return generation.prefill_step(m, tokens, S - 9, None, reference_compat=False)
+
+    outs = _run_grid(2, 1, rank_fn, amd, monkeypatch)
+    assert torch.equal(outs[(0, 0)], outs[(0, 1)]) and outs[(0, 0)].shape == single.shape
+    assert rel_l2(outs[(0, 0)], single) < 1.5e-2
