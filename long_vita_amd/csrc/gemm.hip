@@ -41,6 +41,9 @@ struct GemmArgs {
   int tiles_m, tiles_n;
 };
 
+__device__ __forceinline__ float gelu_tanh(float x) {       // F.gelu(x, approximate="tanh")
+  return 0.5f * x * (1.0f + tanhf(0.79788456080286535588f * (x + 0.044715f * x * x * x)));
+}
 __device__ __forceinline__ float gelu_erf(float x) {
   return 0.5f * x * (1.0f + erff(x * 0.70710678118654752440f));
 }
@@ -96,6 +99,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[N
           float o[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] = acc[ni][mi][rg * 4 + j];
+          if (EPI == VITA_EPI_BIAS2_GELU_TANH || EPI == VITA_EPI_BIAS2_RES) {      // bias added to the ROUNDED product
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = bf16_round(o[j]);
+          }
           if (EPI != VITA_EPI_NONE && p.bias) {
             if (full) {
               const u32x2 b = *reinterpret_cast<const u32x2*>(p.bias + n);
@@ -109,6 +116,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[N
 #pragma unroll
             for (int j = 0; j < 4; ++j) o[j] = gelu_erf(bf16_round(o[j]));
           }
+          if (EPI == VITA_EPI_BIAS2_GELU_TANH) {
+#pragma unroll
+            for (int j = 0; j < 4; ++j) o[j] = gelu_tanh(bf16_round(o[j]));
+          }
           if (EPI == VITA_EPI_BIAS_SCALE_RES) {
 #pragma unroll
             for (int j = 0; j < 4; ++j) {
@@ -116,9 +127,9 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[N
               o[j] = bf16_round(bf16_round(o[j]) * bf16_to_f32(p.scale[nn]));
             }
           }
-          if (EPI == VITA_EPI_RESIDUAL || EPI == VITA_EPI_BIAS_SCALE_RES) {
+          if (EPI == VITA_EPI_RESIDUAL || EPI == VITA_EPI_BIAS_SCALE_RES || EPI == VITA_EPI_BIAS2_RES) {
             const bf16_t* rsrc = p.R + m * p.ldr + n;
-            if (EPI == VITA_EPI_RESIDUAL) {
+            if (EPI == VITA_EPI_RESIDUAL || EPI == VITA_EPI_BIAS2_RES) {
 #pragma unroll
               for (int j = 0; j < 4; ++j) o[j] = bf16_round(o[j]);
             }
@@ -402,6 +413,12 @@ extern "C" int vita_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
       if (!R || !scale || (ldr & 3)) return VITA_ERR_INVALID_ARG;
       return launch_gemm<VITA_EPI_BIAS_SCALE_RES>(a, st);
     case VITA_EPI_SWIGLU: return launch_gemm<VITA_EPI_SWIGLU>(a, st);
+    case VITA_EPI_BIAS2_GELU_TANH:
+      if (!bias) return VITA_ERR_INVALID_ARG;
+      return launch_gemm<VITA_EPI_BIAS2_GELU_TANH>(a, st);
+    case VITA_EPI_BIAS2_RES:
+      if (!bias || !R || (ldr & 3)) return VITA_ERR_INVALID_ARG;
+      return launch_gemm<VITA_EPI_BIAS2_RES>(a, st);
     default: return VITA_ERR_INVALID_ARG;
   }
 }

@@ -21,13 +21,13 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libvita_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "vita_hip.h")
 
-ABI_VERSION = 7
+ABI_VERSION = 8
 VITA_OK = 0
 VITA_ERR_INVALID_ARG = -1
 VITA_ERR_UNSUPPORTED = -2
 VITA_ERR_LAUNCH = -3
 
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_RESIDUAL, EPI_BIAS_SCALE_RES, EPI_SWIGLU = range(6)
+EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_RESIDUAL, EPI_BIAS_SCALE_RES, EPI_SWIGLU, EPI_BIAS2_GELU_TANH, EPI_BIAS2_RES = range(8)
 
 
 class VitaLibraryError(ImportError):

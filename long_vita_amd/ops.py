@@ -13,8 +13,8 @@ from typing import Optional, Sequence
 import torch
 
 from . import lib as _L
-from .lib import (EPI_BIAS, EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_NONE, EPI_RESIDUAL,  # noqa: F401
-                  EPI_SWIGLU, AttnParams)
+from .lib import (EPI_BIAS, EPI_BIAS2_GELU_TANH, EPI_BIAS2_RES, EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_NONE,  # noqa: F401
+                  EPI_RESIDUAL, EPI_SWIGLU, AttnParams)
 
 BF16 = torch.bfloat16
 

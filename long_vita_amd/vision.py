@@ -30,6 +30,26 @@ class VisionConfig:
     llm_hidden: int = 5120
     add_class_token: bool = True
     chunk_frames: int = 256            # forward_chunk, :522-533
+    # SigLIP-400M (get_vision_model_args_siglip_400m, :268-307): tanh GELU, no LayerScale, no class token, biases of
+    # linear_proj / fc1 / fc2 added unfused (Megatron local layer spec, vit_layer_specs.py:30-53)
+    activation: str = "gelu"
+    layerscale: bool = True
+    unfused_bias: bool = False
+
+    @classmethod
+    def siglip_400m(cls, **kw):
+        args = dict(num_layers=27, hidden=1152, heads=16, head_dim=72, ffn=4304, add_class_token=False,
+                    activation="gelu_tanh", layerscale=False, unfused_bias=True)
+        args.update(kw)
+        return cls(**args)
+
+    @property
+    def head_dim_pad(self):            # the flash kernel runs d = 64 / 128: other head sizes are zero-padded at load time
+        return self.head_dim if self.head_dim in (64, 128) else (64 if self.head_dim < 64 else 128)
+
+    @property
+    def ffn_pad(self):                 # fc2's K must be a multiple of the GEMM's BK = 64
+        return -(-self.ffn // 64) * 64
 
     @property
     def grid(self):
@@ -46,14 +66,39 @@ class MegatronVisionModel:
 
     @classmethod
     def from_oracle_layout(cls, cfg: VisionConfig, p: dict, device="cuda"):
-        """p: dict produced by oracle.vit.init_vit_params (plain tensors, Megatron layout)."""
+        """p: dict produced by oracle.vit.init_vit_params / checkpoint.hf_vit_to_params (plain tensors, Megatron layout).
+        Head size and FFN width are zero-padded to what the kernels tile (72 -> 128, 4304 -> 4352 for SigLIP): padded q / k
+        columns contribute 0 to the scores, padded v columns produce 0 context that meets zero proj_w columns, padded
+        fc1 rows give gelu(0) = 0 that meets zero fc2_w columns — the function is unchanged."""
         def d(t):
             return t.to(device=device, dtype=torch.bfloat16).contiguous()
-        conv = torch.zeros(cfg.hidden, cls.K_PAD, dtype=torch.bfloat16)
-        conv[:, :588] = p["conv_w"].reshape(cfg.hidden, 588).to(torch.bfloat16)
-        q = {"conv_w": d(conv), "conv_b": d(p["conv_b"]), "cls": d(p["cls"].reshape(-1)), "pos": d(p["pos"]),
+        h, nh, hd, hp, f, fp = cfg.hidden, cfg.heads, cfg.head_dim, cfg.head_dim_pad, cfg.ffn, cfg.ffn_pad
+        conv = torch.zeros(h, cls.K_PAD, dtype=torch.bfloat16)
+        conv[:, :588] = p["conv_w"].reshape(h, 588).to(torch.bfloat16)
+        q = {"conv_w": d(conv), "conv_b": d(p["conv_b"]), "pos": d(p["pos"]),
              "proj_ln_w": d(p["proj_ln_w"]), "proj_ln_b": d(p["proj_ln_b"]), "proj_fc1": d(p["proj_fc1"]),
-             "proj_fc2": d(p["proj_fc2"]), "layers": [{k: d(v) for k, v in lp.items()} for lp in p["layers"]]}
+             "proj_fc2": d(p["proj_fc2"]), "layers": []}
+        if cfg.add_class_token:
+            q["cls"] = d(p["cls"].reshape(-1))
+        for lp in p["layers"]:
+            o = {k: lp[k] for k in ("ln1_w", "ln1_b", "ln2_w", "ln2_b", "proj_b", "fc2_b")}
+            o["ls1"] = lp["ls1"] if cfg.layerscale else torch.ones(h)
+            o["ls2"] = lp["ls2"] if cfg.layerscale else torch.ones(h)
+            qkv_w = torch.zeros(nh, 3, hp, h, dtype=lp["qkv_w"].dtype)
+            qkv_w[:, :, :hd] = lp["qkv_w"].view(nh, 3, hd, h)
+            qkv_b = torch.zeros(nh, 3, hp, dtype=lp["qkv_b"].dtype)
+            qkv_b[:, :, :hd] = lp["qkv_b"].view(nh, 3, hd)
+            proj_w = torch.zeros(h, nh, hp, dtype=lp["proj_w"].dtype)
+            proj_w[:, :, :hd] = lp["proj_w"].view(h, nh, hd)
+            fc1_w = torch.zeros(fp, h, dtype=lp["fc1_w"].dtype)
+            fc1_w[:f] = lp["fc1_w"]
+            fc1_b = torch.zeros(fp, dtype=lp["fc1_b"].dtype)
+            fc1_b[:f] = lp["fc1_b"]
+            fc2_w = torch.zeros(h, fp, dtype=lp["fc2_w"].dtype)
+            fc2_w[:, :f] = lp["fc2_w"]
+            o.update(qkv_w=qkv_w.view(nh * 3 * hp, h), qkv_b=qkv_b.view(-1), proj_w=proj_w.view(h, nh * hp), fc1_w=fc1_w,
+                     fc1_b=fc1_b, fc2_w=fc2_w)
+            q["layers"].append({k: d(v) for k, v in o.items()})
         return cls(cfg, q)
 
     @classmethod
@@ -66,19 +111,18 @@ class MegatronVisionModel:
         def ones(n, v=1.0):
             return torch.full((n,), v, dtype=torch.bfloat16, device=device)
 
-        h = cfg.hidden
-        conv = rn(h, cls.K_PAD)
-        conv[:, 588:] = 0
+        h, hd_all = cfg.hidden, cfg.heads * cfg.head_dim
         seq = cfg.grid ** 2 + int(cfg.add_class_token)
-        p = {"conv_w": conv, "conv_b": rn(h), "cls": rn(h, s=1.0), "pos": rn(seq, h), "layers": [],
+        p = {"conv_w": rn(h, 3, cfg.patch, cfg.patch), "conv_b": rn(h), "cls": rn(h, s=1.0), "pos": rn(seq, h), "layers": [],
              "proj_ln_w": ones(4 * h), "proj_ln_b": ones(4 * h, 0.0), "proj_fc1": rn(h, 4 * h),
              "proj_fc2": rn(cfg.llm_hidden, h)}
         for _ in range(cfg.num_layers):
-            p["layers"].append({"ln1_w": ones(h), "ln1_b": ones(h, 0.0), "qkv_w": rn(3 * h, h), "qkv_b": rn(3 * h),
-                                "proj_w": rn(h, h), "proj_b": rn(h), "ls1": ones(h, 0.1),
+            p["layers"].append({"ln1_w": ones(h), "ln1_b": ones(h, 0.0), "qkv_w": rn(3 * hd_all, h), "qkv_b": rn(3 * hd_all),
+                                "proj_w": rn(h, hd_all), "proj_b": rn(h), "ls1": ones(h, 0.1),
                                 "ln2_w": ones(h), "ln2_b": ones(h, 0.0), "fc1_w": rn(cfg.ffn, h), "fc1_b": rn(cfg.ffn),
                                 "fc2_w": rn(h, cfg.ffn), "fc2_b": rn(h), "ls2": ones(h, 0.1)})
-        return cls(cfg, p)
+        p = {k: (v.cpu() if torch.is_tensor(v) else [{kk: vv.cpu() for kk, vv in lp.items()} for lp in v]) for k, v in p.items()}
+        return cls.from_oracle_layout(cfg, p, device)
 
     # -- InternViTModel.forward, intern_vit_model.py:190-261 ---------------------------------------
     def vit(self, images: torch.Tensor) -> torch.Tensor:
@@ -92,14 +136,26 @@ class MegatronVisionModel:
         del pe
         seq, h = x.shape[1], cfg.hidden
         x2 = x.view(n * seq, h)
-        for lp in p["layers"]:                                                           # InternViTTransformerLayer :32-89
+        hp = cfg.head_dim_pad
+        scale = 1.0 / (cfg.head_dim ** 0.5)                    # of the TRUE head size (padding adds zeros to q.k only)
+        epi_act = ops.EPI_BIAS2_GELU_TANH if cfg.activation == "gelu_tanh" else ops.EPI_BIAS_GELU
+        if cfg.unfused_bias != (cfg.activation == "gelu_tanh"):
+            raise NotImplementedError("built combinations: InternViT (fused bias, erf GELU), SigLIP (unfused bias, tanh GELU)")
+        for lp in p["layers"]:                    # InternViTTransformerLayer :32-89 / SigLIPViTTransformerLayer :29-86
             y = ops.layernorm(x2, lp["ln1_w"], lp["ln1_b"], cfg.ln_eps)
-            qkv = ops.gemm(y, lp["qkv_w"], ops.EPI_BIAS, lp["qkv_b"]).view(n, seq, cfg.heads, 3, cfg.head_dim)
-            ctx = ops.flash_attn(qkv[:, :, :, 0], qkv[:, :, :, 1], qkv[:, :, :, 2], causal=False)
-            ops.gemm(ctx.view(n * seq, h), lp["proj_w"], ops.EPI_BIAS_SCALE_RES, lp["proj_b"], lp["ls1"], x2, out=x2)
+            qkv = ops.gemm(y, lp["qkv_w"], ops.EPI_BIAS, lp["qkv_b"]).view(n, seq, cfg.heads, 3, hp)
+            ctx = ops.flash_attn(qkv[:, :, :, 0], qkv[:, :, :, 1], qkv[:, :, :, 2], causal=False, softmax_scale=scale)
+            ctx2 = ctx.view(n * seq, cfg.heads * hp)
+            if cfg.unfused_bias:
+                ops.gemm(ctx2, lp["proj_w"], ops.EPI_BIAS2_RES, lp["proj_b"], residual=x2, out=x2)
+            else:
+                ops.gemm(ctx2, lp["proj_w"], ops.EPI_BIAS_SCALE_RES, lp["proj_b"], lp["ls1"], x2, out=x2)
             y = ops.layernorm(x2, lp["ln2_w"], lp["ln2_b"], cfg.ln_eps, out=y)
-            f = ops.gemm(y, lp["fc1_w"], ops.EPI_BIAS_GELU, lp["fc1_b"])
-            ops.gemm(f, lp["fc2_w"], ops.EPI_BIAS_SCALE_RES, lp["fc2_b"], lp["ls2"], x2, out=x2)
+            f = ops.gemm(y, lp["fc1_w"], epi_act, lp["fc1_b"])
+            if cfg.unfused_bias:
+                ops.gemm(f, lp["fc2_w"], ops.EPI_BIAS2_RES, lp["fc2_b"], residual=x2, out=x2)
+            else:
+                ops.gemm(f, lp["fc2_w"], ops.EPI_BIAS_SCALE_RES, lp["fc2_b"], lp["ls2"], x2, out=x2)
             del y, qkv, ctx, f
         return x
 

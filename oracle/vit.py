@@ -30,6 +30,19 @@ class ViTConfig:
     proj_ln_eps: float = 1e-5   # bare torch.nn.LayerNorm(4096)
     llm_hidden: int = 5120
     add_class_token: bool = True
+    # SigLIP-400M (get_vision_model_args_siglip_400m, M/pretrain_long_vita.py:268-307; layer
+    # M/core/models/vision/siglip_vit_model.py:18-86 with the local spec vit_layer_specs.py:30-53):
+    activation: str = "gelu"        # "gelu_tanh": partial(F.gelu, approximate="tanh")
+    layerscale: bool = True         # InternViT ls1 / ls2
+    unfused_bias: bool = False      # linear_proj / linear_fc1 / linear_fc2 hand their bias back (skip_bias_add): it is
+                                    # added to the bf16-rounded product in a separate op
+
+    @classmethod
+    def siglip_400m(cls, **kw):
+        args = dict(num_layers=27, hidden=1152, heads=16, head_dim=72, ffn=4304, add_class_token=False,
+                    activation="gelu_tanh", layerscale=False, unfused_bias=True)
+        args.update(kw)
+        return cls(**args)
 
     @property
     def grid(self):
@@ -56,6 +69,7 @@ def init_vit_params(cfg: ViTConfig, seed: int = 1234, dtype=torch.bfloat16):
     def rn(*shape, std=0.02):
         return (torch.randn(*shape, generator=g) * std).to(dtype)
 
+    hd = cfg.heads * cfg.head_dim
     p = {
         "conv_w": rn(cfg.hidden, 3, cfg.patch, cfg.patch), "conv_b": rn(cfg.hidden),
         "cls": rn(1, 1, cfg.hidden, std=1.0), "pos": rn(cfg.seq, cfg.hidden, std=0.02),
@@ -63,17 +77,22 @@ def init_vit_params(cfg: ViTConfig, seed: int = 1234, dtype=torch.bfloat16):
         "proj_ln_w": torch.ones(4 * cfg.hidden, dtype=dtype), "proj_ln_b": torch.zeros(4 * cfg.hidden, dtype=dtype),
         "proj_fc1": rn(cfg.hidden, 4 * cfg.hidden), "proj_fc2": rn(cfg.llm_hidden, cfg.hidden),
     }
+    if not cfg.add_class_token:
+        del p["cls"]
     for _ in range(cfg.num_layers):
-        p["layers"].append({
+        lp = {
             "ln1_w": torch.ones(cfg.hidden, dtype=dtype), "ln1_b": torch.zeros(cfg.hidden, dtype=dtype),
-            "qkv_w": rn(3 * cfg.hidden, cfg.hidden), "qkv_b": rn(3 * cfg.hidden),
-            "proj_w": rn(cfg.hidden, cfg.hidden), "proj_b": rn(cfg.hidden),
+            "qkv_w": rn(3 * hd, cfg.hidden), "qkv_b": rn(3 * hd),
+            "proj_w": rn(cfg.hidden, hd), "proj_b": rn(cfg.hidden),
             "ls1": torch.full((cfg.hidden,), 0.1, dtype=dtype),
             "ln2_w": torch.ones(cfg.hidden, dtype=dtype), "ln2_b": torch.zeros(cfg.hidden, dtype=dtype),
             "fc1_w": rn(cfg.ffn, cfg.hidden), "fc1_b": rn(cfg.ffn),
             "fc2_w": rn(cfg.hidden, cfg.ffn), "fc2_b": rn(cfg.hidden),
             "ls2": torch.full((cfg.hidden,), 0.1, dtype=dtype),
-        })
+        }
+        if not cfg.layerscale:
+            del lp["ls1"], lp["ls2"]
+        p["layers"].append(lp)
     return p
 
 
@@ -90,26 +109,39 @@ def vit_embed(images, p, cfg: ViTConfig):
     x = x.reshape(x.shape[0], x.shape[1], -1).permute(0, 2, 1)
     if cfg.add_class_token:
         x = torch.cat([p["cls"].expand(x.shape[0], -1, -1).to(x.dtype), x], dim=1)
-    return x + p["pos"][None].to(x.dtype)
+    return (x + p["pos"][None].to(x.dtype)).contiguous()        # layout only (the reference makes it contiguous at :243-244)
+
+
+def _act(y, cfg: ViTConfig):
+    if cfg.activation == "gelu_tanh":
+        return F.gelu(y.float(), approximate="tanh").to(y.dtype)
+    return F.gelu(y.float()).to(y.dtype)
+
+
+def _linear_bias(x, w, b, cfg: ViTConfig):
+    """TE linear (InternViT spec): bias inside the fp32 epilogue; Megatron local spec with skip_bias_add (SigLIP):
+    the product is rounded first and the bias added by a separate bf16 op."""
+    if cfg.unfused_bias:
+        return linear(x, w) + b.to(x.dtype)
+    return linear(x, w, b)
 
 
 def vit_layer(x, lp, cfg: ViTConfig):
-    """InternViTTransformerLayer.forward, intern_vit_model.py:32-89; x [b, s, h].
-    QKV split per head [q, k, v] (Megatron SelfAttention with ng == np)."""
+    """InternViTTransformerLayer.forward, intern_vit_model.py:32-89 / SigLIPViTTransformerLayer.forward,
+    siglip_vit_model.py:29-86; x [b, s, h].  QKV split per head [q, k, v] (Megatron SelfAttention with ng == np)."""
     b, s, h = x.shape
     res = x
     y = F.layer_norm(x.float(), (h,), lp["ln1_w"].float(), lp["ln1_b"].float(), cfg.ln_eps).to(x.dtype)
     qkv = linear(y, lp["qkv_w"], lp["qkv_b"]).view(b, s, cfg.heads, 3 * cfg.head_dim)
     q, k, v = torch.split(qkv, cfg.head_dim, dim=-1)
     ctx = core_attention(q.transpose(0, 1), k.transpose(0, 1), v.transpose(0, 1), causal=False)  # [s, b, h]
-    out = linear(ctx.transpose(0, 1), lp["proj_w"], lp["proj_b"])
-    x = res + out * lp["ls1"].to(x.dtype)
+    out = _linear_bias(ctx.transpose(0, 1), lp["proj_w"], lp["proj_b"], cfg)
+    x = res + (out * lp["ls1"].to(x.dtype) if cfg.layerscale else out)
     res = x
     y = F.layer_norm(x.float(), (h,), lp["ln2_w"].float(), lp["ln2_b"].float(), cfg.ln_eps).to(x.dtype)
-    y = linear(y, lp["fc1_w"], lp["fc1_b"])
-    y = F.gelu(y.float()).to(x.dtype)
-    y = linear(y, lp["fc2_w"], lp["fc2_b"])
-    return res + y * lp["ls2"].to(x.dtype)
+    y = _act(_linear_bias(y, lp["fc1_w"], lp["fc1_b"], cfg), cfg)
+    y = _linear_bias(y, lp["fc2_w"], lp["fc2_b"], cfg)
+    return res + (y * lp["ls2"].to(x.dtype) if cfg.layerscale else y)
 
 
 def vit_project(x, p, cfg: ViTConfig):

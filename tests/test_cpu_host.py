@@ -333,3 +333,43 @@ def test_tensor_parallel_shards_roundtrip():
     y_sh = torch.cat([torch.nn.functional.silu(x @ s[0]["layers"][0]["fc1_w"].float()[:256].T)
                       * (x @ s[0]["layers"][0]["fc1_w"].float()[256:].T) for s in shards], dim=1)
     torch.testing.assert_close(y_sh, y_full)
+
+
+def test_oracle_siglip_matches_transformers():
+    """The SigLIP variant of the restated ViT layer (tanh GELU, no LayerScale / class token, 16 x 72 heads, FFN 4304) ==
+    transformers' SiglipVisionModel encoder in fp32 (Megatron per-head QKV layout -> q_proj / k_proj / v_proj)."""
+    from transformers import SiglipVisionConfig, SiglipVisionModel
+
+    from oracle import vit as ovit
+    cfg = ovit.ViTConfig.siglip_400m(num_layers=2, image=56)                  # 4 x 4 patches keep it small
+    p = ovit.init_vit_params(cfg, seed=6, dtype=torch.float32)
+    hf = SiglipVisionModel(SiglipVisionConfig(hidden_size=1152, intermediate_size=4304, num_hidden_layers=2,
+                                              num_attention_heads=16, image_size=56, patch_size=14,
+                                              hidden_act="gelu_pytorch_tanh", layer_norm_eps=1e-6,
+                                              attn_implementation="eager")).eval()
+    sd = hf.state_dict()
+    pre = "vision_model." if any(k.startswith("vision_model.") for k in sd) else ""      # transformers 4.x vs 5.x
+    vm = hf.vision_model if pre else hf
+    sd[pre + "embeddings.patch_embedding.weight"] = p["conv_w"]
+    sd[pre + "embeddings.patch_embedding.bias"] = p["conv_b"]
+    sd[pre + "embeddings.position_embedding.weight"] = p["pos"]
+    for i, lp in enumerate(p["layers"]):
+        lpre = f"{pre}encoder.layers.{i}."
+        w = lp["qkv_w"].view(16, 3, 72, 1152)
+        b = lp["qkv_b"].view(16, 3, 72)
+        for j, name in enumerate(("q_proj", "k_proj", "v_proj")):
+            sd[lpre + f"self_attn.{name}.weight"] = w[:, j].reshape(1152, 1152)
+            sd[lpre + f"self_attn.{name}.bias"] = b[:, j].reshape(1152)
+        sd[lpre + "self_attn.out_proj.weight"], sd[lpre + "self_attn.out_proj.bias"] = lp["proj_w"], lp["proj_b"]
+        sd[lpre + "layer_norm1.weight"], sd[lpre + "layer_norm1.bias"] = lp["ln1_w"], lp["ln1_b"]
+        sd[lpre + "layer_norm2.weight"], sd[lpre + "layer_norm2.bias"] = lp["ln2_w"], lp["ln2_b"]
+        sd[lpre + "mlp.fc1.weight"], sd[lpre + "mlp.fc1.bias"] = lp["fc1_w"], lp["fc1_b"]
+        sd[lpre + "mlp.fc2.weight"], sd[lpre + "mlp.fc2.bias"] = lp["fc2_w"], lp["fc2_b"]
+    hf.load_state_dict(sd)
+    images = torch.randn(2, 3, 56, 56, generator=torch.Generator().manual_seed(1))
+    with torch.no_grad():
+        ref = vm.encoder(inputs_embeds=vm.embeddings(images)).last_hidden_state
+    x = ovit.vit_embed(images, p, cfg)
+    for lp in p["layers"]:
+        x = ovit.vit_layer(x, lp, cfg)
+    torch.testing.assert_close(x, ref, rtol=2e-4, atol=2e-4)

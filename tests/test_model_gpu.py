@@ -276,3 +276,18 @@ def test_hip_prefill_is_as_close_to_fp32_truth_as_the_reference_bf16_path(amd):
     e_ref, e_hip = rel_l2(ref_bf16, truth), rel_l2(out, truth)
     assert e_hip < 1.5 * e_ref + 1e-3, (e_hip, e_ref)
     assert e_hip < 2e-2
+
+
+@pytest.mark.parametrize("nl,frames", [(2, 3), (27, 1)])
+def test_siglip_400m_vs_oracle(amd, nl, frames):
+    """SigLIP-400M geometry (16 x 72 heads, FFN 4304, tanh GELU, no class token, unfused biases): heads padded to 128 and
+    the FFN to 4352 at load time, same function (BASELINE config 2 names SigLIP next to InternViT)."""
+    V = amd["vision"]
+    ocfg = ovit.ViTConfig.siglip_400m(num_layers=nl)
+    p = ovit.init_vit_params(ocfg, seed=31)
+    vit = V.MegatronVisionModel.from_oracle_layout(V.VisionConfig.siglip_400m(num_layers=nl), p, DEV)
+    images = torch.randn(frames, 3, 448, 448, generator=torch.Generator().manual_seed(2)).bfloat16()
+    ref = ovit.vision_model(images, p, ocfg)                                  # [frames, 256, 5120]
+    out = vit(images=images.to(DEV))
+    assert out.shape == ref.shape == (frames, 256, 5120)
+    assert rel_l2(out, ref) < (1.5e-2 if nl == 2 else 3e-2), rel_l2(out, ref)

@@ -382,3 +382,26 @@ def test_flash_attn_packed_sequences_fwd_bwd(ops, S, cu):
         assert rel_l2(dq[0], qf.grad[:, 0]) < 2.5e-2
         assert rel_l2(dk[0], kf.grad[:, 0]) < 2.5e-2
         assert rel_l2(dv[0], vf.grad[:, 0]) < 2.5e-2
+
+
+def test_gemm_siglip_epilogues(ops):
+    """BIAS2_* epilogues: the bias meets the bf16-ROUNDED product (Megatron skip_bias_add), then tanh-GELU / residual."""
+    g = torch.Generator().manual_seed(5)
+    M, N, K = 300, 4352, 1152
+    a = (torch.randn(M, K, generator=g) * 0.5).bfloat16()
+    w = (torch.randn(N, K, generator=g) * 0.05).bfloat16()
+    b = torch.randn(N, generator=g).bfloat16()
+    r = torch.randn(M, N, generator=g).bfloat16()
+    prod = (a.float() @ w.float().t()).bfloat16()
+    pre = (prod + b)                                                         # bf16 add
+    ref_act = torch.nn.functional.gelu(pre.float(), approximate="tanh").bfloat16()
+    ref_res = r + pre
+    ad, wd, bd, rd = a.to(DEV), w.to(DEV), b.to(DEV), r.to(DEV)
+    out_act = ops.gemm(ad, wd, ops.EPI_BIAS2_GELU_TANH, bd).cpu()
+    out_res = ops.gemm(ad, wd, ops.EPI_BIAS2_RES, bd, residual=rd).cpu()
+    for out, ref in ((out_act, ref_act), (out_res, ref_res)):
+        d = (out.float() - ref.float()).abs()
+        assert float((d == 0).float().mean()) > 0.97                         # accumulation order moves a few roundings
+        assert float((d / (ref.float().abs() + 1.0)).max()) < 2e-2
+    with pytest.raises(ValueError):
+        ops.gemm(ad, wd, ops.EPI_BIAS2_RES, bd)                              # residual required
