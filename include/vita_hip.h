@@ -368,21 +368,24 @@ int vita_decode_layer_attn(const vita_decode_layer_params* p, void* stream);
 int vita_decode_layer_mlp(const vita_decode_layer_params* p, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Frame preprocessing — ImageProcessor.process_images,
- * H/data/processor/image_processor.py:180-223, then the bf16 cast of M/tasks/inference/module.py:693:
- * frames [n][height][width][3] uint8 RGB (frame_stride bytes apart) -> expand2square with pad_rgb
- * (:189-201) -> Pillow BICUBIC resize to out_size x out_size (:206-208; 22-bit fixed-point separable
- * passes with a uint8 intermediate, bit-exact) -> (x * 1.0 / 255.0 - mean) / std in float32 (:210-215)
- * -> images [n][3][out_size][out_size] bf16.
- * bounds [out_size][2] int32 (first tap, tap count) and coeffs [out_size][ksize] int32 are Pillow's
- * precompute_coeffs / normalize_coeffs_8bpc tables for max(height, width) -> out_size (the padded
- * image is square, so one table serves both passes); pad_rgb, mean, std_ are HOST arrays of 3.
- * tmp: device scratch of n * max(height, width) * out_size * 3 bytes; u8_out (optional): the uint8
- * resize result [n][out_size][out_size][3]. */
+ * Frame / image preprocessing — ImageProcessor.process_images and dynamic_preprocess,
+ * H/data/processor/image_processor.py:180-223,404-448, then the bf16 cast of
+ * M/tasks/inference/module.py:693.  frames [n][height][width][3] uint8 RGB (frame_stride bytes apart)
+ *   -> pad_to_square != 0: expand2square with pad_rgb (:189-201)
+ *   -> Pillow BICUBIC resize to out_w x out_h (:206-208 / :429, :443; 22-bit fixed-point separable passes with a
+ *      uint8 intermediate, bit-exact)
+ *   -> cut into tile x tile blocks in row-major order (the crop loop :431-441; tile == out_w == out_h: one block)
+ *   -> (x * 1.0 / 255.0 - mean) / std in float32 (:210-215) -> images [n * blocks][3][tile][tile] bf16.
+ * h_bounds [out_w][2] / h_coeffs [out_w][h_ksize] and v_bounds [out_h][2] / v_coeffs [out_h][v_ksize] (int32,
+ * device) are Pillow's precompute_coeffs / normalize_coeffs_8bpc tables for the (padded) source width -> out_w
+ * and height -> out_h; pad_rgb, mean, std_ are HOST arrays of 3.
+ * tmp: device scratch of n * source_height * out_w * 3 bytes; u8_out (optional): the uint8 resize result
+ * [n][out_h][out_w][3]. */
 int vita_frames_resize_norm(const void* frames, int64_t frame_stride, int n, int height, int width,
-                            int out_size, const int* pad_rgb, const void* bounds, const void* coeffs,
-                            int ksize, const float* mean, const float* std_, void* tmp, void* images,
-                            void* u8_out, void* stream);
+                            int pad_to_square, const int* pad_rgb, int out_w, int out_h, int tile,
+                            const void* h_bounds, const void* h_coeffs, int h_ksize, const void* v_bounds,
+                            const void* v_coeffs, int v_ksize, const float* mean, const float* std_,
+                            void* tmp, void* images, void* u8_out, void* stream);
 
 #ifdef __cplusplus
 }

@@ -18,15 +18,15 @@ constexpr int kPrecisionBits = 32 - 8 - 2;
 
 __device__ __forceinline__ int clip8(int v) { return v < 0 ? 0 : (v > 255 ? 255 : v); }
 
-// horizontal pass over the virtually padded P x P square: tmp[n][y][xx][c], y in [0, P), xx in [0, out)
+// horizontal pass over the (virtually padded) Ph x Pw source: tmp[n][y][xx][c], y in [0, Ph), xx in [0, out_w)
 __global__ __launch_bounds__(256) void resample_h_kernel(const uint8_t* __restrict__ frames, int64_t frame_stride, int H,
-                                                         int W, int P, int ox, int oy, int out, int pad0, int pad1,
+                                                         int W, int Ph, int ox, int oy, int out_w, int pad0, int pad1,
                                                          int pad2, const int* __restrict__ bounds,
                                                          const int* __restrict__ kk, int ksize,
                                                          uint8_t* __restrict__ tmp) {
   const int xx = blockIdx.x * blockDim.x + threadIdx.x;
   const int y = blockIdx.y, n = blockIdx.z;
-  if (xx >= out) return;
+  if (xx >= out_w) return;
   const int xmin = bounds[2 * xx], cnt = bounds[2 * xx + 1];
   const int* k = kk + (int64_t)xx * ksize;
   int s0 = 1 << (kPrecisionBits - 1), s1 = s0, s2 = s0;
@@ -40,38 +40,41 @@ __global__ __launch_bounds__(256) void resample_h_kernel(const uint8_t* __restri
     const int c = k[x];
     s0 += p0 * c; s1 += p1 * c; s2 += p2 * c;
   }
-  uint8_t* o = tmp + (((int64_t)n * P + y) * out + xx) * 3;
+  uint8_t* o = tmp + (((int64_t)n * Ph + y) * out_w + xx) * 3;
   o[0] = (uint8_t)clip8(s0 >> kPrecisionBits);
   o[1] = (uint8_t)clip8(s1 >> kPrecisionBits);
   o[2] = (uint8_t)clip8(s2 >> kPrecisionBits);
 }
 
-// vertical pass + normalisation: images[n][c][yy][xx] bf16 (and, optionally, the uint8 resize result for parity checks)
-__global__ __launch_bounds__(256) void resample_v_norm_kernel(const uint8_t* __restrict__ tmp, int P, int out,
-                                                              const int* __restrict__ bounds,
+// vertical pass + normalisation.  The out_h x out_w result is cut into tile x tile images (row-major blocks, the crop
+// order of dynamic_preprocess): images[(n * tiles + block)][c][yy % tile][xx % tile] bf16; u8_out keeps the uncut result.
+__global__ __launch_bounds__(256) void resample_v_norm_kernel(const uint8_t* __restrict__ tmp, int Ph, int out_w, int out_h,
+                                                              int tile, const int* __restrict__ bounds,
                                                               const int* __restrict__ kk, int ksize, float m0, float m1,
                                                               float m2, float sd0, float sd1, float sd2,
                                                               bf16_t* __restrict__ images, uint8_t* __restrict__ u8_out) {
   const int xx = blockIdx.x * blockDim.x + threadIdx.x;
   const int yy = blockIdx.y, n = blockIdx.z;
-  if (xx >= out) return;
+  if (xx >= out_w) return;
   const int ymin = bounds[2 * yy], cnt = bounds[2 * yy + 1];
   const int* k = kk + (int64_t)yy * ksize;
   int s0 = 1 << (kPrecisionBits - 1), s1 = s0, s2 = s0;
-  const uint8_t* col = tmp + (((int64_t)n * P + ymin) * out + xx) * 3;
+  const uint8_t* col = tmp + (((int64_t)n * Ph + ymin) * out_w + xx) * 3;
   for (int y = 0; y < cnt; ++y) {
     const int c = k[y];
     s0 += (int)col[0] * c; s1 += (int)col[1] * c; s2 += (int)col[2] * c;
-    col += (int64_t)out * 3;
+    col += (int64_t)out_w * 3;
   }
   const int v0 = clip8(s0 >> kPrecisionBits), v1 = clip8(s1 >> kPrecisionBits), v2 = clip8(s2 >> kPrecisionBits);
   if (u8_out) {
-    uint8_t* u = u8_out + (((int64_t)n * out + yy) * out + xx) * 3;
+    uint8_t* u = u8_out + (((int64_t)n * out_h + yy) * out_w + xx) * 3;
     u[0] = (uint8_t)v0; u[1] = (uint8_t)v1; u[2] = (uint8_t)v2;
   }
   // float32, same operation order as numpy: (x * 1.0 / 255.0 - mean) / std, then round-to-nearest-even to bf16
-  const int64_t plane = (int64_t)out * out;
-  bf16_t* o = images + (int64_t)n * 3 * plane + (int64_t)yy * out + xx;
+  const int tiles_x = out_w / tile, tiles = tiles_x * (out_h / tile);
+  const int block = (yy / tile) * tiles_x + xx / tile;
+  const int64_t plane = (int64_t)tile * tile;
+  bf16_t* o = images + ((int64_t)n * tiles + block) * 3 * plane + (int64_t)(yy % tile) * tile + (xx % tile);
   o[0] = f32_to_bf16(__fdiv_rn(__fsub_rn(__fdiv_rn((float)v0, 255.0f), m0), sd0));
   o[plane] = f32_to_bf16(__fdiv_rn(__fsub_rn(__fdiv_rn((float)v1, 255.0f), m1), sd1));
   o[2 * plane] = f32_to_bf16(__fdiv_rn(__fsub_rn(__fdiv_rn((float)v2, 255.0f), m2), sd2));
@@ -79,25 +82,29 @@ __global__ __launch_bounds__(256) void resample_v_norm_kernel(const uint8_t* __r
 
 }  // namespace
 
-extern "C" int vita_frames_resize_norm(const void* frames, int64_t frame_stride, int n, int height, int width, int out_size,
-                                       const int* pad_rgb, const void* bounds, const void* coeffs, int ksize,
-                                       const float* mean, const float* std_, void* tmp, void* images, void* u8_out,
-                                       void* stream) {
-  if (!frames || !bounds || !coeffs || !tmp || !images || !pad_rgb || !mean || !std_) return VITA_ERR_INVALID_ARG;
-  if (n < 0 || height <= 0 || width <= 0 || out_size <= 0 || ksize <= 0) return VITA_ERR_INVALID_ARG;
+extern "C" int vita_frames_resize_norm(const void* frames, int64_t frame_stride, int n, int height, int width,
+                                       int pad_to_square, const int* pad_rgb, int out_w, int out_h, int tile,
+                                       const void* h_bounds, const void* h_coeffs, int h_ksize, const void* v_bounds,
+                                       const void* v_coeffs, int v_ksize, const float* mean, const float* std_, void* tmp,
+                                       void* images, void* u8_out, void* stream) {
+  if (!frames || !h_bounds || !h_coeffs || !v_bounds || !v_coeffs || !tmp || !images || !pad_rgb || !mean || !std_)
+    return VITA_ERR_INVALID_ARG;
+  if (n < 0 || height <= 0 || width <= 0 || out_w <= 0 || out_h <= 0 || tile <= 0 || h_ksize <= 0 || v_ksize <= 0)
+    return VITA_ERR_INVALID_ARG;
+  if (out_w % tile || out_h % tile) return VITA_ERR_INVALID_ARG;
   if (n == 0) return VITA_OK;
-  if (n > 65535 || out_size > 65535) return VITA_ERR_UNSUPPORTED;
-  const int P = height > width ? height : width;                 // expand2square
-  if (P > 65535) return VITA_ERR_UNSUPPORTED;
-  const int ox = (P - width) / 2, oy = (P - height) / 2;          // paste offsets (:195, :199)
+  const int P = height > width ? height : width;
+  const int Pw = pad_to_square ? P : width, Ph = pad_to_square ? P : height;     // expand2square (:189-201) or as is
+  if (n > 65535 || out_h > 65535 || Ph > 65535) return VITA_ERR_UNSUPPORTED;
+  const int ox = (Pw - width) / 2, oy = (Ph - height) / 2;                        // paste offsets (:195, :199)
   hipStream_t st = (hipStream_t)stream;
   const dim3 block(256);
-  const unsigned gx = (unsigned)((out_size + 255) / 256);
-  hipLaunchKernelGGL(resample_h_kernel, dim3(gx, (unsigned)P, (unsigned)n), block, 0, st, (const uint8_t*)frames,
-                     frame_stride, height, width, P, ox, oy, out_size, pad_rgb[0], pad_rgb[1], pad_rgb[2],
-                     (const int*)bounds, (const int*)coeffs, ksize, (uint8_t*)tmp);
-  hipLaunchKernelGGL(resample_v_norm_kernel, dim3(gx, (unsigned)out_size, (unsigned)n), block, 0, st,
-                     (const uint8_t*)tmp, P, out_size, (const int*)bounds, (const int*)coeffs, ksize, mean[0], mean[1],
-                     mean[2], std_[0], std_[1], std_[2], (bf16_t*)images, (uint8_t*)u8_out);
+  const unsigned gx = (unsigned)((out_w + 255) / 256);
+  hipLaunchKernelGGL(resample_h_kernel, dim3(gx, (unsigned)Ph, (unsigned)n), block, 0, st, (const uint8_t*)frames,
+                     frame_stride, height, width, Ph, ox, oy, out_w, pad_rgb[0], pad_rgb[1], pad_rgb[2],
+                     (const int*)h_bounds, (const int*)h_coeffs, h_ksize, (uint8_t*)tmp);
+  hipLaunchKernelGGL(resample_v_norm_kernel, dim3(gx, (unsigned)out_h, (unsigned)n), block, 0, st, (const uint8_t*)tmp, Ph,
+                     out_w, out_h, tile, (const int*)v_bounds, (const int*)v_coeffs, v_ksize, mean[0], mean[1], mean[2],
+                     std_[0], std_[1], std_[2], (bf16_t*)images, (uint8_t*)u8_out);
   return vita_check_launch();
 }

@@ -91,40 +91,94 @@ class ImageProcessor:
         self.min_patch_grid, self.max_patch_grid = min_patch_grid, max_patch_grid
         self.device = device
         self._tables = {}
-        if process_type in ("anyres", "dynamic"):
-            raise NotImplementedError("sub-patch tiling (process_anyres / process_dynamic) is not on the video path")
+        if process_type == "anyres":
+            raise NotImplementedError("process_anyres is not built (every reference script uses --vision-process-type dynamic)")
+        if process_type == "dynamic":                                   # :61-77
+            max_num, min_num = self.max_patch_grid, self.min_patch_grid
+            target_ratios = set((i, j) for n in range(min_num, max_num + 1) for i in range(1, n + 1)
+                                for j in range(1, n + 1) if i * j <= max_num and i * j >= min_num)
+            self.target_ratios = sorted(target_ratios, key=lambda x: x[0] * x[1])
+            self.possible_resolutions = [[dim * self.patch_size for dim in pair] for pair in self.target_ratios]
 
-    def _table(self, side: int):
-        t = self._tables.get(side)
+    def _table(self, in_size: int, out_size: int):
+        t = self._tables.get((in_size, out_size))
         if t is None:
-            b, c, k = pil_resample_table(side, self.image_size)
+            b, c, k = pil_resample_table(in_size, out_size)
             t = (torch.from_numpy(b).to(self.device), torch.from_numpy(c).to(self.device), k)
-            self._tables[side] = t
+            self._tables[(in_size, out_size)] = t
         return t
 
-    def process_frames(self, frames: torch.Tensor, return_u8: bool = False):
-        """frames [N, H, W, 3] uint8 on the device -> [N, 3, S, S] bf16 (and optionally the uint8 resize)."""
+    def _resize_norm(self, frames: torch.Tensor, out_w: int, out_h: int, tile: int, pad_to_square: bool, return_u8=False):
+        """frames [N, H, W, 3] uint8 (device) -> [N * blocks, 3, tile, tile] bf16: Pillow-exact resize to out_w x out_h,
+        cut into tile x tile blocks (row-major), normalised."""
         if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3 or not frames.is_cuda:
             raise ValueError("frames must be a [N, H, W, 3] uint8 HIP device tensor (no CPU fallback)")
         frames = frames.contiguous()
         n, h, w, _ = frames.shape
-        S, P = self.image_size, max(h, w)
-        bounds, coeffs, ksize = self._table(P)
-        out = torch.empty(n, 3, S, S, dtype=torch.bfloat16, device=frames.device)
-        u8 = torch.empty(n, S, S, 3, dtype=torch.uint8, device=frames.device) if return_u8 else None
+        P = max(h, w)
+        pw, ph = (P, P) if pad_to_square else (w, h)
+        hb, hc, hk = self._table(pw, out_w)
+        vb, vc, vk = self._table(ph, out_h)
+        blocks = (out_w // tile) * (out_h // tile)
+        out = torch.empty(n * blocks, 3, tile, tile, dtype=torch.bfloat16, device=frames.device)
+        u8 = torch.empty(n, out_h, out_w, 3, dtype=torch.uint8, device=frames.device) if return_u8 else None
         pad = (C.c_int * 3)(*[int(x * 255) for x in self.mean])             # tuple(int(x * 255) for x in mean) :204
         mean = (C.c_float * 3)(*[float(np.float32(x)) for x in self.mean])
         std = (C.c_float * 3)(*[float(np.float32(x)) for x in self.std])
-        chunk = max(1, min(n, 65535, (1 << 30) // (P * S * 3)))            # bound the uint8 scratch to 1 GiB
-        tmp = torch.empty(chunk * P * S * 3, dtype=torch.uint8, device=frames.device)
+        chunk = max(1, min(n, 65535, (1 << 30) // (ph * out_w * 3)))       # bound the uint8 scratch to 1 GiB
+        tmp = torch.empty(chunk * ph * out_w * 3, dtype=torch.uint8, device=frames.device)
         st = torch.cuda.current_stream().cuda_stream
         for i in range(0, n, chunk):
             m = min(chunk, n - i)
-            _L.check(_L.load().vita_frames_resize_norm(frames[i].data_ptr(), h * w * 3, m, h, w, S, pad, bounds.data_ptr(),
-                                                       coeffs.data_ptr(), ksize, mean, std, tmp.data_ptr(),
-                                                       out[i].data_ptr(), None if u8 is None else u8[i].data_ptr(), st),
-                     "vita_frames_resize_norm")
+            _L.check(_L.load().vita_frames_resize_norm(
+                frames[i].data_ptr(), h * w * 3, m, h, w, int(pad_to_square), pad, out_w, out_h, tile, hb.data_ptr(),
+                hc.data_ptr(), hk, vb.data_ptr(), vc.data_ptr(), vk, mean, std, tmp.data_ptr(), out[i * blocks].data_ptr(),
+                None if u8 is None else u8[i].data_ptr(), st), "vita_frames_resize_norm")
         return (out, u8) if return_u8 else out
+
+    def process_frames(self, frames: torch.Tensor, return_u8: bool = False):
+        """frames [N, H, W, 3] uint8 on the device -> [N, 3, S, S] bf16 (and optionally the uint8 resize): the per-frame
+        body of process_images (:203-221): expand2square, BICUBIC resize to S x S, normalise."""
+        S = self.image_size
+        return self._resize_norm(frames, S, S, S, True, return_u8)
+
+    # -- dynamic_preprocess (:404-448) + process_dynamic (:299-316) ---------------------------------------------------
+    def find_closest_aspect_ratio(self, aspect_ratio, width, height):
+        """:386-401"""
+        best_ratio_diff, best_ratio, area = float("inf"), (1, 1), width * height
+        for ratio in self.target_ratios:
+            target_aspect_ratio = ratio[0] / ratio[1]
+            ratio_diff = abs(aspect_ratio - target_aspect_ratio)
+            if ratio_diff < best_ratio_diff:
+                best_ratio_diff, best_ratio = ratio_diff, ratio
+            elif ratio_diff == best_ratio_diff:
+                if area > 0.5 * self.image_size * self.image_size * ratio[0] * ratio[1]:
+                    best_ratio = ratio
+        return best_ratio
+
+    def process_dynamic(self, img_or_array):
+        """One image -> ([thumbnail +] tiles [B, 3, S, S] bf16 on the device, (target_width, target_height)): the image is
+        resized (BICUBIC) to the closest-aspect grid of S x S tiles and cut up; with more than one tile a S x S thumbnail of
+        the whole image goes first (use_thumbnail=True, :312).  The tiles are square already, so process_images' own
+        expand2square / resize are identities and only the normalisation remains."""
+        if self.process_type != "dynamic":
+            raise ValueError("process_dynamic needs process_type='dynamic'")
+        arr = np.asarray(img_or_array.convert("RGB") if hasattr(img_or_array, "convert") else img_or_array, dtype=np.uint8)
+        h, w, _ = arr.shape
+        S = self.image_size
+        ratio = self.find_closest_aspect_ratio(w / h, w, h)
+        tw, th = S * ratio[0], S * ratio[1]
+        frame = torch.from_numpy(arr)[None].to(self.device)
+        tiles = self._resize_norm(frame, tw, th, S, False)
+        if tiles.shape[0] != 1:
+            tiles = torch.cat([self._resize_norm(frame, S, S, S, False), tiles], dim=0)
+        return tiles, (tw, th)
+
+    def process_images_with_subpatch(self, img_or_path):
+        """:225-240"""
+        if self.process_type == "dynamic":
+            return self.process_dynamic(img_or_path)
+        raise NotImplementedError("only the 'dynamic' sub-patch path is built")
 
     def process_images(self, img_or_array_list: Sequence):
         """:180-223.  Accepts decoded frames (PIL images or [H, W, 3] uint8 arrays); frames of equal size are batched

@@ -376,6 +376,14 @@ def golden_image_processor():
         ref = proc.process_images([Image.fromarray(f) for f in frames])             # [N, 3, size, size] float32
         out["cases"].append({"normalize_type": norm, "image_size": size, "frames": [torch.from_numpy(f) for f in frames],
                              "output": ref.clone(), "output_bf16": torch.tensor(ref, dtype=torch.bfloat16)})
+    # dynamic tiling (--vision-process-type dynamic --max-patch-grid 12, every reference script)
+    out["dynamic"] = []
+    proc = ImageProcessor("dynamic", image_size=56, normalize_type="imagenet", min_patch_grid=1, max_patch_grid=12)
+    for h, w in [(90, 160), (300, 70), (56, 56), (61, 200), (75, 75)]:
+        frame = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        tiles, res = proc.process_dynamic(Image.fromarray(frame))
+        out["dynamic"].append({"frame": torch.from_numpy(frame), "output_bf16": torch.tensor(tiles, dtype=torch.bfloat16),
+                               "resolution": tuple(int(x) for x in res)})
     import PIL
     out["pillow_version"] = PIL.__version__
     torch.save(out, os.path.join(OUT, "image_processor.pt"))

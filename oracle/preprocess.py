@@ -48,3 +48,36 @@ def process_images(frames, image_size=448, normalize_type="imagenet") -> torch.T
 def to_model_dtype(images: torch.Tensor) -> torch.Tensor:
     """M/tasks/inference/module.py:693"""
     return torch.tensor(images, dtype=torch.bfloat16)
+
+
+def dynamic_preprocess(frame: np.ndarray, min_num=1, max_num=12, image_size=448, use_thumbnail=True):
+    """H/data/processor/image_processor.py:386-448 (find_closest_aspect_ratio + dynamic_preprocess): closest-aspect grid of
+    image_size tiles, BICUBIC resize (PIL's default), crop in row-major order, thumbnail first if more than one tile."""
+    image = Image.fromarray(frame)
+    orig_width, orig_height = image.size
+    aspect_ratio = orig_width / orig_height
+    target_ratios = set((i, j) for n in range(min_num, max_num + 1) for i in range(1, n + 1) for j in range(1, n + 1)
+                        if i * j <= max_num and i * j >= min_num)
+    target_ratios = sorted(target_ratios, key=lambda x: x[0] * x[1])
+    best_ratio_diff, best_ratio, area = float("inf"), (1, 1), orig_width * orig_height
+    for ratio in target_ratios:
+        ratio_diff = abs(aspect_ratio - ratio[0] / ratio[1])
+        if ratio_diff < best_ratio_diff:
+            best_ratio_diff, best_ratio = ratio_diff, ratio
+        elif ratio_diff == best_ratio_diff and area > 0.5 * image_size * image_size * ratio[0] * ratio[1]:
+            best_ratio = ratio
+    target_width, target_height = image_size * best_ratio[0], image_size * best_ratio[1]
+    blocks = best_ratio[0] * best_ratio[1]
+    resized_img = image.resize((target_width, target_height))
+    per_row = target_width // image_size
+    tiles = [resized_img.crop(((i % per_row) * image_size, (i // per_row) * image_size,
+                               (i % per_row + 1) * image_size, (i // per_row + 1) * image_size)) for i in range(blocks)]
+    if use_thumbnail and len(tiles) != 1:
+        tiles = [image.resize((image_size, image_size))] + tiles
+    return [np.array(t) for t in tiles], (target_width, target_height)
+
+
+def process_dynamic(frame: np.ndarray, image_size=448, normalize_type="imagenet", min_patch_grid=1, max_patch_grid=12):
+    """ImageProcessor.process_dynamic (:299-316): tiles -> process_images -> [B, 3, S, S] float32, (tw, th)."""
+    tiles, res = dynamic_preprocess(frame, min_patch_grid, max_patch_grid, image_size, True)
+    return process_images(tiles, image_size, normalize_type), res

@@ -21,6 +21,14 @@ def test_oracle_matches_reference_fixture():
         assert torch.equal(opre.to_model_dtype(out), case["output_bf16"])
 
 
+def test_oracle_dynamic_tiling_matches_reference_fixture():
+    g = load_golden("image_processor.pt")
+    assert len(g["dynamic"]) == 5
+    for case in g["dynamic"]:
+        out, res = opre.process_dynamic(case["frame"].numpy(), 56, "imagenet", 1, 12)
+        assert res == case["resolution"] and torch.equal(opre.to_model_dtype(out), case["output_bf16"])
+
+
 @pytest.mark.parametrize("H,W,S", SHAPES[:7])
 def test_host_coefficient_table_reproduces_pillow(H, W, S):
     """pil_resample_table + the two integer passes (numpy restatement of the kernels) == Pillow's resize."""
@@ -83,3 +91,21 @@ def test_hip_process_images_on_reference_fixture_and_mixed_sizes(proc_mod):
         assert torch.equal(out.cpu(), case["output_bf16"])
     with pytest.raises(ValueError):
         proc.process_frames(torch.zeros(1, 8, 8, 3, dtype=torch.uint8))               # CPU tensor: no fallback
+
+
+@pytest.mark.gpu
+def test_hip_dynamic_tiling_bit_exact(proc_mod):
+    """process_dynamic on the device: closest-aspect grid, non-square Pillow-exact resize, tile cut, thumbnail first — equal to
+    the fixture made by the reference's class (image_size 56) and to the oracle at the real size (448, max_patch_grid 12)."""
+    g = load_golden("image_processor.pt")
+    proc = proc_mod.ImageProcessor("dynamic", image_size=56, normalize_type="imagenet", max_patch_grid=12)
+    for case in g["dynamic"]:
+        tiles, res = proc.process_dynamic(case["frame"].numpy())
+        assert tuple(res) == case["resolution"] and torch.equal(tiles.cpu(), case["output_bf16"])
+    proc = proc_mod.ImageProcessor("dynamic", image_size=448, normalize_type="imagenet", max_patch_grid=12)
+    rng = np.random.default_rng(3)
+    for h, w in [(720, 1280), (1000, 333), (448, 448), (500, 1400)]:
+        frame = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        tiles, res = proc.process_images_with_subpatch(frame)
+        ref, ref_res = opre.process_dynamic(frame, 448, "imagenet", 1, 12)
+        assert tuple(res) == ref_res and torch.equal(tiles.cpu(), opre.to_model_dtype(ref))
