@@ -1,0 +1,123 @@
+"""Request -> tensors: mirror of get_external_inputs (M/tasks/inference/module.py:493-707), the step in front of the
+prefill.  Token-id surgery is host-side integer work and follows the reference statement by
+statement (bit-exact: fixture made by the reference's own function, tests/golden/external_inputs.pt):
+
+  * every `<image>` tag becomes  <img> + 256 x <IMG_CONTEXT> + </img>  and, when the image was tiled
+    (process_dynamic returned more than one patch), one  "\\n" + per tile <patch> + 256 x <PATCH_CONTEXT> + </patch>
+    row per tile row (:551-614);
+  * every `<video>` tag becomes, per frame,  <vid> + 256 x <VID_CONTEXT> + </vid>  (:619-678);
+  * `indices` [2, n_images, 256] records (batch, position) of every context token in order (:575-585);
+  * each row is padded to a multiple of 64 with pad (or eos) (:684-686).
+
+The pixels come from long_vita_amd.image_processor.ImageProcessor (GPU kernels) instead of PIL on the host; get_args()
+values are keyword arguments.  `video_frames_list` (already decoded frames, one [N, H, W, 3] uint8 array per <video> tag)
+is this framework's addition: file decoding (decord) is out of scope."""
+from __future__ import annotations
+
+from typing import Optional, Sequence
+
+import torch
+
+# long_vita/constants.py:5-22 (the active `if True:` set)
+IMG_TAG_TOKEN, VID_TAG_TOKEN = "<image>", "<video>"
+IMG_CONTEXT_TOKEN, IMG_START_TOKEN, IMG_END_TOKEN = "<IMG_CONTEXT>", "<img>", "</img>"
+VID_CONTEXT_TOKEN, VID_START_TOKEN, VID_END_TOKEN = "<VID_CONTEXT>", "<vid>", "</vid>"
+PATCH_CONTEXT_TOKEN, PATCH_START_TOKEN, PATCH_END_TOKEN = "<PATCH_CONTEXT>", "<patch>", "</patch>"
+
+
+def _single_id(tokenizer, text: str) -> int:
+    ids = tokenizer(text, add_special_tokens=False).input_ids
+    assert len(ids) == 1, f"{text!r} must be one token"                       # :525-535
+    return ids[0]
+
+
+def get_external_inputs(tokens, image_list, image_path_list, video_path_list, tokenizer, image_processor, *,
+                        image_token_length: int = 256, max_num_frame: int = 4096, max_fps: int = 1, bf16: bool = True,
+                        video_frames_list: Optional[Sequence] = None, device="cuda"):
+    tokens = tokens.tolist()
+    IMG_CONTEXT_ID, IMG_START_ID, IMG_END_ID = (_single_id(tokenizer, t) for t in (IMG_CONTEXT_TOKEN, IMG_START_TOKEN, IMG_END_TOKEN))
+    VID_CONTEXT_ID, VID_START_ID, VID_END_ID = (_single_id(tokenizer, t) for t in (VID_CONTEXT_TOKEN, VID_START_TOKEN, VID_END_TOKEN))
+    PATCH_CONTEXT_ID, PATCH_START_ID, PATCH_END_ID = (_single_id(tokenizer, t) for t in (PATCH_CONTEXT_TOKEN, PATCH_START_TOKEN, PATCH_END_TOKEN))
+    IMG_TAG_ID, VID_TAG_ID = tokenizer(IMG_TAG_TOKEN, add_special_tokens=False).input_ids[0], tokenizer(VID_TAG_TOKEN, add_special_tokens=False).input_ids[0]
+    nl_tokens = tokenizer("\n", add_special_tokens=False).input_ids
+
+    image_indices, images = [], []
+
+    def context_indices(start: int):                                          # :575-585
+        b = torch.zeros(1, image_token_length, dtype=torch.int64)
+        s = torch.arange(start, start + image_token_length).unsqueeze(0)
+        return torch.stack([b, s], dim=0)                                     # [2, 1, image_token_length]
+
+    # ---- image tags (:551-614) ------------------------------------------------------------------
+    for batch_idx, input_ids in enumerate(tokens):
+        img_positions = [i for i, x in enumerate(input_ids) if x == IMG_TAG_ID]
+        if len(img_positions) == 0:
+            continue
+        if image_path_list is not None:
+            assert len(img_positions) == len(image_path_list)
+        if image_list is not None:
+            assert len(img_positions) == len(image_list)
+        new_input_ids, st = [], 0
+        for img_idx, img_pos in enumerate(img_positions):
+            if image_path_list is not None:
+                image_patches, (best_width, best_height) = image_processor.process_images_with_subpatch(image_path_list[img_idx])
+            if image_list is not None:
+                image_patches, (best_width, best_height) = image_processor.process_images_with_subpatch(image_list[img_idx])
+            images.append(image_patches)
+            new_input_ids += input_ids[st:img_pos]
+            new_input_ids += [IMG_START_ID]
+            image_indices.append(context_indices(len(new_input_ids)))
+            new_input_ids += [IMG_CONTEXT_ID] * image_token_length
+            new_input_ids += [IMG_END_ID]
+            if len(image_patches) > 1:
+                for _i in range(0, best_height, image_processor.patch_size):
+                    new_input_ids += nl_tokens
+                    for _j in range(0, best_width, image_processor.patch_size):
+                        new_input_ids += [PATCH_START_ID]
+                        image_indices.append(context_indices(len(new_input_ids)))
+                        new_input_ids += [PATCH_CONTEXT_ID] * image_token_length
+                        new_input_ids += [PATCH_END_ID]
+            st = img_pos + 1
+        new_input_ids += input_ids[st:]
+        tokens[batch_idx] = new_input_ids
+
+    # ---- video tags (:619-678) ------------------------------------------------------------------
+    for batch_idx, input_ids in enumerate(tokens):
+        vid_positions = [i for i, x in enumerate(input_ids) if x == VID_TAG_ID]
+        if len(vid_positions) == 0:
+            continue
+        for lst in (video_path_list, image_path_list, image_list, video_frames_list):
+            if lst is not None:
+                assert len(vid_positions) == len(lst)
+        new_input_ids, st = [], 0
+        for vid_idx, vid_pos in enumerate(vid_positions):
+            if video_path_list is not None:
+                video_frames, _ = image_processor.process_video(video_path_list[vid_idx], max_num_frame, max_fps)
+            if image_path_list is not None:
+                video_frames = image_processor.process_images([image_path_list[vid_idx]])
+            if image_list is not None:
+                video_frames = image_processor.process_images([image_list[vid_idx]])
+            if video_frames_list is not None:
+                video_frames = image_processor.process_images(list(video_frames_list[vid_idx])[:max_num_frame])
+            images.append(video_frames)
+            new_input_ids += input_ids[st:vid_pos]
+            for _ in video_frames:
+                new_input_ids += [VID_START_ID]
+                image_indices.append(context_indices(len(new_input_ids)))
+                new_input_ids += [VID_CONTEXT_ID] * image_token_length
+                new_input_ids += [VID_END_ID]
+            st = vid_pos + 1
+        new_input_ids += input_ids[st:]
+        tokens[batch_idx] = new_input_ids
+
+    images = torch.cat(images, dim=0)
+    image_indices = torch.cat(image_indices, dim=1)
+    pad_id = tokenizer.pad_token_id if tokenizer.pad_token_id else tokenizer.eos_token_id
+    token_lengths = [len(x) for x in tokens]
+    tokens = [x + [pad_id] * (-(-len(x) // 64) * 64 - len(x)) for x in tokens]
+
+    external_inputs = {"indices": image_indices.contiguous().to(device),
+                       "images": images.to(dtype=torch.bfloat16 if bf16 else torch.float16).contiguous().to(device)}
+    tokens = torch.tensor(tokens, dtype=torch.long, device=device)
+    token_lengths = torch.tensor(token_lengths, dtype=torch.long, device=device)
+    return external_inputs, tokens, token_lengths

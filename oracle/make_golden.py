@@ -45,7 +45,30 @@ class _StubModule(types.ModuleType):
         return m
 
 
+class _StubFinder:
+    """Fabricates any missing `megatron.*` / `apex.*` module on demand (an attribute-mocking package), so that reference files
+    whose module-level imports reach deep into Megatron-LM can be imported for the one function a fixture needs."""
+
+    ROOTS = ("megatron", "apex", "mindspeed", "flash_attn", "transformer_engine")
+
+    def find_spec(self, fullname, path=None, target=None):
+        import importlib.machinery
+        if fullname.split(".")[0] not in self.ROOTS:
+            return None
+        return importlib.machinery.ModuleSpec(fullname, self, is_package=True)
+
+    def create_module(self, spec):
+        m = _StubModule(spec.name)
+        m.__path__ = []
+        return m
+
+    def exec_module(self, module):
+        pass
+
+
 def _install_stubs():
+    if not any(isinstance(f, _StubFinder) for f in sys.meta_path):
+        sys.meta_path.append(_StubFinder())
     names = [
         "megatron", "megatron.training", "megatron.core", "megatron.core.mpu", "megatron.core.parallel_state",
         "megatron.core.tensor_parallel", "megatron.core.tensor_parallel.mappings",
@@ -59,6 +82,7 @@ def _install_stubs():
     for n in names:
         if n not in sys.modules:
             sys.modules[n] = _StubModule(n)
+            sys.modules[n].__path__ = []                  # a package: deeper submodules come from _StubFinder
     for n in names:
         if "." in n:
             parent, child = n.rsplit(".", 1)
@@ -389,6 +413,70 @@ def golden_image_processor():
     torch.save(out, os.path.join(OUT, "image_processor.pt"))
 
 
+class FakeTokenizer:
+    """Just enough tokenizer for get_external_inputs: special tokens map to fixed ids, "\n" to 198."""
+
+    def __init__(self):
+        from long_vita import constants as c
+        names = [c.IMG_TAG_TOKEN, c.VID_TAG_TOKEN, c.IMG_CONTEXT_TOKEN, c.IMG_START_TOKEN, c.IMG_END_TOKEN, c.VID_CONTEXT_TOKEN,
+                 c.VID_START_TOKEN, c.VID_END_TOKEN, c.PATCH_CONTEXT_TOKEN, c.PATCH_START_TOKEN, c.PATCH_END_TOKEN]
+        self.table = {n: 151700 + i for i, n in enumerate(names)}
+        self.table["\n"] = 198
+        self.pad_token_id, self.eos_token_id = None, 151645
+
+    def __call__(self, text, add_special_tokens=False):
+        return types.SimpleNamespace(input_ids=[self.table[text]])
+
+
+class FakeProcessor:
+    """Stands in for ImageProcessor: the pixel work is covered by image_processor.pt; here only the counts matter."""
+    patch_size = 448
+
+    def process_images_with_subpatch(self, spec):                             # spec = (tiles_x, tiles_y)
+        tx, ty = spec
+        n = tx * ty
+        return torch.zeros(n + 1 if n > 1 else 1, 3, 2, 2), (tx * 448, ty * 448)
+
+    def process_images(self, lst):
+        return torch.zeros(len(lst), 3, 2, 2)
+
+    def process_video(self, n_frames, max_num_frame, max_fps):
+        return torch.zeros(min(n_frames, max_num_frame), 3, 2, 2), None
+
+
+def golden_external_inputs():
+    """The reference's own get_external_inputs (M/tasks/inference/module.py:493-707) under the stub Megatron, with a fake
+    tokenizer / processor: token surgery for image tags (untiled, 2 x 1 and 2 x 3 tiles), video tags, both, and padding."""
+    import importlib
+    if "long_vita" in sys.modules and not hasattr(sys.modules["long_vita"], "__path__"):
+        sys.modules["long_vita"].__path__ = [os.path.join(REF, "long_vita")]
+    mod = importlib.import_module("long_vita_megatron.tasks.inference.module")
+    tok = FakeTokenizer()
+    from long_vita import constants as c
+    IMG, VID = tok.table[c.IMG_TAG_TOKEN], tok.table[c.VID_TAG_TOKEN]
+    STATE["args"].image_token_length, STATE["args"].max_num_frame, STATE["args"].max_fps, STATE["args"].bf16 = 256, 5, 1, True
+    rng = torch.Generator().manual_seed(5)
+
+    def text(n):
+        return torch.randint(0, 150000, (n,), generator=rng).tolist()
+
+    cases = [
+        dict(tokens=[text(7) + [IMG] + text(5)], image_list=[(1, 1)]),
+        dict(tokens=[text(3) + [IMG] + text(4) + [IMG] + text(9)], image_list=[(2, 1), (2, 3)]),
+        dict(tokens=[text(10) + [VID] + text(2)], video_path_list=[4]),
+        dict(tokens=[text(2) + [VID] + text(6)], video_path_list=[9]),                      # capped at max_num_frame = 5
+        dict(tokens=[[IMG] + text(1)], image_path_list=[(3, 1)]),
+    ]
+    out = {"table": tok.table, "cases": []}
+    with cpu_as_cuda():
+        for c in cases:
+            ext, toks, lens = mod.get_external_inputs(torch.tensor(c["tokens"]), c.get("image_list"), c.get("image_path_list"),
+                                                      c.get("video_path_list"), tok, FakeProcessor())
+            out["cases"].append(dict(c, out_tokens=toks.clone(), out_lengths=lens.clone(), indices=ext["indices"].clone(),
+                                     n_images=int(ext["images"].shape[0]), images_dtype=str(ext["images"].dtype)))
+    torch.save(out, os.path.join(OUT, "external_inputs.pt"))
+
+
 def _tree_map(p, f):
     if isinstance(p, dict):
         return {k: _tree_map(v, f) for k, v in p.items()}
@@ -412,6 +500,8 @@ def main():
     print("hf_vit ok")
     golden_image_processor()
     print("image_processor ok")
+    golden_external_inputs()
+    print("external_inputs ok")
 
 
 if __name__ == "__main__":

@@ -373,3 +373,42 @@ def test_oracle_siglip_matches_transformers():
     for lp in p["layers"]:
         x = ovit.vit_layer(x, lp, cfg)
     torch.testing.assert_close(x, ref, rtol=2e-4, atol=2e-4)
+
+
+def test_get_external_inputs_matches_reference_fixture():
+    """Token surgery for <image> / <video> tags, context-token indices, padding to 64: equal, integer for integer, to what the
+    reference's own get_external_inputs produced under the same fake tokenizer / processor (oracle/make_golden.py)."""
+    import types as _t
+
+    from conftest import load_golden
+    from long_vita_amd.inference_module import get_external_inputs
+    g = load_golden("external_inputs.pt")
+
+    class Tok:
+        pad_token_id, eos_token_id = None, 151645
+
+        def __call__(self, text, add_special_tokens=False):
+            return _t.SimpleNamespace(input_ids=[g["table"][text]])
+
+    class Proc:
+        patch_size = 448
+
+        def process_images_with_subpatch(self, spec):
+            n = spec[0] * spec[1]
+            return torch.zeros(n + 1 if n > 1 else 1, 3, 2, 2), (spec[0] * 448, spec[1] * 448)
+
+        def process_images(self, lst):
+            return torch.zeros(len(lst), 3, 2, 2)
+
+        def process_video(self, n_frames, max_num_frame, max_fps):
+            return torch.zeros(min(n_frames, max_num_frame), 3, 2, 2), None
+
+    assert len(g["cases"]) == 5
+    for c in g["cases"]:
+        ext, toks, lens = get_external_inputs(torch.tensor(c["tokens"]), c.get("image_list"), c.get("image_path_list"),
+                                              c.get("video_path_list"), Tok(), Proc(), image_token_length=256, max_num_frame=5,
+                                              max_fps=1, device="cpu")
+        assert torch.equal(toks, c["out_tokens"]) and torch.equal(lens, c["out_lengths"])
+        assert torch.equal(ext["indices"], c["indices"]) and ext["indices"].dtype == torch.int64
+        assert ext["images"].shape[0] == c["n_images"] and str(ext["images"].dtype) == c["images_dtype"]
+        assert toks.shape[1] % 64 == 0

@@ -291,3 +291,49 @@ def test_siglip_400m_vs_oracle(amd, nl, frames):
     out = vit(images=images.to(DEV))
     assert out.shape == ref.shape == (frames, 256, 5120)
     assert rel_l2(out, ref) < (1.5e-2 if nl == 2 else 3e-2), rel_l2(out, ref)
+
+
+def test_request_to_logits_end_to_end(amd):
+    """The whole drop-in chain on one request: `<image>` tag -> get_external_inputs (token surgery + dynamic tiling and
+    normalisation on the GPU) -> ViT + projector -> scatter -> decoder -> masked head, against the CPU chain built from the
+    oracle pieces (Pillow preprocessing, oracle ViT / decoder) on the same request."""
+    import types as _t
+
+    import numpy as np
+
+    from long_vita_amd import image_processor as ip_mod, inference_module as im
+    from oracle import preprocess as opre
+    cfgd = SMALL
+    ocfg, p, model = _llm_pair(amd, cfgd)
+    V = amd["vision"]
+    vcfg_o = ovit.ViTConfig(num_layers=1, llm_hidden=cfgd["hidden"])
+    vp = ovit.init_vit_params(vcfg_o, seed=21)
+    model.external_feature_model = V.MegatronVisionModel.from_oracle_layout(
+        V.VisionConfig(num_layers=1, llm_hidden=cfgd["hidden"]), vp, DEV)
+    names = [im.IMG_TAG_TOKEN, im.VID_TAG_TOKEN, im.IMG_CONTEXT_TOKEN, im.IMG_START_TOKEN, im.IMG_END_TOKEN, im.VID_CONTEXT_TOKEN,
+             im.VID_START_TOKEN, im.VID_END_TOKEN, im.PATCH_CONTEXT_TOKEN, im.PATCH_START_TOKEN, im.PATCH_END_TOKEN, "\n"]
+    table = {n: 1000 + i for i, n in enumerate(names)}
+
+    class Tok:
+        pad_token_id, eos_token_id = 0, 1
+
+        def __call__(self, text, add_special_tokens=False):
+            return _t.SimpleNamespace(input_ids=[table[text]])
+
+    rng = np.random.default_rng(8)
+    image = rng.integers(0, 256, (500, 940, 3), dtype=np.uint8)               # -> 2 x 1 tiles + thumbnail
+    gen = torch.Generator().manual_seed(4)
+    text = torch.randint(2, 1000, (1, 40), generator=gen)
+    text[0, 11] = table[im.IMG_TAG_TOKEN]
+    proc = ip_mod.ImageProcessor("dynamic", image_size=448, max_patch_grid=12)
+    ext, tokens, lens = im.get_external_inputs(text, [image], None, None, Tok(), proc, image_token_length=256)
+    n_img = ext["images"].shape[0]
+    assert n_img == 3 and tokens.shape[1] % 64 == 0 and int(lens[0]) == 40 - 1 + 3 * 258 + 1    # 3 x (start + 256 + end) + "\n"
+    ctx_len = int(lens[0])
+    out = amd["gen"].prefill_step(model, tokens, ctx_len, ext, reference_compat=False)
+    # CPU chain
+    ref_imgs, _ = opre.process_dynamic(image, 448, "imagenet", 1, 12)
+    assert torch.equal(ext["images"].cpu(), opre.to_model_dtype(ref_imgs))     # pixels: bit-exact
+    feats = ovit.vision_model(opre.to_model_dtype(ref_imgs), vp, vcfg_o)
+    ref = ollm.prefill_logits(tokens.cpu(), p, ocfg, [ctx_len - 1], {"features": feats, "indices": ext["indices"].cpu()})[:, -1]
+    assert rel_l2(out, ref) < 2e-2, rel_l2(out, ref)
