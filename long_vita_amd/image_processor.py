@@ -180,6 +180,51 @@ class ImageProcessor:
             return self.process_dynamic(img_or_path)
         raise NotImplementedError("only the 'dynamic' sub-patch path is built")
 
+    # -- process_video (:136-178) ----------------------------------------------------------------------------------------
+    @staticmethod
+    def video_frame_indices(total_frames: int, avg_fps: float, max_fps: int = 1, num_frames: int = 8):
+        """Frame selection of get_video_frames (:113-124) for a decoded-on-demand video: step = max(fps / max_fps,
+        total / (num_frames + 1)), indices int(i * step) below total."""
+        step_size = total_frames / (num_frames + 1)
+        step_size = max(avg_fps / max_fps, step_size)
+        indices = [int(i * step_size) for i in range(0, num_frames)]
+        return [i for i in indices if i < total_frames]
+
+    @staticmethod
+    def directory_frame_paths(video_dir: str, max_num_frame: int = 8, max_fps: int = 1):
+        """Frame selection of the directory branch (:137-163): png / jpeg / jpg files, natural order (natsort.natsorted:
+        digit runs compare as integers), fps 2 for ShareGPTVideo else 1, target = int(min(total / fps * max_fps, max)),
+        every int(total / target)-th file."""
+        import os
+        import re
+        all_filepath = []
+        for root, _dirs, files in os.walk(video_dir):
+            for filename in files:
+                if filename.endswith("png") or filename.endswith("jpeg") or filename.endswith("jpg"):
+                    all_filepath.append(os.path.join(root, filename))
+        if len(all_filepath) == 0:
+            return None
+        all_filepath.sort(key=lambda sp: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", sp)])
+        total_frame = len(all_filepath)
+        fps = 2 if "ShareGPTVideo" in video_dir else 1
+        target_frame = int(min(total_frame / fps * max_fps, max_num_frame))
+        index = [int(1.0 * total_frame / target_frame) * x for x in range(target_frame)]
+        return [all_filepath[x] for x in index]
+
+    def process_video(self, video_file_or_dir, max_num_frame=8, max_fps=1):
+        """Directory of frames: select (above), decode with PIL on the host, preprocess on the GPU.  A video FILE needs a
+        decoder (decord in the reference): decode the frames chosen by video_frame_indices yourself and call
+        process_images / process_frames."""
+        import os
+
+        from PIL import Image
+        if os.path.isdir(video_file_or_dir):
+            paths = self.directory_frame_paths(video_file_or_dir, max_num_frame, max_fps)
+            if paths is None:
+                return None
+            return self.process_images([Image.open(x).convert("RGB") for x in paths]), paths
+        raise NotImplementedError("video files need a decoder (decord is not part of this framework): see video_frame_indices")
+
     def process_images(self, img_or_array_list: Sequence):
         """:180-223.  Accepts decoded frames (PIL images or [H, W, 3] uint8 arrays); frames of equal size are batched
         into one launch.  Returns [N, 3, S, S] bf16 on the device (the dtype module.py:693 casts to)."""

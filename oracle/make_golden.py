@@ -408,6 +408,41 @@ def golden_image_processor():
         tiles, res = proc.process_dynamic(Image.fromarray(frame))
         out["dynamic"].append({"frame": torch.from_numpy(frame), "output_bf16": torch.tensor(tiles, dtype=torch.bfloat16),
                                "resolution": tuple(int(x) for x in res)})
+    # frame selection rules (process_video :136-178, get_video_frames :113-134) with a fake decord / natsort
+    class FakeVideoReader:
+        def __init__(self, spec, num_threads=1):
+            self.n, self.fps = spec
+
+        def __len__(self):
+            return self.n
+
+        def get_avg_fps(self):
+            return self.fps
+
+        def __getitem__(self, i):
+            return types.SimpleNamespace(asnumpy=lambda i=i: np.full((2, 2, 3), i % 256, dtype=np.uint8))
+
+    mod = sys.modules["long_vita_image_processor"]
+    mod.decord.VideoReader = FakeVideoReader
+    import re
+    mod.natsort.natsorted = lambda xs: sorted(xs, key=lambda sp: [int(t) if t.isdigit() else t for t in re.split(r"(\\d+)", sp)])
+    proc = ImageProcessor("", image_size=28)
+    out["video_index_rule"] = []
+    for (n, fps, num, mfps) in [(100, 25.0, 8, 1), (3000, 29.97, 64, 1), (40, 30.0, 8, 1), (500, 24.0, 16, 2), (7, 5.0, 8, 1)]:
+        frames = proc.get_video_frames((n, fps), max_fps=mfps, num_frames=num)
+        out["video_index_rule"].append(dict(total=n, fps=fps, num_frames=num, max_fps=mfps,
+                                            picked=[int(np.array(f)[0, 0, 0]) for f in frames]))
+    import tempfile
+    out["video_dir_rule"] = []
+    for tag, nfiles, maxf in [("plain", 23, 8), ("ShareGPTVideo_x", 30, 8), ("few", 3, 8)]:
+        with tempfile.TemporaryDirectory() as td:
+            d = os.path.join(td, tag)
+            os.makedirs(d)
+            for i in range(nfiles):
+                Image.fromarray(np.full((4, 4, 3), i, dtype=np.uint8)).save(os.path.join(d, f"frame{i}.png"))
+            _, paths = proc.process_video(d, max_num_frame=maxf, max_fps=1)
+            out["video_dir_rule"].append(dict(tag=tag, nfiles=nfiles, max_num_frame=maxf,
+                                              picked=[os.path.basename(x) for x in paths]))
     import PIL
     out["pillow_version"] = PIL.__version__
     torch.save(out, os.path.join(OUT, "image_processor.pt"))

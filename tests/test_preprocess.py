@@ -109,3 +109,23 @@ def test_hip_dynamic_tiling_bit_exact(proc_mod):
         tiles, res = proc.process_images_with_subpatch(frame)
         ref, ref_res = opre.process_dynamic(frame, 448, "imagenet", 1, 12)
         assert tuple(res) == ref_res and torch.equal(tiles.cpu(), opre.to_model_dtype(ref))
+
+
+def test_video_frame_selection_rules_match_reference_fixture(tmp_path):
+    """Which frames of a video are used (get_video_frames :113-124, the directory branch of process_video :137-163): same
+    indices / file names as the reference's class picked under a fake decord reader and natural file order."""
+    from PIL import Image
+
+    from long_vita_amd.image_processor import ImageProcessor
+    g = load_golden("image_processor.pt")
+    assert len(g["video_index_rule"]) == 5 and len(g["video_dir_rule"]) == 3
+    for c in g["video_index_rule"]:
+        idx = ImageProcessor.video_frame_indices(c["total"], c["fps"], c["max_fps"], c["num_frames"])
+        assert [i % 256 for i in idx] == c["picked"]
+    for c in g["video_dir_rule"]:
+        d = tmp_path / c["tag"]
+        d.mkdir()
+        for i in range(c["nfiles"]):
+            Image.fromarray(np.full((4, 4, 3), i, dtype=np.uint8)).save(str(d / f"frame{i}.png"))
+        paths = ImageProcessor.directory_frame_paths(str(d), c["max_num_frame"], 1)
+        assert [p.split("/")[-1] for p in paths] == c["picked"]
