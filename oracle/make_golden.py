@@ -425,7 +425,7 @@ def golden_image_processor():
     mod = sys.modules["long_vita_image_processor"]
     mod.decord.VideoReader = FakeVideoReader
     import re
-    mod.natsort.natsorted = lambda xs: sorted(xs, key=lambda sp: [int(t) if t.isdigit() else t for t in re.split(r"(\\d+)", sp)])
+    mod.natsort.natsorted = lambda xs: sorted(xs, key=lambda sp: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", sp)])
     proc = ImageProcessor("", image_size=28)
     out["video_index_rule"] = []
     for (n, fps, num, mfps) in [(100, 25.0, 8, 1), (3000, 29.97, 64, 1), (40, 30.0, 8, 1), (500, 24.0, 16, 2), (7, 5.0, 8, 1)]:
