@@ -10,6 +10,7 @@ LLM CP > 1  (TE AttnFuncWithCP P2P ring, gpt_layer_specs.py:40) -> ONE all-gathe
 """
 from __future__ import annotations
 
+import os
 from typing import Optional
 
 import torch
@@ -25,6 +26,8 @@ class DotProductAttention:
         self.causal = causal
         self.softmax_scale = softmax_scale
         self._kv_gather = None
+        self._streams = []
+        self.split_streams = bool(int(os.environ.get("VITA_CP_STREAMS", "1")))
 
     # -- Megatron calling convention: [s, b, heads, d] ---------------------------------------------
     def forward(self, query, key, value, attention_mask=None, attn_mask_type=None, packed_seq_params=None):
@@ -80,16 +83,40 @@ class DotProductAttention:
             kv_row += [p * 2 * s_l, p * 2 * s_l + c]
         if events:
             events[0].record()
+        # The per-split launches are a quarter of the heads each (640 workgroups at 128K / CP = 8 for 256 CUs): run them on
+        # separate HIP streams so that the workgroups of split j+1 fill the CUs that split j's tail leaves idle.
+        main = torch.cuda.current_stream()
+        side = self._side_streams(n_split - 1, q5.device) if (self.split_streams and n_split > 1) else []
+        ready = None
+        if side:
+            ready = torch.cuda.Event()
+            ready.record(main)                                      # q5 rotated, kv packed, gathers issued
+        done = []
         for j in range(n_split):
-            if works[j] is not None:
-                works[j].wait()
-            rows = gathered[j].view(cp * 2 * s_l, hg, d)          # K rows of rank p at p*2*s_l, V at +s_l
-            ops.flash_attn(q5[:, :, j * hg:(j + 1) * hg], rows.unsqueeze(0), rows[s_l:].unsqueeze(0), causal=True,
-                           softmax_scale=self.softmax_scale, chunk_len=c, q_chunk_gid=mpu.zigzag_chunk_ids(cp, r),
-                           kv_chunk_gid=kv_gid, kv_chunk_row=kv_row, out=out[:, :, j * hg * qpg:(j + 1) * hg * qpg])
+            stream = main if (j == 0 or not side) else side[j - 1]
+            with torch.cuda.stream(stream):
+                if stream is not main:
+                    stream.wait_event(ready)
+                if works[j] is not None:
+                    works[j].wait()                                 # this stream waits for gather j only
+                rows = gathered[j].view(cp * 2 * s_l, hg, d)        # K rows of rank p at p*2*s_l, V at +s_l
+                ops.flash_attn(q5[:, :, j * hg:(j + 1) * hg], rows.unsqueeze(0), rows[s_l:].unsqueeze(0), causal=True,
+                               softmax_scale=self.softmax_scale, chunk_len=c, q_chunk_gid=mpu.zigzag_chunk_ids(cp, r),
+                               kv_chunk_gid=kv_gid, kv_chunk_row=kv_row, out=out[:, :, j * hg * qpg:(j + 1) * hg * qpg])
+                if stream is not main:
+                    ev = torch.cuda.Event()
+                    ev.record(stream)
+                    done.append(ev)
+        for ev in done:
+            main.wait_event(ev)                                     # the o-projection (main stream) needs every split
         if events:
             events[1].record()
         return out
+
+    def _side_streams(self, n: int, device):
+        if len(self._streams) < n:
+            self._streams += [torch.cuda.Stream(device=device) for _ in range(n - len(self._streams))]
+        return self._streams[:n]
 
     def _gather_buffer(self, kv_local, cp):
         n = kv_local.numel() * cp
