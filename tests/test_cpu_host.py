@@ -412,3 +412,21 @@ def test_get_external_inputs_matches_reference_fixture():
         assert torch.equal(ext["indices"], c["indices"]) and ext["indices"].dtype == torch.int64
         assert ext["images"].shape[0] == c["n_images"] and str(ext["images"].dtype) == c["images_dtype"]
         assert toks.shape[1] % 64 == 0
+
+
+def test_c_abi_compiles_and_validates_from_plain_c(tmp_path):
+    """include/vita_hip.h is C (gcc -std=c11 -Wall -Werror), the library resolves from C, argument validation answers without
+    a GPU, and the ctypes struct mirrors have the sizes the C compiler gives the structs."""
+    import ctypes
+
+    from long_vita_amd import lib
+    lib.build()
+    exe = tmp_path / "abi_smoke"
+    src = os.path.join(ROOT, "tests", "c", "abi_smoke.c")
+    subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-I", os.path.join(ROOT, "include"), src, "-o", str(exe), "-ldl"],
+                   check=True)
+    out = subprocess.run([str(exe), lib.LIB_PATH], capture_output=True, text=True)
+    assert out.returncode == 0 and "C ABI OK" in out.stdout, out.stdout + out.stderr
+    sizes = dict(re.findall(r"sizeof\((\w+)\) = (\d+)", out.stdout))
+    assert int(sizes["vita_attn_params"]) == ctypes.sizeof(lib.AttnParams)
+    assert int(sizes["vita_decode_layer_params"]) == ctypes.sizeof(lib.DecodeLayerParams)
