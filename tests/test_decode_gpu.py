@@ -174,14 +174,14 @@ def test_cached_decode_with_visual_prompt(amd):
         assert lp_err(lp_c, lp_r) < 1.5e-2
 
 
-@pytest.mark.parametrize("cp,P,fused", [(2, 1500, True), (2, 1024, False), (4, 2300, True)])
+@pytest.mark.parametrize("cp,P,fused", [(2, 1500, True), (2, 1024, False), (4, 2300, True), (8, 4500, True)])
 def test_cached_decode_context_parallel(amd, monkeypatch, cp, P, fused):
     """Simulated CP ranks: padded zig-zag prefill fills the cache shards (pad rows dropped), generated tokens
     are appended round-robin, per-rank partials merged after the all-gather == CP = 1 cached decode."""
     cfgd = SMALL
     ocfg, p, model1 = _llm_pair(amd, cfgd)
     G = amd["gpt"]
-    n_new, max_len = 5, 4096
+    n_new, max_len = 5, 8192 if cp == 8 else 4096
     prompt = torch.randint(0, cfgd["vocab"], (1, P), generator=torch.Generator().manual_seed(P)).to(DEV)
     toks1, lp1 = _decode_run(amd, model1, prompt, n_new, max_len, True)
 

@@ -157,7 +157,7 @@ def _run_ranks(cp, fn, amd, monkeypatch):
     return results
 
 
-@pytest.mark.parametrize("cp,S", [(2, 2048), (4, 4096)])
+@pytest.mark.parametrize("cp,S", [(2, 2048), (4, 4096), (8, 8192)])
 def test_llm_prefill_context_parallel_vs_cp1(amd, monkeypatch, cp, S):
     """Zig-zag CP prefill (all-gather of K/V + chunk-table attention + masked head + sync_output) on
     `cp` simulated ranks reproduces the CP=1 logits; both are checked against the oracle."""
