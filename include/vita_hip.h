@@ -374,7 +374,9 @@ int vita_decode_layer_mlp(const vita_decode_layer_params* p, void* stream);
  *   -> pad_to_square != 0: expand2square with pad_rgb (:189-201)
  *   -> Pillow BICUBIC resize to out_w x out_h (:206-208 / :429, :443; 22-bit fixed-point separable passes with a
  *      uint8 intermediate, bit-exact)
- *   -> cut into tile x tile blocks in row-major order (the crop loop :431-441; tile == out_w == out_h: one block)
+ *   -> optionally pasted at (off_x, off_y) onto a canvas_w x canvas_h canvas (resize_and_pad_image :322-362; the caller
+ *      pre-fills `images` with the normalised pad colour; canvas_w <= 0: no canvas)
+ *   -> cut into tile x tile blocks in row-major order (the crop loops :431-441, :365-384; tile == out_w == out_h: one block)
  *   -> (x * 1.0 / 255.0 - mean) / std in float32 (:210-215) -> images [n * blocks][3][tile][tile] bf16.
  * h_bounds [out_w][2] / h_coeffs [out_w][h_ksize] and v_bounds [out_h][2] / v_coeffs [out_h][v_ksize] (int32,
  * device) are Pillow's precompute_coeffs / normalize_coeffs_8bpc tables for the (padded) source width -> out_w
@@ -383,7 +385,7 @@ int vita_decode_layer_mlp(const vita_decode_layer_params* p, void* stream);
  * [n][out_h][out_w][3]. */
 int vita_frames_resize_norm(const void* frames, int64_t frame_stride, int n, int height, int width,
                             int pad_to_square, const int* pad_rgb, int out_w, int out_h, int tile,
-                            const void* h_bounds, const void* h_coeffs, int h_ksize, const void* v_bounds,
+                            int canvas_w, int canvas_h, int off_x, int off_y, const void* h_bounds, const void* h_coeffs, int h_ksize, const void* v_bounds,
                             const void* v_coeffs, int v_ksize, const float* mean, const float* std_,
                             void* tmp, void* images, void* u8_out, void* stream);
 

@@ -49,7 +49,8 @@ __global__ __launch_bounds__(256) void resample_h_kernel(const uint8_t* __restri
 // vertical pass + normalisation.  The out_h x out_w result is cut into tile x tile images (row-major blocks, the crop
 // order of dynamic_preprocess): images[(n * tiles + block)][c][yy % tile][xx % tile] bf16; u8_out keeps the uncut result.
 __global__ __launch_bounds__(256) void resample_v_norm_kernel(const uint8_t* __restrict__ tmp, int Ph, int out_w, int out_h,
-                                                              int tile, const int* __restrict__ bounds,
+                                                              int tile, int canvas_w, int canvas_h, int off_x, int off_y,
+                                                              const int* __restrict__ bounds,
                                                               const int* __restrict__ kk, int ksize, float m0, float m1,
                                                               float m2, float sd0, float sd1, float sd2,
                                                               bf16_t* __restrict__ images, uint8_t* __restrict__ u8_out) {
@@ -71,10 +72,12 @@ __global__ __launch_bounds__(256) void resample_v_norm_kernel(const uint8_t* __r
     u[0] = (uint8_t)v0; u[1] = (uint8_t)v1; u[2] = (uint8_t)v2;
   }
   // float32, same operation order as numpy: (x * 1.0 / 255.0 - mean) / std, then round-to-nearest-even to bf16
-  const int tiles_x = out_w / tile, tiles = tiles_x * (out_h / tile);
-  const int block = (yy / tile) * tiles_x + xx / tile;
+  // position on the canvas the resized image is pasted onto (resize_and_pad_image :351-360; canvas == image otherwise)
+  const int cx = xx + off_x, cy = yy + off_y;
+  const int tiles_x = canvas_w / tile, tiles = tiles_x * (canvas_h / tile);
+  const int block = (cy / tile) * tiles_x + cx / tile;
   const int64_t plane = (int64_t)tile * tile;
-  bf16_t* o = images + ((int64_t)n * tiles + block) * 3 * plane + (int64_t)(yy % tile) * tile + (xx % tile);
+  bf16_t* o = images + ((int64_t)n * tiles + block) * 3 * plane + (int64_t)(cy % tile) * tile + (cx % tile);
   o[0] = f32_to_bf16(__fdiv_rn(__fsub_rn(__fdiv_rn((float)v0, 255.0f), m0), sd0));
   o[plane] = f32_to_bf16(__fdiv_rn(__fsub_rn(__fdiv_rn((float)v1, 255.0f), m1), sd1));
   o[2 * plane] = f32_to_bf16(__fdiv_rn(__fsub_rn(__fdiv_rn((float)v2, 255.0f), m2), sd2));
@@ -84,14 +87,16 @@ __global__ __launch_bounds__(256) void resample_v_norm_kernel(const uint8_t* __r
 
 extern "C" int vita_frames_resize_norm(const void* frames, int64_t frame_stride, int n, int height, int width,
                                        int pad_to_square, const int* pad_rgb, int out_w, int out_h, int tile,
-                                       const void* h_bounds, const void* h_coeffs, int h_ksize, const void* v_bounds,
+                                       int canvas_w, int canvas_h, int off_x, int off_y, const void* h_bounds, const void* h_coeffs, int h_ksize, const void* v_bounds,
                                        const void* v_coeffs, int v_ksize, const float* mean, const float* std_, void* tmp,
                                        void* images, void* u8_out, void* stream) {
   if (!frames || !h_bounds || !h_coeffs || !v_bounds || !v_coeffs || !tmp || !images || !pad_rgb || !mean || !std_)
     return VITA_ERR_INVALID_ARG;
   if (n < 0 || height <= 0 || width <= 0 || out_w <= 0 || out_h <= 0 || tile <= 0 || h_ksize <= 0 || v_ksize <= 0)
     return VITA_ERR_INVALID_ARG;
-  if (out_w % tile || out_h % tile) return VITA_ERR_INVALID_ARG;
+  if (canvas_w <= 0) { canvas_w = out_w; canvas_h = out_h; off_x = off_y = 0; }      // no canvas: the image itself
+  if (canvas_w % tile || canvas_h % tile || off_x < 0 || off_y < 0 || off_x + out_w > canvas_w || off_y + out_h > canvas_h)
+    return VITA_ERR_INVALID_ARG;
   if (n == 0) return VITA_OK;
   const int P = height > width ? height : width;
   const int Pw = pad_to_square ? P : width, Ph = pad_to_square ? P : height;     // expand2square (:189-201) or as is
@@ -104,7 +109,7 @@ extern "C" int vita_frames_resize_norm(const void* frames, int64_t frame_stride,
                      frame_stride, height, width, Ph, ox, oy, out_w, pad_rgb[0], pad_rgb[1], pad_rgb[2],
                      (const int*)h_bounds, (const int*)h_coeffs, h_ksize, (uint8_t*)tmp);
   hipLaunchKernelGGL(resample_v_norm_kernel, dim3(gx, (unsigned)out_h, (unsigned)n), block, 0, st, (const uint8_t*)tmp, Ph,
-                     out_w, out_h, tile, (const int*)v_bounds, (const int*)v_coeffs, v_ksize, mean[0], mean[1], mean[2],
+                     out_w, out_h, tile, canvas_w, canvas_h, off_x, off_y, (const int*)v_bounds, (const int*)v_coeffs, v_ksize, mean[0], mean[1], mean[2],
                      std_[0], std_[1], std_[2], (bf16_t*)images, (uint8_t*)u8_out);
   return vita_check_launch();
 }

@@ -91,8 +91,10 @@ class ImageProcessor:
         self.min_patch_grid, self.max_patch_grid = min_patch_grid, max_patch_grid
         self.device = device
         self._tables = {}
-        if process_type == "anyres":
-            raise NotImplementedError("process_anyres is not built (every reference script uses --vision-process-type dynamic)")
+        if process_type == "anyres":                                    # :48-59
+            self.grid_pinpoints = [(i, j) for i in range(min_patch_grid, max_patch_grid + 1)
+                                   for j in range(min_patch_grid, max_patch_grid + 1)]
+            self.possible_resolutions = [[dim * self.patch_size for dim in pair] for pair in self.grid_pinpoints]
         if process_type == "dynamic":                                   # :61-77
             max_num, min_num = self.max_patch_grid, self.min_patch_grid
             target_ratios = set((i, j) for n in range(min_num, max_num + 1) for i in range(1, n + 1)
@@ -108,9 +110,11 @@ class ImageProcessor:
             self._tables[(in_size, out_size)] = t
         return t
 
-    def _resize_norm(self, frames: torch.Tensor, out_w: int, out_h: int, tile: int, pad_to_square: bool, return_u8=False):
+    def _resize_norm(self, frames: torch.Tensor, out_w: int, out_h: int, tile: int, pad_to_square: bool, return_u8=False,
+                     canvas=None):
         """frames [N, H, W, 3] uint8 (device) -> [N * blocks, 3, tile, tile] bf16: Pillow-exact resize to out_w x out_h,
-        cut into tile x tile blocks (row-major), normalised."""
+        cut into tile x tile blocks (row-major), normalised.  canvas = (canvas_w, canvas_h, off_x, off_y, rgb): the resized
+        image is pasted onto a canvas of that size filled with `rgb` first (resize_and_pad_image)."""
         if frames.dtype != torch.uint8 or frames.dim() != 4 or frames.shape[-1] != 3 or not frames.is_cuda:
             raise ValueError("frames must be a [N, H, W, 3] uint8 HIP device tensor (no CPU fallback)")
         frames = frames.contiguous()
@@ -119,8 +123,13 @@ class ImageProcessor:
         pw, ph = (P, P) if pad_to_square else (w, h)
         hb, hc, hk = self._table(pw, out_w)
         vb, vc, vk = self._table(ph, out_h)
-        blocks = (out_w // tile) * (out_h // tile)
+        cw, ch, ox, oy = (canvas[0], canvas[1], canvas[2], canvas[3]) if canvas else (0, 0, 0, 0)
+        blocks = ((cw if canvas else out_w) // tile) * ((ch if canvas else out_h) // tile)
         out = torch.empty(n * blocks, 3, tile, tile, dtype=torch.bfloat16, device=frames.device)
+        if canvas:                                                       # normalised pad colour, same float32 op order
+            for ci in range(3):
+                v = (np.float32(canvas[4][ci]) * np.float32(1.0) / np.float32(255.0) - np.float32(self.mean[ci])) / np.float32(self.std[ci])
+                out[:, ci].fill_(float(v))
         u8 = torch.empty(n, out_h, out_w, 3, dtype=torch.uint8, device=frames.device) if return_u8 else None
         pad = (C.c_int * 3)(*[int(x * 255) for x in self.mean])             # tuple(int(x * 255) for x in mean) :204
         mean = (C.c_float * 3)(*[float(np.float32(x)) for x in self.mean])
@@ -131,7 +140,7 @@ class ImageProcessor:
         for i in range(0, n, chunk):
             m = min(chunk, n - i)
             _L.check(_L.load().vita_frames_resize_norm(
-                frames[i].data_ptr(), h * w * 3, m, h, w, int(pad_to_square), pad, out_w, out_h, tile, hb.data_ptr(),
+                frames[i].data_ptr(), h * w * 3, m, h, w, int(pad_to_square), pad, out_w, out_h, tile, cw, ch, ox, oy, hb.data_ptr(),
                 hc.data_ptr(), hk, vb.data_ptr(), vc.data_ptr(), vk, mean, std, tmp.data_ptr(), out[i * blocks].data_ptr(),
                 None if u8 is None else u8[i].data_ptr(), st), "vita_frames_resize_norm")
         return (out, u8) if return_u8 else out
@@ -174,11 +183,51 @@ class ImageProcessor:
             tiles = torch.cat([self._resize_norm(frame, S, S, S, False), tiles], dim=0)
         return tiles, (tw, th)
 
+    # -- select_best_resolution (:319-352) + resize_and_pad_image (:355-394) + divide_to_patches (:397-416) + process_anyres ----
+    def select_best_resolution(self, original_size):
+        original_width, original_height = original_size
+        best_fit, max_effective_resolution, min_wasted_resolution = None, 0, float("inf")
+        for width, height in self.possible_resolutions:
+            scale = min(width / original_width, height / original_height)
+            downscaled_width, downscaled_height = int(original_width * scale), int(original_height * scale)
+            effective_resolution = min(downscaled_width * downscaled_height, original_width * original_height)
+            wasted_resolution = (width * height) - effective_resolution
+            if effective_resolution > max_effective_resolution or (
+                    effective_resolution == max_effective_resolution and wasted_resolution < min_wasted_resolution):
+                max_effective_resolution, min_wasted_resolution, best_fit = effective_resolution, wasted_resolution, (width, height)
+        return best_fit
+
+    def process_anyres(self, img_or_array):
+        """One image -> ([image, tiles...] [1 + B, 3, S, S] bf16, best_resolution): aspect-preserving BICUBIC resize into the
+        best grid resolution, black padding, S x S tiles; the whole image (expand2square + resize) goes first.  A 1 x 1 grid
+        returns just the image (:279-282)."""
+        if self.process_type != "anyres":
+            raise ValueError("process_anyres needs process_type='anyres'")
+        arr = np.asarray(img_or_array.convert("RGB") if hasattr(img_or_array, "convert") else img_or_array, dtype=np.uint8)
+        h, w, _ = arr.shape
+        S = self.image_size
+        target_width, target_height = self.select_best_resolution((w, h))
+        frame = torch.from_numpy(arr)[None].to(self.device)
+        whole = self._resize_norm(frame, S, S, S, True)
+        if (target_width, target_height) == (S, S):
+            return whole, (target_width, target_height)
+        scale_w, scale_h = target_width / w, target_height / h              # resize_and_pad_image :338-350
+        if scale_w < scale_h:
+            new_width, new_height = target_width, min(math.ceil(h * scale_w), target_height)
+        else:
+            new_height, new_width = target_height, min(math.ceil(w * scale_h), target_width)
+        paste_x, paste_y = (target_width - new_width) // 2, (target_height - new_height) // 2
+        tiles = self._resize_norm(frame, new_width, new_height, S, False,
+                                  canvas=(target_width, target_height, paste_x, paste_y, (0, 0, 0)))
+        return torch.cat([whole, tiles], dim=0), (target_width, target_height)
+
     def process_images_with_subpatch(self, img_or_path):
         """:225-240"""
+        if self.process_type == "anyres":
+            return self.process_anyres(img_or_path)
         if self.process_type == "dynamic":
             return self.process_dynamic(img_or_path)
-        raise NotImplementedError("only the 'dynamic' sub-patch path is built")
+        return self.process_images([img_or_path])
 
     # -- process_video (:136-178) ----------------------------------------------------------------------------------------
     @staticmethod

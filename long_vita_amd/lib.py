@@ -21,7 +21,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libvita_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "vita_hip.h")
 
-ABI_VERSION = 9
+ABI_VERSION = 10
 VITA_OK = 0
 VITA_ERR_INVALID_ARG = -1
 VITA_ERR_UNSUPPORTED = -2
@@ -144,7 +144,7 @@ PROTOTYPES = {
     "vita_add_bf16": (_i, [_p, _p, _p, _l, _p]),
     "vita_decode_layer_attn": (_i, [C.POINTER(DecodeLayerParams), _p]),
     "vita_decode_layer_mlp": (_i, [C.POINTER(DecodeLayerParams), _p]),
-    "vita_frames_resize_norm": (_i, [_p, _l, _i, _i, _i, _i, C.POINTER(C.c_int), _i, _i, _i, _p, _p, _i, _p, _p, _i,
+    "vita_frames_resize_norm": (_i, [_p, _l, _i, _i, _i, _i, C.POINTER(C.c_int), _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _p, _i,
                                       C.POINTER(C.c_float), C.POINTER(C.c_float), _p, _p, _p, _p]),
     "vita_decode_attn_merge": (_i, [_p, _p, _p, _i, _l, _l, _i, _i, _p, _p, _p, _p, _p]),
 }

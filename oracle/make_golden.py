@@ -408,6 +408,14 @@ def golden_image_processor():
         tiles, res = proc.process_dynamic(Image.fromarray(frame))
         out["dynamic"].append({"frame": torch.from_numpy(frame), "output_bf16": torch.tensor(tiles, dtype=torch.bfloat16),
                                "resolution": tuple(int(x) for x in res)})
+    # anyres tiling (process_anyres :242-266)
+    out["anyres"] = []
+    proc = ImageProcessor("anyres", image_size=56, normalize_type="imagenet", min_patch_grid=1, max_patch_grid=4)
+    for h, w in [(90, 160), (300, 70), (56, 56), (61, 200), (40, 40)]:
+        frame = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        tiles, res = proc.process_anyres(Image.fromarray(frame))
+        out["anyres"].append({"frame": torch.from_numpy(frame), "output_bf16": torch.tensor(tiles, dtype=torch.bfloat16),
+                              "resolution": tuple(int(x) for x in res)})
     # frame selection rules (process_video :136-178, get_video_frames :113-134) with a fake decord / natsort
     class FakeVideoReader:
         def __init__(self, spec, num_threads=1):

@@ -81,3 +81,33 @@ def process_dynamic(frame: np.ndarray, image_size=448, normalize_type="imagenet"
     """ImageProcessor.process_dynamic (:299-316): tiles -> process_images -> [B, 3, S, S] float32, (tw, th)."""
     tiles, res = dynamic_preprocess(frame, min_patch_grid, max_patch_grid, image_size, True)
     return process_images(tiles, image_size, normalize_type), res
+
+
+def process_anyres(frame: np.ndarray, image_size=448, normalize_type="imagenet", min_patch_grid=1, max_patch_grid=6):
+    """ImageProcessor.process_anyres (:242-266) with select_best_resolution (:319-352), resize_and_pad_image (:355-394) and
+    divide_to_patches (:397-416): [image + tiles, 3, S, S] float32, best_resolution."""
+    import math
+    image = Image.fromarray(frame)
+    possible = [[i * image_size, j * image_size] for i in range(min_patch_grid, max_patch_grid + 1)
+                for j in range(min_patch_grid, max_patch_grid + 1)]
+    ow, oh = image.size
+    best_fit, max_eff, min_waste = None, 0, float("inf")
+    for width, height in possible:
+        scale = min(width / ow, height / oh)
+        dw, dh = int(ow * scale), int(oh * scale)
+        eff = min(dw * dh, ow * oh)
+        waste = width * height - eff
+        if eff > max_eff or (eff == max_eff and waste < min_waste):
+            max_eff, min_waste, best_fit = eff, waste, (width, height)
+    tw, th = best_fit
+    scale_w, scale_h = tw / ow, th / oh
+    if scale_w < scale_h:
+        nw, nh = tw, min(math.ceil(oh * scale_w), th)
+    else:
+        nh, nw = th, min(math.ceil(ow * scale_h), tw)
+    new_image = Image.new("RGB", (tw, th), (0, 0, 0))
+    new_image.paste(image.resize((nw, nh)), ((tw - nw) // 2, (th - nh) // 2))
+    patches = [np.array(new_image.crop((j, i, j + image_size, i + image_size)))
+               for i in range(0, th, image_size) for j in range(0, tw, image_size)]
+    tiles = [frame] if best_fit == (image_size, image_size) else [frame] + patches
+    return process_images(tiles, image_size, normalize_type), best_fit

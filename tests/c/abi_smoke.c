@@ -27,7 +27,7 @@ int main(int argc, char** argv) {
   int (*dlayer)(const vita_decode_layer_params*, void*) =
       (int (*)(const vita_decode_layer_params*, void*))dlsym(h, "vita_decode_layer_attn");
   CHECK(abi && errstr && rms && gemm && attn && dlayer);
-  CHECK(abi() >= 9);
+  CHECK(abi() >= 10);
   CHECK(strcmp(errstr(VITA_OK), "ok") == 0);
   CHECK(rms(NULL, NULL, NULL, NULL, 4, 64, 1e-6f, NULL) == VITA_ERR_INVALID_ARG);
   char dummy[16];

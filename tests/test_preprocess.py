@@ -21,6 +21,14 @@ def test_oracle_matches_reference_fixture():
         assert torch.equal(opre.to_model_dtype(out), case["output_bf16"])
 
 
+def test_oracle_anyres_tiling_matches_reference_fixture():
+    g = load_golden("image_processor.pt")
+    assert len(g["anyres"]) == 5
+    for case in g["anyres"]:
+        out, res = opre.process_anyres(case["frame"].numpy(), 56, "imagenet", 1, 4)
+        assert tuple(res) == case["resolution"] and torch.equal(opre.to_model_dtype(out), case["output_bf16"])
+
+
 def test_oracle_dynamic_tiling_matches_reference_fixture():
     g = load_golden("image_processor.pt")
     assert len(g["dynamic"]) == 5
@@ -129,3 +137,21 @@ def test_video_frame_selection_rules_match_reference_fixture(tmp_path):
             Image.fromarray(np.full((4, 4, 3), i, dtype=np.uint8)).save(str(d / f"frame{i}.png"))
         paths = ImageProcessor.directory_frame_paths(str(d), c["max_num_frame"], 1)
         assert [p.split("/")[-1] for p in paths] == c["picked"]
+
+
+@pytest.mark.gpu
+def test_hip_anyres_tiling_bit_exact(proc_mod):
+    """process_anyres on the device: best grid resolution, aspect-preserving resize pasted onto a black canvas, tile cut, the
+    whole image first — equal to the reference-made fixture (image_size 56) and to the oracle at 448."""
+    g = load_golden("image_processor.pt")
+    proc = proc_mod.ImageProcessor("anyres", image_size=56, normalize_type="imagenet", max_patch_grid=4)
+    for case in g["anyres"]:
+        tiles, res = proc.process_anyres(case["frame"].numpy())
+        assert tuple(res) == case["resolution"] and torch.equal(tiles.cpu(), case["output_bf16"])
+    proc = proc_mod.ImageProcessor("anyres", image_size=448, normalize_type="imagenet", max_patch_grid=3)
+    rng = np.random.default_rng(5)
+    for h, w in [(720, 1280), (1000, 333), (300, 300)]:
+        frame = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
+        tiles, res = proc.process_images_with_subpatch(frame)
+        ref, ref_res = opre.process_anyres(frame, 448, "imagenet", 1, 3)
+        assert tuple(res) == tuple(ref_res) and torch.equal(tiles.cpu(), opre.to_model_dtype(ref))
