@@ -402,7 +402,7 @@ def golden_image_processor():
                              "output": ref.clone(), "output_bf16": torch.tensor(ref, dtype=torch.bfloat16)})
     # dynamic tiling (--vision-process-type dynamic --max-patch-grid 12, every reference script)
     out["dynamic"] = []
-    proc = ImageProcessor("dynamic", image_size=56, normalize_type="imagenet", min_patch_grid=1, max_patch_grid=12)
+    proc = ImageProcessor("dynamic", image_size=28, normalize_type="imagenet", min_patch_grid=1, max_patch_grid=12)
     for h, w in [(90, 160), (300, 70), (56, 56), (61, 200), (75, 75)]:
         frame = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
         tiles, res = proc.process_dynamic(Image.fromarray(frame))
@@ -410,7 +410,7 @@ def golden_image_processor():
                                "resolution": tuple(int(x) for x in res)})
     # anyres tiling (process_anyres :242-266)
     out["anyres"] = []
-    proc = ImageProcessor("anyres", image_size=56, normalize_type="imagenet", min_patch_grid=1, max_patch_grid=4)
+    proc = ImageProcessor("anyres", image_size=28, normalize_type="imagenet", min_patch_grid=1, max_patch_grid=4)
     for h, w in [(90, 160), (300, 70), (56, 56), (61, 200), (40, 40)]:
         frame = rng.integers(0, 256, (h, w, 3), dtype=np.uint8)
         tiles, res = proc.process_anyres(Image.fromarray(frame))

@@ -25,7 +25,7 @@ def test_oracle_anyres_tiling_matches_reference_fixture():
     g = load_golden("image_processor.pt")
     assert len(g["anyres"]) == 5
     for case in g["anyres"]:
-        out, res = opre.process_anyres(case["frame"].numpy(), 56, "imagenet", 1, 4)
+        out, res = opre.process_anyres(case["frame"].numpy(), 28, "imagenet", 1, 4)
         assert tuple(res) == case["resolution"] and torch.equal(opre.to_model_dtype(out), case["output_bf16"])
 
 
@@ -33,7 +33,7 @@ def test_oracle_dynamic_tiling_matches_reference_fixture():
     g = load_golden("image_processor.pt")
     assert len(g["dynamic"]) == 5
     for case in g["dynamic"]:
-        out, res = opre.process_dynamic(case["frame"].numpy(), 56, "imagenet", 1, 12)
+        out, res = opre.process_dynamic(case["frame"].numpy(), 28, "imagenet", 1, 12)
         assert res == case["resolution"] and torch.equal(opre.to_model_dtype(out), case["output_bf16"])
 
 
@@ -104,9 +104,9 @@ def test_hip_process_images_on_reference_fixture_and_mixed_sizes(proc_mod):
 @pytest.mark.gpu
 def test_hip_dynamic_tiling_bit_exact(proc_mod):
     """process_dynamic on the device: closest-aspect grid, non-square Pillow-exact resize, tile cut, thumbnail first — equal to
-    the fixture made by the reference's class (image_size 56) and to the oracle at the real size (448, max_patch_grid 12)."""
+    the fixture made by the reference's class (image_size 28) and to the oracle at the real size (448, max_patch_grid 12)."""
     g = load_golden("image_processor.pt")
-    proc = proc_mod.ImageProcessor("dynamic", image_size=56, normalize_type="imagenet", max_patch_grid=12)
+    proc = proc_mod.ImageProcessor("dynamic", image_size=28, normalize_type="imagenet", max_patch_grid=12)
     for case in g["dynamic"]:
         tiles, res = proc.process_dynamic(case["frame"].numpy())
         assert tuple(res) == case["resolution"] and torch.equal(tiles.cpu(), case["output_bf16"])
@@ -142,9 +142,9 @@ def test_video_frame_selection_rules_match_reference_fixture(tmp_path):
 @pytest.mark.gpu
 def test_hip_anyres_tiling_bit_exact(proc_mod):
     """process_anyres on the device: best grid resolution, aspect-preserving resize pasted onto a black canvas, tile cut, the
-    whole image first — equal to the reference-made fixture (image_size 56) and to the oracle at 448."""
+    whole image first — equal to the reference-made fixture (image_size 28) and to the oracle at 448."""
     g = load_golden("image_processor.pt")
-    proc = proc_mod.ImageProcessor("anyres", image_size=56, normalize_type="imagenet", max_patch_grid=4)
+    proc = proc_mod.ImageProcessor("anyres", image_size=28, normalize_type="imagenet", max_patch_grid=4)
     for case in g["anyres"]:
         tiles, res = proc.process_anyres(case["frame"].numpy())
         assert tuple(res) == case["resolution"] and torch.equal(tiles.cpu(), case["output_bf16"])
