@@ -70,11 +70,22 @@ def cpu_baseline(fpt_workload: float):
     flops = L * (2 * S * (cfg.hidden * qkv_out + cfg.hidden * cfg.heads * cfg.head_dim + 3 * cfg.hidden * cfg.ffn)
                  + 4 * cfg.head_dim * cfg.heads * (S * (S + 1) // 2))
     rate = flops / dt
+    # the ViT + projector leg of the same path: oracle.vit on 4 frames, seconds per frame
+    from oracle import vit as ovit
+    vcfg = ovit.ViTConfig()
+    vp = ovit.init_vit_params(vcfg, seed=2)
+    imgs = torch.randn(4, 3, 448, 448, generator=torch.Generator().manual_seed(3)).bfloat16()
+    t0 = time.perf_counter()
+    with torch.no_grad():
+        ovit.vision_model(imgs, vp, vcfg)
+    vit_s_per_frame = (time.perf_counter() - t0) / imgs.size(0)
     return {"value": rate / fpt_workload, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"{L} of 48 full-width decoder layers at S={S} (oracle.llm.decoder_layer, text-only) took {dt:.1f} s = "
                       f"{rate / 1e12:.2f} TFLOP/s on the host; value = that rate / the workload's algorithmic FLOPs per token "
                       f"({fpt_workload / 1e9:.1f} GFLOP); the linear per-layer extrapolation of the sample itself would be "
-                      f"{S / (dt / L * 48):.1f} tokens/s at S={S}"}
+                      f"{S / (dt / L * 48):.1f} tokens/s at S={S}; oracle.vit (24-layer ViT + projector) on 4 frames: "
+                      f"{vit_s_per_frame:.2f} s/frame",
+            "vit_s_per_frame": vit_s_per_frame}
 
 
 def main():

@@ -24,6 +24,9 @@ def get_batch_on_this_cp_rank(tokens, position_ids, external_inputs):
     cp_size = mpu.get_context_parallel_world_size()
     if cp_size == 1:
         return tokens, position_ids, external_inputs
+    if external_inputs["images"].shape[0] == 0:      # inference_module's per-rank loader: no visual token on this rank
+        r = mpu.get_context_parallel_rank()
+        return training_utils.zigzag_slice(tokens, cp_size, r), training_utils.zigzag_slice(position_ids, cp_size, r), None
     batch = {"tokens": tokens, "position_ids": position_ids,
              "external_images": external_inputs["images"], "external_indices": external_inputs["indices"]}
     batch = training_utils.get_batch_on_this_cp_rank(batch, seq_length=tokens.shape[1])

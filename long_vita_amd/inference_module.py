@@ -11,7 +11,15 @@ statement (bit-exact: fixture made by the reference's own function, tests/golden
 
 The pixels come from long_vita_amd.image_processor.ImageProcessor (GPU kernels) instead of PIL on the host; get_args()
 values are keyword arguments.  `video_frames_list` (already decoded frames, one [N, H, W, 3] uint8 array per <video> tag)
-is this framework's addition: file decoding (decord) is out of scope."""
+is this framework's addition: file decoding (decord) is out of scope.
+
+Per-rank loading (cp_size / cp_rank given).  The reference builds all N frames on rank 0 and broadcasts them to the
+world (4.9 GB at 4096 frames, module.py:340-360); get_batch_on_this_cp_rank (generation.py:517-539) then throws away, on
+every rank, the frames without a token in the rank's two zig-zag chunks.  Which frames those are depends only on the
+token layout, so here every rank lays the tokens out first (no pixel touched), keeps the frames
+`frames_on_this_cp_rank` names, and decodes / uploads / resizes only those: the returned images / indices are exactly the
+rows the reference's selection would keep, and that selection is idempotent on them (every returned frame has a token
+on the rank; source rows are renumbered over the selected frames), so everything downstream is unchanged."""
 from __future__ import annotations
 
 from typing import Optional, Sequence
@@ -31,10 +39,56 @@ def _single_id(tokenizer, text: str) -> int:
     return ids[0]
 
 
+def frames_on_this_cp_rank(starts: Sequence[int], length: int, seq_length: int, cp_size: int, cp_rank: int):
+    """keep[i] = does the context-token run [starts[i], starts[i] + length) intersect the rank's zig-zag chunks
+    {r, 2CP-1-r} of a sequence of seq_length tokens — the frame selection of M/training/utils.py:279-289
+    (mask = isin(indices_s, calibration_index); image kept iff mask.any(dim=-1)) in closed form."""
+    if seq_length % (2 * cp_size):
+        raise ValueError(f"sequence length {seq_length} not divisible by 2*CP = {2 * cp_size}")
+    c = seq_length // (2 * cp_size)
+    owned = ((cp_rank * c, (cp_rank + 1) * c), ((2 * cp_size - 1 - cp_rank) * c, (2 * cp_size - cp_rank) * c))
+    return [any(st < hi and st + length > lo for lo, hi in owned) for st in starts]
+
+
+def _video_sources(image_processor, vid_idx, image_list, image_path_list, video_path_list, video_frames_list,
+                   max_num_frame, max_fps):
+    """The frames a <video> tag stands for, as things process_images accepts, without touching a pixel
+    (same precedence as the eager branch below: the last list given wins)."""
+    import os
+    src = None
+    if video_path_list is not None:
+        path = video_path_list[vid_idx]
+        if not os.path.isdir(path):
+            raise NotImplementedError("video files need a decoder (decord is not part of this framework): "
+                                      "decode the frames ImageProcessor.video_frame_indices names and pass video_frames_list")
+        src = image_processor.directory_frame_paths(path, max_num_frame, max_fps)
+    if image_path_list is not None:
+        src = [image_path_list[vid_idx]]
+    if image_list is not None:
+        src = [image_list[vid_idx]]
+    if video_frames_list is not None:
+        src = list(video_frames_list[vid_idx])[:max_num_frame]
+    return src
+
+
+def _open_frames(sources):
+    from PIL import Image
+    return [Image.open(x).convert("RGB") if isinstance(x, str) else x for x in sources]
+
+
 def get_external_inputs(tokens, image_list, image_path_list, video_path_list, tokenizer, image_processor, *,
                         image_token_length: int = 256, max_num_frame: int = 4096, max_fps: int = 1, bf16: bool = True,
-                        video_frames_list: Optional[Sequence] = None, device="cuda"):
+                        video_frames_list: Optional[Sequence] = None, device="cuda",
+                        cp_size: Optional[int] = None, cp_rank: Optional[int] = None, cp_seq_length: Optional[int] = None):
+    """cp_size / cp_rank: per-rank loading (module docstring); cp_seq_length = the length the sequence is chunked at when
+    that is not the 64-padded row (generation._cp_prefill_length pads a KV-cache prefill to 2*CP*256)."""
+    per_rank = cp_size is not None and cp_size > 1
+    if per_rank and (cp_rank is None or not 0 <= cp_rank < cp_size):
+        raise ValueError("per-rank loading needs 0 <= cp_rank < cp_size")
     tokens = tokens.tolist()
+    if per_rank and len(tokens) != 1:
+        raise ValueError("per-rank loading runs batch 1")
+    pending = {}                                                               # slot in `images` -> frame sources
     IMG_CONTEXT_ID, IMG_START_ID, IMG_END_ID = (_single_id(tokenizer, t) for t in (IMG_CONTEXT_TOKEN, IMG_START_TOKEN, IMG_END_TOKEN))
     VID_CONTEXT_ID, VID_START_ID, VID_END_ID = (_single_id(tokenizer, t) for t in (VID_CONTEXT_TOKEN, VID_START_TOKEN, VID_END_TOKEN))
     PATCH_CONTEXT_ID, PATCH_START_ID, PATCH_END_ID = (_single_id(tokenizer, t) for t in (PATCH_CONTEXT_TOKEN, PATCH_START_TOKEN, PATCH_END_TOKEN))
@@ -91,13 +145,17 @@ def get_external_inputs(tokens, image_list, image_path_list, video_path_list, to
                 assert len(vid_positions) == len(lst)
         new_input_ids, st = [], 0
         for vid_idx, vid_pos in enumerate(vid_positions):
-            if video_path_list is not None:
+            if per_rank:
+                video_frames = _video_sources(image_processor, vid_idx, image_list, image_path_list, video_path_list,
+                                              video_frames_list, max_num_frame, max_fps)
+                pending[len(images)] = video_frames
+            elif video_path_list is not None:
                 video_frames, _ = image_processor.process_video(video_path_list[vid_idx], max_num_frame, max_fps)
-            if image_path_list is not None:
+            if not per_rank and image_path_list is not None:
                 video_frames = image_processor.process_images([image_path_list[vid_idx]])
-            if image_list is not None:
+            if not per_rank and image_list is not None:
                 video_frames = image_processor.process_images([image_list[vid_idx]])
-            if video_frames_list is not None:
+            if not per_rank and video_frames_list is not None:
                 video_frames = image_processor.process_images(list(video_frames_list[vid_idx])[:max_num_frame])
             images.append(video_frames)
             new_input_ids += input_ids[st:vid_pos]
@@ -110,11 +168,31 @@ def get_external_inputs(tokens, image_list, image_path_list, video_path_list, to
         new_input_ids += input_ids[st:]
         tokens[batch_idx] = new_input_ids
 
-    images = torch.cat(images, dim=0)
     image_indices = torch.cat(image_indices, dim=1)
     pad_id = tokenizer.pad_token_id if tokenizer.pad_token_id else tokenizer.eos_token_id
     token_lengths = [len(x) for x in tokens]
     tokens = [x + [pad_id] * (-(-len(x) // 64) * 64 - len(x)) for x in tokens]
+    if per_rank:
+        seq_length = len(tokens[0]) if cp_seq_length is None else cp_seq_length
+        keep = frames_on_this_cp_rank(image_indices[1, :, 0].tolist(), image_token_length, seq_length, cp_size, cp_rank)
+        kept, at = [], 0
+        for slot, entry in enumerate(images):
+            n = len(entry)
+            mine = [i for i in range(n) if keep[at + i]]
+            at += n
+            if not mine:
+                continue
+            if slot in pending:                                                # only these frames are decoded / uploaded
+                kept.append(image_processor.process_images(_open_frames([entry[i] for i in mine])))
+            else:
+                kept.append(entry[mine])
+        assert at == len(keep)
+        image_indices = image_indices[:, torch.tensor(keep, dtype=torch.bool)]
+        images = kept
+    if len(images) == 0:                                                       # a rank whose chunks hold text only
+        size = getattr(image_processor, "image_size", 448)
+        images = [torch.empty(0, 3, size, size)]
+    images = torch.cat(images, dim=0)
 
     external_inputs = {"indices": image_indices.contiguous().to(device),
                        "images": images.to(dtype=torch.bfloat16 if bf16 else torch.float16).contiguous().to(device)}

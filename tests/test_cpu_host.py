@@ -414,6 +414,80 @@ def test_get_external_inputs_matches_reference_fixture():
         assert toks.shape[1] % 64 == 0
 
 
+@pytest.mark.parametrize("cp", [2, 4, 8])
+def test_per_rank_frame_loading_equals_reference_selection(cp):
+    """get_external_inputs(cp_size=, cp_rank=) touches only the frames with a token on the rank, and what it returns is
+    what the reference's selection (oracle.glue.get_batch_on_this_cp_rank, pinned by cp_batch.pt) keeps of the full
+    output — images, and src / tgt indices after running the selection on it again (idempotence)."""
+    import types as _t
+
+    from oracle import glue
+    from long_vita_amd.inference_module import frames_on_this_cp_rank, get_external_inputs
+    IMG, VID = 900001, 900002
+    table = {"<image>": IMG, "<video>": VID, "<IMG_CONTEXT>": 900003, "<img>": 900004, "</img>": 900005,
+             "<VID_CONTEXT>": 900006, "<vid>": 900007, "</vid>": 900008, "<PATCH_CONTEXT>": 900009, "<patch>": 900010,
+             "</patch>": 900011, "\n": 198}
+
+    class Tok:
+        pad_token_id, eos_token_id = None, 151645
+
+        def __call__(self, text, add_special_tokens=False):
+            return _t.SimpleNamespace(input_ids=[table[text]])
+
+    class Proc:
+        patch_size, image_size = 448, 2
+        touched = []
+
+        def process_images_with_subpatch(self, spec):
+            n = spec[0] * spec[1]
+            n = n + 1 if n > 1 else 1
+            return torch.arange(n).view(n, 1, 1, 1).expand(n, 3, 2, 2).float() + 1000 * spec[2], (spec[0] * 448, spec[1] * 448)
+
+        def process_images(self, lst):                       # a "frame" is its own id
+            Proc.touched += [int(x[0, 0, 0]) for x in lst]
+            return torch.stack([torch.full((3, 2, 2), float(x[0, 0, 0])) for x in lst])
+
+    L = 8                                                    # context tokens per frame (the rule is length-agnostic)
+    g = torch.Generator().manual_seed(cp)
+    text = lambda n: torch.randint(0, 150000, (n,), generator=g).tolist()
+    n_frames = 37
+    video = [torch.full((1, 1, 3), 5000 + i) for i in range(n_frames)]
+    # the reference reads image_list inside the <video> branch too (module.py:640-645), so a request carries one kind
+    requests = [(text(11) + [VID] + text(29), None, dict(video_frames_list=[video]), n_frames),
+                (text(5) + [IMG] + text(40) + [IMG] + text(17) + [IMG] + text(3), [(2, 1, 7), (1, 1, 8), (2, 3, 9)], {}, 3 + 1 + 7)]
+    for row, image_list, extra, n_units in requests:
+        kw = dict(image_token_length=L, max_num_frame=64, max_fps=1, device="cpu", **extra)
+        full, toks, lens = get_external_inputs(torch.tensor([row]), image_list, None, None, Tok(), Proc(), **kw)
+        S = toks.shape[1]
+        assert S % (2 * cp) == 0 and full["images"].shape[0] == n_units
+        pos = torch.arange(S).unsqueeze(0)
+        n_empty = 0
+        for r in range(cp):
+            Proc.touched = []
+            mine, toks_r, lens_r = get_external_inputs(torch.tensor([row]), image_list, None, None, Tok(), Proc(), cp_size=cp,
+                                                       cp_rank=r, **kw)
+            assert torch.equal(toks_r, toks) and torch.equal(lens_r, lens)
+            keep = frames_on_this_cp_rank(full["indices"][1, :, 0].tolist(), L, S, cp, r)
+            if not any(keep):
+                assert mine["images"].shape[0] == 0 and mine["indices"].shape == (2, 0, L)
+                n_empty += 1
+                continue
+            ref = glue.get_batch_on_this_cp_rank({"tokens": toks, "position_ids": pos, "external_images": full["images"].float(),
+                                                  "external_indices": full["indices"]}, S, cp, r)
+            assert torch.equal(mine["images"].float(), ref["external_images"])
+            assert torch.equal(mine["indices"], full["indices"][:, torch.tensor(keep)])
+            again = glue.get_batch_on_this_cp_rank({"tokens": toks, "position_ids": pos, "external_images": mine["images"].float(),
+                                                    "external_indices": mine["indices"]}, S, cp, r)
+            for k in ("external_images", "external_src_indices", "external_tgt_indices"):
+                assert torch.equal(again[k], ref[k]), k
+            if image_list is None:                       # only the rank's video frames went through the pixel path
+                assert sorted(Proc.touched) == [5000 + i for i in range(n_frames) if keep[i]]
+                assert len(Proc.touched) < n_frames
+        assert n_empty < cp
+    with pytest.raises(ValueError):
+        get_external_inputs(torch.tensor([row]), image_list, None, None, Tok(), Proc(), cp_size=cp, cp_rank=cp, **kw)
+
+
 def test_c_abi_compiles_and_validates_from_plain_c(tmp_path):
     """include/vita_hip.h is C (gcc -std=c11 -Wall -Werror), the library resolves from C, argument validation answers without
     a GPU, and the ctypes struct mirrors have the sizes the C compiler gives the structs."""

@@ -203,6 +203,60 @@ def test_cp_prefill_with_video_tokens(amd, monkeypatch):
     assert rel_l2(outs[0], single) < 1.5e-2
 
 
+def test_per_rank_frame_loading_gives_the_same_cp_prefill(amd, monkeypatch):
+    """get_external_inputs(cp_size=, cp_rank=) (no world broadcast of all frames): each simulated
+    rank decodes / resizes only its own frames, the pixels are the rows of the global result, and the CP prefill logits are
+    bit-identical to the ones computed from the global request."""
+    import types as _t
+
+    import numpy as np
+
+    from long_vita_amd import image_processor as ip_mod, inference_module as im
+    cp, n_frames, S = 2, 7, 2048
+    cfgd = SMALL
+    ocfg, p, model1 = _llm_pair(amd, cfgd)
+    V, G = amd["vision"], amd["gpt"]
+    vit = V.MegatronVisionModel.random_init(V.VisionConfig(num_layers=1, llm_hidden=cfgd["hidden"]), seed=4, device=DEV)
+    names = [im.IMG_TAG_TOKEN, im.VID_TAG_TOKEN, im.IMG_CONTEXT_TOKEN, im.IMG_START_TOKEN, im.IMG_END_TOKEN, im.VID_CONTEXT_TOKEN,
+             im.VID_START_TOKEN, im.VID_END_TOKEN, im.PATCH_CONTEXT_TOKEN, im.PATCH_START_TOKEN, im.PATCH_END_TOKEN, "\n"]
+    table = {n: 1000 + i for i, n in enumerate(names)}
+
+    class Tok:
+        pad_token_id, eos_token_id = 0, 1
+
+        def __call__(self, text, add_special_tokens=False):
+            return _t.SimpleNamespace(input_ids=[table[text]])
+
+    rng = np.random.default_rng(3)
+    video = [rng.integers(0, 256, (90, 160, 3), dtype=np.uint8) for _ in range(n_frames)]
+    text = torch.randint(2, 1000, (1, 60), generator=torch.Generator().manual_seed(9))
+    text[0, 20] = table[im.VID_TAG_TOKEN]
+    proc = ip_mod.ImageProcessor("", image_size=448)
+    kw = dict(image_token_length=256, max_num_frame=16, video_frames_list=[video])
+    full, tokens, lens = im.get_external_inputs(text, None, None, None, Tok(), proc, **kw)
+    ctx = int(lens[0])
+    assert ctx == 59 + n_frames * 258 and tokens.shape[1] <= S
+    tokens = torch.cat([tokens, tokens.new_zeros(1, S - tokens.shape[1])], dim=1)       # chunked at S = 2 * CP * 512
+    mine = [im.get_external_inputs(text, None, None, None, Tok(), proc, cp_size=cp, cp_rank=r, cp_seq_length=S, **kw)[0]
+            for r in range(cp)]
+    keep = [im.frames_on_this_cp_rank(full["indices"][1, :, 0].tolist(), 256, S, cp, r) for r in range(cp)]
+    for r in range(cp):
+        sel = torch.tensor(keep[r], device=DEV)
+        assert 0 < int(sel.sum()) < n_frames
+        assert torch.equal(mine[r]["images"], full["images"][sel]) and torch.equal(mine[r]["indices"], full["indices"][:, sel])
+
+    def run(ext_of_rank):
+        def rank_fn(r):
+            m = G.GPTVLModel(model1.cfg, model1.p, vit)
+            return amd["gen"].prefill_step(m, tokens, ctx, ext_of_rank(r), reference_compat=False)
+        return _run_ranks(cp, rank_fn, amd, monkeypatch)
+
+    a = run(lambda r: full)
+    b = run(lambda r: mine[r])
+    assert torch.equal(a[0], a[1]) and torch.equal(b[0], b[1])
+    assert torch.equal(a[0], b[0])
+
+
 def test_reference_compat_logit_mask_rule(amd):
     """generation.py:141-165 incl. the wrap at ctx % half == 0."""
     gen, mpu = amd["gen"], amd["mpu"]

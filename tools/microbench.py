@@ -82,8 +82,41 @@ def bench_hbm():
     emit(kind="gemm_skinny", M=2, N=152064, K=cols, ms=med, gbps=152064 * cols * 2 / med / 1e6)
 
 
+def bench_peaks():
+    """'achievable peak' references measured on the same box — the vendor GEMM library (hipBLASLt /
+    rocBLAS behind torch.matmul, bf16 in, fp32 accumulate) on the decoder's shapes and on a square problem, this
+    library's kernel beside it, and a device-to-device copy / a read-only reduction for the HBM ceiling.
+    torch.matmul is a yardstick here, not part of the product path."""
+    for (M, N, K, tag) in [(8192, 8192, 8192, "square8k"), (131072, 5120, 5120, "S128K/o"), (131072, 27648, 5120, "S128K/fc1"),
+                           (131072, 5120, 13824, "S128K/fc2"), (16384, 7168, 5120, "S16K/qkv")]:
+        a = (torch.randn(M, K, device=DEV) * 0.5).bfloat16()
+        w = (torch.randn(N, K, device=DEV) * 0.02).bfloat16()
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        med, best = timeit(lambda: torch.matmul(a, w.t(), out=out))
+        emit(kind="peak_gemm_vendor", tag=tag, M=M, N=N, K=K, ms=med, ms_best=best, tflops=2.0 * M * N * K / med / 1e9)
+        med2, best2 = timeit(lambda: ops.gemm(a, w, 0, None, None, None, out=out))
+        emit(kind="peak_gemm_ours", tag=tag, M=M, N=N, K=K, ms=med2, ms_best=best2, tflops=2.0 * M * N * K / med2 / 1e9,
+             ours_over_vendor=med / med2)
+        del a, w, out
+    n = 1 << 31                                                       # 2 GiB each way: far beyond the 256 MB MALL
+    src = torch.empty(n, dtype=torch.uint8, device=DEV).random_(0, 255)
+    dst = torch.empty_like(src)
+    med, best = timeit(lambda: dst.copy_(src))
+    emit(kind="peak_hbm_copy", bytes_each_way=n, ms=med, ms_best=best, gbps_read_plus_write=2 * n / med / 1e6)
+    x = src.view(torch.bfloat16).view(-1, 5120)
+    y = dst.view(torch.bfloat16).view(-1, 5120)
+    w = torch.ones(5120, device=DEV).bfloat16()
+    med, best = timeit(lambda: ops.rmsnorm(x, w, 1e-6, out=y))
+    emit(kind="peak_hbm_rmsnorm_ours", bytes_each_way=n, ms=med, ms_best=best, gbps_read_plus_write=2 * n / med / 1e6)
+    f = src.view(torch.float32)
+    med, best = timeit(lambda: f.sum())
+    emit(kind="peak_hbm_read_only", bytes=n, ms=med, ms_best=best, gbps=n / med / 1e6)
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "attn", "hbm"]
+    if "peaks" in which:
+        bench_peaks()
     if "gemm" in which:
         for (M, tag) in [(16384, "S16K"), (131072, "S128K")]:
             bench_gemm(M, 7168, 5120, 1, tag + "/qkv")
