@@ -185,7 +185,11 @@ def main():
     }
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
-            line["cpu_baseline"] = cpu_baseline(fpt)
+            try:
+                line["cpu_baseline"] = cpu_baseline(fpt)
+            except Exception as e:  # noqa: BLE001 — a reported baseline must not cost the measured line
+                line["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+                                        "sample": f"failed: {type(e).__name__}: {e}"}
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
