@@ -223,16 +223,16 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 256 && WM * WN == 4) ? 1 : 2) 
     }
     w_src[q] = p.W + g * p.ldw + ls * 8;
   }
-  auto stage = [&](unsigned sl) __attribute__((always_inline)) {
+  auto stage = [&](unsigned sl, int adv) __attribute__((always_inline)) {
 #pragma unroll
     for (int q = 0; q < QA; ++q) {
       __builtin_amdgcn_global_load_lds((gbl_cvoid*)a_src[q], (lds_void*)(uintptr_t)(sl + (wave * QA + q) * 1024), 16, 0, 0);
-      a_src[q] += BK;
+      a_src[q] += adv;
     }
 #pragma unroll
     for (int q = 0; q < QW; ++q) {
       __builtin_amdgcn_global_load_lds((gbl_cvoid*)w_src[q], (lds_void*)(uintptr_t)(sl + A_BYTES + (wave * QW + q) * 1024), 16, 0, 0);
-      w_src[q] += BK;
+      w_src[q] += adv;
     }
   };
 
@@ -253,13 +253,15 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 256 && WM * WN == 4) ? 1 : 2) 
       for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
 
   const int nk = (int)(p.K / BK);
-  stage(lds0);
+  // measurement aid (EPI 0 only, VITA_GEMM_EXP=10): ldr = -1 makes every K tile re-read tile 0, so all loads hit L1/L2
+  const int kstep = (EPI == VITA_EPI_NONE && p.ldr == -1) ? 0 : BK;
+  stage(lds0, kstep);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int t = 0; t < nk; ++t) {
     const unsigned cur = lds0 + (t & 1) * STAGE;
-    if (t + 1 < nk) stage(lds0 + ((t + 1) & 1) * STAGE);
+    if (t + 1 < nk) stage(lds0 + ((t + 1) & 1) * STAGE, kstep);
     bf16x8 af[4][MI], wf[4][NI];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -298,6 +300,177 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 256 && WM * WN == 4) ? 1 : 2) 
   }
 
   gemm_epilogue<EPI, MI, NI, TM, TN>(p, acc, m0, n0, wm, wn, lane);
+}
+
+// ---- 4 waves x (128 x 128): one wave per SIMD, operands HBM/L2 -> VGPR -> LDS ------------------------------------------
+// Per MFMA this geometry moves 0.5 KiB of fragment reads + 0.25 KiB of staging writes through the LDS port (the 8-wave
+// kernel above: 0.75 + 0.25), and the port is what bounds these kernels.  With one wave per SIMD nothing hides a stall,
+// so program order is the issue order (sched_group_barrier pins the MFMAs between the memory instructions):
+// (slot plan above the main loop).
+// MODE (measurement only, EPI 0; results are wrong for MODE > 0): 1 = every K tile re-reads tile 0 (all loads hit L1/L2),
+// 2 = no global loads / LDS writes, 3 = no fragment reads either (MFMA stream only) — the ablation ladder in DESIGN.md §4.2
+template <int EPI, int MODE = 0>
+__global__ __launch_bounds__(256, 1) void gemm4_kernel(GemmArgs p) {
+  constexpr int BM = 256, BN = 256, WN = 2, TM = 128, TN = 128, MI = 4, NI = 4;
+  constexpr int A_BYTES = BM * BK * 2, W_BYTES = BN * BK * 2, STAGE = A_BYTES + W_BYTES;
+  constexpr int QA = 8, QW = 8, NP = QA + QW, NF = MI + NI, NM = MI * NI;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  int pid;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  constexpr int GROUP_M = 4;
+  const int per_group = GROUP_M * p.tiles_n;
+  const int group = pid / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int in_group = pid - group * per_group;
+  const int tm = first_m + in_group % gsz;
+  const int tn = in_group / gsz;
+  const int64_t m0 = (int64_t)tm * BM;
+  const int64_t n0 = (int64_t)tn * (EPI == VITA_EPI_SWIGLU ? BN / 2 : BN);
+
+  // piece j of a wave = 8 tile rows x 128 B: lane -> (row (wave*8 + j)*8 + lane/8, 16-B slot lane&7), stored swizzled
+  const bf16_t* src[NP];
+  unsigned dst[NP];
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    const bool isw = j >= QA;
+    const int lr = (wave * 8 + (isw ? j - QA : j)) * 8 + (lane >> 3);
+    int64_t g;
+    if (!isw) {
+      g = m0 + lr;
+      g = g < p.M ? g : p.M - 1;
+      src[j] = p.A + g * p.lda + (lane & 7) * 8;
+    } else {
+      if (EPI == VITA_EPI_SWIGLU) {
+        const int blk = lr >> 5;
+        int64_t oc = n0 + (blk >> 1) * 32 + (lr & 31);
+        oc = oc < p.N ? oc : p.N - 1;
+        g = ((blk & 1) ? p.N : 0) + oc;
+      } else {
+        g = n0 + lr;
+        g = g < p.N ? g : p.N - 1;
+      }
+      src[j] = p.W + g * p.ldw + (lane & 7) * 8;
+    }
+    dst[j] = (isw ? A_BYTES : 0) + tile_off(lr, lane & 7);
+  }
+  unsigned fa[4], fw[4];
+#pragma unroll
+  for (int kk = 0; kk < 4; ++kk) {
+    fa[kk] = tile_off(wm * TM + (lane & 31), kk * 2 + (lane >> 5));
+    fw[kk] = A_BYTES + tile_off(wn * TN + (lane & 31), kk * 2 + (lane >> 5));
+  }
+  f32x16 acc[NI][MI];
+#pragma unroll
+  for (int i = 0; i < NI; ++i)
+#pragma unroll
+    for (int j = 0; j < MI; ++j)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
+
+  const int nk = (int)(p.K / BK);
+  u32x4 g[NP];
+  bf16x8 af[2][MI], wf[2][NI];
+  auto read_frag = [&](unsigned base, int kk, int set, int i) __attribute__((always_inline)) {
+    if (i == 0) wf[set][0] = *(lds_bf16x8*)(uintptr_t)(base + fw[kk]);
+    else if (i <= MI) af[set][i - 1] = *(lds_bf16x8*)(uintptr_t)(base + fa[kk] + (i - 1) * 32 * 128);
+    else wf[set][i - MI] = *(lds_bf16x8*)(uintptr_t)(base + fw[kk] + (i - MI) * 32 * 128);
+  };
+  // prologue: tile 0 -> stage 0, tile 1 -> registers, first fragments
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    g[j] = *(const u32x4*)src[j];
+    src[j] += (nk > 1 && MODE == 0) ? BK : 0;
+  }
+#pragma unroll
+  for (int j = 0; j < NP; ++j) *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(lds0 + dst[j]) = g[j];
+  __syncthreads();
+#pragma unroll
+  for (int j = 0; j < NP; ++j) {
+    g[j] = *(const u32x4*)src[j];
+    src[j] += (nk > 2 && MODE == 0) ? BK : 0;
+  }
+#pragma unroll
+  for (int i = 0; i < NF; ++i) read_frag(lds0, 0, 0, i);
+  if (MODE == 3) {
+#pragma unroll
+    for (int i = 0; i < NF; ++i) read_frag(lds0, 1, 1, i);
+  }
+
+  // Every MFMA has exactly one memory instruction behind it (64 + 64 per K tile):
+  //   positions 0..7 of k-steps 0..2 : fragment reads of the next k-step
+  //   positions 8..15 of k-steps 0, 1 : ds_write_b128 of tile t+1 (in registers since the previous iteration) -> other stage
+  //   positions 8..15 of k-step 2, 0..7 of k-step 3 : global_load_dwordx4 of tile t+2
+  //   position 8 of k-step 3        : lgkmcnt(0) + s_barrier (no vmcnt: the loads just issued stay in flight)
+  //   positions 8..15 of k-step 3   : first fragment reads of tile t+1
+  for (int t = 0; t < nk; ++t) {
+    const unsigned cur = lds0 + (t & 1) * STAGE, nxt = lds0 + ((t + 1) & 1) * STAGE;
+    const int adv = (MODE == 0 && t + 3 < nk) ? BK : 0;   // the pointers stop at the last K tile (re-staged, never read)
+#pragma unroll
+    for (int kk = 0; kk < 4; ++kk) {
+#pragma unroll
+      for (int ni = 0; ni < NI; ++ni)
+#pragma unroll
+        for (int mi = 0; mi < MI; ++mi) {
+          const int i = ni * MI + mi;
+          if (kk == 3 && i == NM / 2) {
+            __builtin_amdgcn_sched_barrier(0);
+            asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+            __builtin_amdgcn_sched_barrier(0);
+          }
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk & 1][ni], af[kk & 1][mi], acc[ni][mi], 0, 0, 0);
+          if (kk == 3 && i >= NM / 2) __builtin_amdgcn_sched_group_barrier(0x008, 1, 1);
+          else __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          if (MODE < 3 && kk < 3 && i < NF) {
+            read_frag(cur, kk + 1, (kk + 1) & 1, i);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          }
+          if (MODE < 3 && kk == 3 && i >= NM / 2) {
+            read_frag(nxt, 0, 0, i - NM / 2);
+            __builtin_amdgcn_sched_group_barrier(0x100, 1, 1);
+          }
+          if (MODE >= 2) continue;
+          if (kk < 2 && i >= NM / 2) {
+            const int j = kk * 8 + i - NM / 2;
+            *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(nxt + dst[j]) = g[j];
+            __builtin_amdgcn_sched_group_barrier(0x200, 1, 0);
+          }
+          if ((kk == 2 && i >= NM / 2) || (kk == 3 && i < NM / 2)) {
+            const int j = kk == 2 ? i - NM / 2 : 8 + i;
+            g[j] = *(const u32x4*)src[j];
+            src[j] += adv;
+            __builtin_amdgcn_sched_group_barrier(0x020, 1, 0);
+          }
+        }
+    }
+  }
+  gemm_epilogue<EPI, MI, NI, TM, TN>(p, acc, m0, n0, wm, wn, lane);
+}
+
+template <int EPI, int MODE = 0>
+int launch_gemm4(GemmArgs a, hipStream_t st) {
+  constexpr int lds = 2 * (256 + 256) * BK * 2;
+  const int64_t tm = (a.M + 255) / 256;
+  const int64_t bn_out = EPI == VITA_EPI_SWIGLU ? 128 : 256;
+  const int64_t tn = (a.N + bn_out - 1) / bn_out;
+  if (tm * tn > 0x7fffffff) return VITA_ERR_UNSUPPORTED;
+  a.tiles_m = (int)tm; a.tiles_n = (int)tn;
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<EPI, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((gemm4_kernel<EPI, MODE>), dim3((unsigned)(tm * tn)), dim3(256), lds, st, a);
+  return vita_check_launch();
 }
 
 // ---- skinny-M (M <= 16): one wave per output column, x rows cached in LDS ------------------
@@ -380,6 +553,15 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
   if (gemm_tile_override() == 256) big = true;
   static const bool nopin = getenv("VITA_GEMM_NOPIN") != nullptr;     // developer tuning aid
   if (gemm_tile_override() == 2564) return launch_gemm_cfg<EPI, 256, 256, 2, 2>(a, st);   // 4 waves x (128 x 128)
+  if (EPI == VITA_EPI_NONE) {     // developer measurement aids, read per launch (tools/microbench.py variants)
+    const char* e = getenv("VITA_GEMM_EXP");
+    const int v = e ? atoi(e) : 0;
+    if (v == 10) { GemmArgs b = a; b.ldr = -1; return launch_gemm_cfg<EPI, 256, 256, 2, 4>(b, st); }   // 8 waves, L2-hit loads
+    if (v == 4) return launch_gemm4<EPI>(a, st);                                                        // 4 waves x (128 x 128)
+    if (v == 41) return launch_gemm4<VITA_EPI_NONE, 1>(a, st);
+    if (v == 42) return launch_gemm4<VITA_EPI_NONE, 2>(a, st);
+    if (v == 43) return launch_gemm4<VITA_EPI_NONE, 3>(a, st);
+  }
   if (nopin) return big ? launch_gemm_cfg<EPI, 256, 256, 2, 4, false>(a, st) : launch_gemm_cfg<EPI, 128, 128, 2, 2, false>(a, st);
   return big ? launch_gemm_cfg<EPI, 256, 256, 2, 4>(a, st) : launch_gemm_cfg<EPI, 128, 128, 2, 2>(a, st);
 }

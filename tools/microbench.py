@@ -103,18 +103,41 @@ def bench_peaks():
     dst = torch.empty_like(src)
     med, best = timeit(lambda: dst.copy_(src))
     emit(kind="peak_hbm_copy", bytes_each_way=n, ms=med, ms_best=best, gbps_read_plus_write=2 * n / med / 1e6)
-    x = src.view(torch.bfloat16).view(-1, 5120)
-    y = dst.view(torch.bfloat16).view(-1, 5120)
+    rows = (n // 2) // 5120
+    x = src.view(torch.bfloat16)[:rows * 5120].view(rows, 5120)
+    y = dst.view(torch.bfloat16)[:rows * 5120].view(rows, 5120)
     w = torch.ones(5120, device=DEV).bfloat16()
     med, best = timeit(lambda: ops.rmsnorm(x, w, 1e-6, out=y))
-    emit(kind="peak_hbm_rmsnorm_ours", bytes_each_way=n, ms=med, ms_best=best, gbps_read_plus_write=2 * n / med / 1e6)
+    emit(kind="peak_hbm_rmsnorm_ours", bytes_each_way=rows * 5120 * 2, ms=med, ms_best=best, gbps_read_plus_write=2 * rows * 5120 * 2 / med / 1e6)
     f = src.view(torch.float32)
     med, best = timeit(lambda: f.sum())
     emit(kind="peak_hbm_read_only", bytes=n, ms=med, ms_best=best, gbps=n / med / 1e6)
 
 
+def bench_gemm_variants():
+    """Experiment: placement of the LDS-DMA pieces in the 256x256 GEMM (VITA_GEMM_EXP, see gemm.hip)."""
+    for (M, N, K, tag) in [(131072, 5120, 5120, "S128K/o"), (131072, 5120, 13824, "S128K/fc2"), (16384, 7168, 5120, "S16K/qkv"),
+                           (8192, 8192, 8192, "square8k")]:
+        a = (torch.randn(M, K, device=DEV) * 0.5).bfloat16()
+        w = (torch.randn(N, K, device=DEV) * 0.02).bfloat16()
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        ref = torch.matmul(a[:4096], w.t()).float()
+        for v in os.environ.get("VARIANTS", "0,4").split(","):
+            os.environ["VITA_GEMM_EXP"] = v
+            out.zero_()
+            med, best = timeit(lambda: ops.gemm(a, w, 0, None, None, None, out=out))
+            err = float((out[:4096].float() - ref).abs().max())
+            tail = float((out[-256:].float() - torch.matmul(a[-256:], w.t()).float()).abs().max())
+            emit(kind="gemm_dma_variant", variant=v, tag=tag, ms=med, ms_best=best, tflops=2.0 * M * N * K / med / 1e9,
+                 max_abs_err_vs_vendor=err, tail_err=tail)
+        os.environ.pop("VITA_GEMM_EXP")
+        del a, w, out
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "attn", "hbm"]
+    if "variants" in which:
+        bench_gemm_variants()
     if "peaks" in which:
         bench_peaks()
     if "gemm" in which:
