@@ -21,7 +21,6 @@
 // Replaces torch.matmul / TE linears (see include/vita_hip.h).
 #include "vita_common.h"
 #include <stdlib.h>
-#include <type_traits>
 
 namespace {
 
@@ -474,184 +473,6 @@ int launch_gemm4(GemmArgs a, hipStream_t st) {
   return vita_check_launch();
 }
 
-// ---- gemm5 (experimental, VITA_GEMM_EXP=5): 4 waves x (128 x 128), BK = 32, ring of three LDS stages -------------------------
-// What the gemm4 ablation asks for: the first fragments of tile t+1 are read BEFORE the barrier of tile t
-// (tile t+1 was stored during iteration t-1), loads run four tiles ahead through two staging register sets, and every wait
-// is counted by hand — the loads are inline asm, which hipcc's waitcnt pass does not track, so a store waits with
-// vmcnt(15 - j) for exactly its own load (issued 48 MFMAs earlier) instead of the vmcnt(0) the compiler emits for a
-// loop-carried load.  Per iteration (32 MFMAs per wave): slots 0-7 fragment reads of (t, k-step 1), 8-15 ds_write_b128 of
-// tile t+2, 16-23 fragment reads of (t+1, k-step 0), 24-31 global_load_dwordx4 of tile t+4; lgkmcnt(0) + s_barrier.
-// sched_barrier(0) after every slot: program order is the issue order.
-__device__ __forceinline__ int tile_off32(int row, int slot) {       // [rows][32] bf16: 64-byte rows, slot ^ ((row >> 2) & 3)
-  return row * 64 + ((slot ^ ((row >> 2) & 3)) << 4);
-}
-
-template <int EPI>
-__global__ __launch_bounds__(256, 1) void gemm5_kernel(GemmArgs p) {
-  constexpr int BM = 256, BN = 256, WN = 2, TM = 128, TN = 128, MI = 4, NI = 4, BK5 = 32;
-  constexpr int A_BYTES = BM * BK5 * 2, STAGE = 2 * A_BYTES;      // 16 KiB + 16 KiB
-  constexpr int NPC = 8, NF = MI + NI;
-  extern __shared__ __attribute__((aligned(16))) char smem[];
-  const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-
-  const int nwg = p.tiles_m * p.tiles_n;
-  int pid;
-  {
-    const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
-    pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
-  }
-  constexpr int GROUP_M = 4;
-  const int per_group = GROUP_M * p.tiles_n;
-  const int group = pid / per_group;
-  const int first_m = group * GROUP_M;
-  const int gsz = min(p.tiles_m - first_m, GROUP_M);
-  const int in_group = pid - group * per_group;
-  const int tm = first_m + in_group % gsz;
-  const int tn = in_group / gsz;
-  const int64_t m0 = (int64_t)tm * BM;
-  const int64_t n0 = (int64_t)tn * (EPI == VITA_EPI_SWIGLU ? BN / 2 : BN);
-
-  // piece j of a thread: operand (j < 4: A, else W), tile row (j & 3) * 64 + tid / 4, 16-byte slot tid & 3
-  const bf16_t* src[NPC];
-  unsigned dst[NPC];
-#pragma unroll
-  for (int j = 0; j < NPC; ++j) {
-    const bool isw = j >= 4;
-    const int lr = (j & 3) * 64 + (tid >> 2);
-    int64_t g;
-    if (!isw) {
-      g = m0 + lr;
-      g = g < p.M ? g : p.M - 1;
-      src[j] = p.A + g * p.lda + (tid & 3) * 8;
-    } else {
-      if (EPI == VITA_EPI_SWIGLU) {
-        const int blk = lr >> 5;
-        int64_t oc = n0 + (blk >> 1) * 32 + (lr & 31);
-        oc = oc < p.N ? oc : p.N - 1;
-        g = ((blk & 1) ? p.N : 0) + oc;
-      } else {
-        g = n0 + lr;
-        g = g < p.N ? g : p.N - 1;
-      }
-      src[j] = p.W + g * p.ldw + (tid & 3) * 8;
-    }
-    dst[j] = (isw ? A_BYTES : 0) + tile_off32(lr, tid & 3);
-  }
-  unsigned fa[2], fw[2];
-#pragma unroll
-  for (int kk = 0; kk < 2; ++kk) {
-    fa[kk] = tile_off32(wm * TM + (lane & 31), kk * 2 + (lane >> 5));
-    fw[kk] = A_BYTES + tile_off32(wn * TN + (lane & 31), kk * 2 + (lane >> 5));
-  }
-  f32x16 acc[NI][MI];
-#pragma unroll
-  for (int i = 0; i < NI; ++i)
-#pragma unroll
-    for (int j = 0; j < MI; ++j)
-#pragma unroll
-      for (int r = 0; r < 16; ++r) acc[i][j][r] = 0.f;
-
-  const int nk = (int)(p.K / BK5);
-  u32x4 g[2][NPC];
-  bf16x8 af[2][MI], wf[2][NI];
-  auto read_frag = [&](unsigned base, int kk, int i) __attribute__((always_inline)) {   // fragment set = k-step
-    if (i == 0) wf[kk][0] = *(lds_bf16x8*)(uintptr_t)(base + fw[kk]);
-    else if (i <= MI) af[kk][i - 1] = *(lds_bf16x8*)(uintptr_t)(base + fa[kk] + (i - 1) * 32 * 64);
-    else wf[kk][i - MI] = *(lds_bf16x8*)(uintptr_t)(base + fw[kk] + (i - MI) * 32 * 64);
-  };
-  int loaded = 0;                                                    // tiles fetched so far (the pointers stop at nk - 1)
-  auto load_tile = [&](int set) __attribute__((always_inline)) {
-    const int adv = (loaded + 1 < nk) ? BK5 : 0;
-#pragma unroll
-    for (int j = 0; j < NPC; ++j) {
-      asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(g[set][j]) : "v"(src[j]) : "memory");
-      src[j] += adv;
-    }
-    ++loaded;
-  };
-  auto store_tile = [&](int set, unsigned stage) __attribute__((always_inline)) {
-#pragma unroll
-    for (int j = 0; j < NPC; ++j) *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(stage + dst[j]) = g[set][j];
-  };
-  // prologue: tiles 0, 1 -> stages 0, 1; tiles 2, 3 -> register sets 0, 1; fragments (0, k-step 0)
-  load_tile(0);
-  load_tile(1);
-  asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-  store_tile(0, lds0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  store_tile(1, lds0 + STAGE);
-  load_tile(0);
-  load_tile(1);
-  asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-#pragma unroll
-  for (int i = 0; i < NF; ++i) read_frag(lds0, 0, i);
-
-  unsigned st_cur = lds0, st_nxt = lds0 + STAGE, st_wr = lds0 + 2 * STAGE;
-  auto body = [&](auto setc) __attribute__((always_inline)) {
-    constexpr int SET = decltype(setc)::value;
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk)
-#pragma unroll
-      for (int ni = 0; ni < NI; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < MI; ++mi) {
-          const int i = ni * MI + mi;
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(wf[kk][ni], af[kk][mi], acc[ni][mi], 0, 0, 0);
-          if (kk == 0 && i < NF) read_frag(st_cur, 1, i);                               // slots 0-7
-          if (kk == 1 && i < NF) read_frag(st_nxt, 0, i);                               // slots 16-23
-          if (kk == 0 && i >= 8) {                                                      // slots 8-15: tile t+2 -> LDS
-            const int j = i - 8;
-            if (j == 0) asm volatile("s_waitcnt vmcnt(15)" ::: "memory");
-            if (j == 1) asm volatile("s_waitcnt vmcnt(14)" ::: "memory");
-            if (j == 2) asm volatile("s_waitcnt vmcnt(13)" ::: "memory");
-            if (j == 3) asm volatile("s_waitcnt vmcnt(12)" ::: "memory");
-            if (j == 4) asm volatile("s_waitcnt vmcnt(11)" ::: "memory");
-            if (j == 5) asm volatile("s_waitcnt vmcnt(10)" ::: "memory");
-            if (j == 6) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
-            if (j == 7) asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
-            *(__attribute__((address_space(3))) u32x4*)(uintptr_t)(st_wr + dst[j]) = g[SET][j];
-          }
-          if (kk == 1 && i >= 8) {                                                      // slots 24-31: tile t+4 -> registers
-            const int j = i - 8;
-            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(g[SET][j]) : "v"(src[j]) : "memory");
-            src[j] += (loaded + 1 < nk) ? BK5 : 0;
-          }
-          __builtin_amdgcn_sched_barrier(0);
-        }
-    ++loaded;
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-    const unsigned o = st_cur;
-    st_cur = st_nxt; st_nxt = st_wr; st_wr = o;
-  };
-  for (int t = 0; t < nk; t += 2) {                   // K % 64 == 0 (checked at the C entry): nk is even
-    body(std::integral_constant<int, 0>{});
-    body(std::integral_constant<int, 1>{});
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");      // the staging registers are dead from here on
-  gemm_epilogue<EPI, MI, NI, TM, TN>(p, acc, m0, n0, wm, wn, lane);
-}
-
-template <int EPI>
-int launch_gemm5(GemmArgs a, hipStream_t st) {
-  constexpr int lds = 3 * 2 * 256 * 32 * 2;
-  if (a.K % 64) return VITA_ERR_UNSUPPORTED;
-  const int64_t tm = (a.M + 255) / 256;
-  const int64_t bn_out = EPI == VITA_EPI_SWIGLU ? 128 : 256;
-  const int64_t tn = (a.N + bn_out - 1) / bn_out;
-  if (tm * tn > 0x7fffffff) return VITA_ERR_UNSUPPORTED;
-  a.tiles_m = (int)tm; a.tiles_n = (int)tn;
-  static bool attr_set = false;
-  if (!attr_set) {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm5_kernel<EPI>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((gemm5_kernel<EPI>), dim3((unsigned)(tm * tn)), dim3(256), lds, st, a);
-  return vita_check_launch();
-}
-
 // ---- skinny-M (M <= 16): one wave per output column, x rows cached in LDS ------------------
 // HBM-bound on W: algorithmic bytes = N*K*2.  Each lane streams 16-byte pieces of one W row.
 template <int MAXM>
@@ -737,7 +558,6 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     const int v = e ? atoi(e) : 0;
     if (v == 10) { GemmArgs b = a; b.ldr = -1; return launch_gemm_cfg<EPI, 256, 256, 2, 4>(b, st); }   // 8 waves, L2-hit loads
     if (v == 4) return launch_gemm4<EPI>(a, st);                                                        // 4 waves x (128 x 128)
-    if (v == 5) return launch_gemm5<EPI>(a, st);                                                        // ring of 3, BK = 32
     if (v == 41) return launch_gemm4<VITA_EPI_NONE, 1>(a, st);
     if (v == 42) return launch_gemm4<VITA_EPI_NONE, 2>(a, st);
     if (v == 43) return launch_gemm4<VITA_EPI_NONE, 3>(a, st);
