@@ -15,11 +15,12 @@ Pinning status ("how do we know the restatement is right"):
     under ``tests/golden/``; ``tests/test_oracle_golden.py`` checks every restatement here against
     those fixtures.  Pinned that way: zig-zag CP slice + index remap, index_of_a_in_b, RoPE table
     / apply / CP slice, RMSNorm, embedding scatter (3 forms), logits-masked linear fwd + bwd,
-    pixel-shuffle, HF InternViT layer / full ViT / projector.
+    pixel-shuffle, HF InternViT layer / full ViT / projector, Pillow resize / tiling / frame selection,
+    get_external_inputs token surgery, and the decode-time logit-mask rule + sync_output order + block pick
+    (the reference's decode loop run as CP gloo processes, decode_loop.pt).
   * Restated but only cross-checked (no runnable reference): unfused attention math
     (M/core/transformer/dot_product_attention.py needs Megatron objects) — checked against
     torch SDPA and the HF ViT `_naive_attn`; decoder-layer assembly — checked against
-    transformers' Qwen2 (5.x installed, reference pins >=4.48.3); decode-time logit-mask rule
-    (inline in a 250-line function, M/inference/text_generation/generation.py:141-165).
+    transformers' Qwen2 (5.x installed, reference pins >=4.48.3).
     For these rows parity is "unpinned against the reference itself".
 """

@@ -520,6 +520,97 @@ def golden_external_inputs():
     torch.save(out, os.path.join(OUT, "external_inputs.pt"))
 
 
+DECODE_CASES = [dict(name="cp2_s32", cp=2, seq=32, prompt=5, vocab=97),            # context 5..31: crosses ctx % 8 == 0 three times
+                dict(name="cp4_s64", cp=4, seq=64, prompt=13, vocab=101),
+                dict(name="cp1_s24", cp=1, seq=24, prompt=3, vocab=89)]
+
+
+def fake_next_token(tok: torch.Tensor, pos: torch.Tensor, vocab: int) -> torch.Tensor:
+    """The "model" of the decode-loop fixture: the logits at a position are one-hot at a function of the token there and of
+    its GLOBAL position, so the sampled token says which position's logits the loop picked."""
+    return (tok * 7 + pos * 3 + 1) % vocab
+
+
+def _decode_worker(rank: int, case: dict, port: int, out_dir: str):
+    """One CP rank of the reference's decode loop (M/inference/text_generation/generation.py:33-280, with its
+    get_batch_on_this_cp_rank :517-539 and sync_output :542-566) on CPU + gloo, Megatron stubbed."""
+    import torch.distributed as dist
+    cp, seq, vocab = case["cp"], case["seq"], case["vocab"]
+    _install_stubs()
+    STATE["cp_size"], STATE["cp_rank"] = cp, rank
+    a = STATE["args"]
+    a.use_kv_cache, a.logit_mask = False, True                       # server_cp .sh:184 (no cache under CP) + --logit-mask
+    a.max_position_embeddings, a.max_tokens_to_oom, a.padded_vocab_size, a.eos_id = 1 << 20, 1 << 30, vocab, -1
+    a.reset_position_ids, a.context_parallel_size, a.seq_length = False, cp, seq
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=cp)
+    for mod in ("megatron.core.mpu", "megatron.core.parallel_state"):
+        m = sys.modules[mod]
+        m.is_pipeline_last_stage = lambda: True
+        m.get_context_parallel_group = lambda: None
+    sys.modules["megatron.training"].get_tokenizer = lambda: types.SimpleNamespace(eod=-1)
+    gen = importlib.import_module("long_vita_megatron.inference.text_generation.generation")
+    gen.copy_from_last_to_first_pipeline_stage = lambda *a_, **k_: None
+    gen.broadcast_from_last_pipeline_stage = lambda size, dtype, tensor=None: tensor
+    gen.broadcast_from_last_to_first_pipeline_stage = lambda size, dtype, tensor=None: tensor
+    masks = []
+
+    class FakeForwardStep:
+        def __init__(self, model, batch_size, max_sequence_length, external_inputs=None):
+            self.inference_params = types.SimpleNamespace(external_inputs=external_inputs, logit_mask=None, use_kv_cache=True)
+
+        def __call__(self, tokens, position_ids, attention_mask):
+            lm = self.inference_params.logit_mask
+            sel = lm[0].nonzero().flatten()                          # masked_select keeps ascending position order
+            masks.append(sel.tolist())
+            nxt = fake_next_token(tokens[0, sel], position_ids[0, sel], vocab)
+            return torch.nn.functional.one_hot(nxt, vocab).float()[None]          # [1, n_sel, V]
+
+    gen.ForwardStep = FakeForwardStep
+    g = torch.Generator().manual_seed(77)
+    tokens = torch.zeros(1, seq, dtype=torch.long)
+    tokens[0, :case["prompt"]] = torch.randint(0, vocab, (case["prompt"],), generator=g)
+    lengths = torch.tensor([case["prompt"]])
+    ext = None
+    if cp > 1:                                                       # every rank must own a visual token (SURVEY.md §9 quirk 1)
+        c = seq // (2 * cp)
+        starts = torch.arange(2 * cp) * c + 1
+        ext = {"images": torch.zeros(2 * cp, 3, 2, 2),
+               "indices": torch.stack([torch.zeros(2 * cp, 2, dtype=torch.long), torch.stack([starts, starts + 1], dim=1)])}
+    prompt = tokens.clone()
+    with cpu_as_cuda():
+        for _ in gen.generate_tokens_probs_and_return_on_first_stage(None, tokens, lengths, external_inputs=ext):
+            pass
+    torch.save(dict(masks=masks, tokens=tokens, prompt=prompt, lengths=lengths), os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def golden_decode_loop():
+    """The reference's own decode loop on CP = 1 / 2 / 4 gloo ranks with a position-revealing fake model: per step the
+    logit-mask positions of every rank, and the tokens it generates (which encode the block sync_output + the picker chose)."""
+    import socket
+    import tempfile
+
+    import torch.multiprocessing as mp
+    out = {"cases": []}
+    for case in DECODE_CASES:
+        with socket.socket() as so:
+            so.bind(("127.0.0.1", 0))
+            port = so.getsockname()[1]
+        with tempfile.TemporaryDirectory() as d:
+            ctx = mp.get_context("spawn")
+            procs = [ctx.Process(target=_decode_worker, args=(r, case, port, d)) for r in range(case["cp"])]
+            [p_.start() for p_ in procs]
+            [p_.join(600) for p_ in procs]
+            assert all(p_.exitcode == 0 for p_ in procs), [p_.exitcode for p_ in procs]
+            ranks = [torch.load(os.path.join(d, f"rank{r}.pt")) for r in range(case["cp"])]
+        for r_ in ranks[1:]:
+            assert torch.equal(r_["tokens"], ranks[0]["tokens"])     # every rank generated the same text
+        out["cases"].append(dict(case, prompt=ranks[0]["prompt"], lengths=ranks[0]["lengths"], tokens=ranks[0]["tokens"],
+                                 masks=[r_["masks"] for r_ in ranks]))
+    torch.save(out, os.path.join(OUT, "decode_loop.pt"))
+
+
 def _tree_map(p, f):
     if isinstance(p, dict):
         return {k: _tree_map(v, f) for k, v in p.items()}
@@ -531,20 +622,15 @@ def _tree_map(p, f):
 def main():
     os.makedirs(OUT, exist_ok=True)
     _install_stubs()
-    golden_cp_slice()
-    print("cp_slice ok")
-    golden_rope_rmsnorm()
-    print("rope_rmsnorm ok")
-    golden_embedding_scatter()
-    print("embedding_scatter ok")
-    golden_masked_linear()
-    print("masked_linear ok")
-    golden_hf_vit()
-    print("hf_vit ok")
-    golden_image_processor()
-    print("image_processor ok")
-    golden_external_inputs()
-    print("external_inputs ok")
+    only = set(sys.argv[1:])                              # python -m oracle.make_golden [fixture ...]
+    for name, fn in [("cp_slice", golden_cp_slice), ("rope_rmsnorm", golden_rope_rmsnorm),
+                     ("embedding_scatter", golden_embedding_scatter), ("masked_linear", golden_masked_linear),
+                     ("hf_vit", golden_hf_vit), ("image_processor", golden_image_processor),
+                     ("external_inputs", golden_external_inputs), ("decode_loop", golden_decode_loop)]:
+        if only and name not in only:
+            continue
+        fn()
+        print(name, "ok")
 
 
 if __name__ == "__main__":

@@ -315,6 +315,69 @@ def test_tensor_x_context_parallel_groups_gloo_world4(tmp_path):
         assert p.returncode == 0 and "OK" in out, out
 
 
+_DECODE_WORKER = r"""
+import os, sys, types, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["VITA_ROOT"])
+from long_vita_amd import generation, parallel_state as mpu
+case = torch.load(os.environ["VITA_CASE"])
+cp, seq, V = case["cp"], case["seq"], case["vocab"]
+rank = int(os.environ["RANK"])
+if cp > 1:
+    dist.init_process_group("gloo", rank=rank, world_size=cp)
+mpu.initialize_model_parallel()
+nxt = lambda tok, pos: (tok * 7 + pos * 3 + 1) % V               # oracle/make_golden.py:fake_next_token
+masks = []
+
+def model(tokens, position_ids, attention_mask, inference_params=None):
+    sel = inference_params.logit_mask[0].nonzero().flatten()
+    masks.append(sel.tolist())
+    return torch.nn.functional.one_hot(nxt(tokens[0, sel], position_ids[0, sel]), V).float()[None]
+
+for compat in (True, False):
+    masks.clear()
+    tokens = case["prompt"].clone()
+    for _ in generation.generate_tokens_probs_and_return_on_first_stage(model, tokens, case["lengths"].clone(), use_kv_cache=False,
+                                                                       logit_mask=True, reference_compat=compat):
+        pass
+    if compat:      # bit for bit what the reference's own loop did on this rank: every mask, every generated token
+        assert masks == case["masks"][rank], (masks[:4], case["masks"][rank][:4])
+        assert torch.equal(tokens, case["tokens"])
+    else:           # the corrected rule follows the true continuation through every chunk boundary
+        n = int(case["lengths"][0])
+        for ctx in range(n, seq):
+            assert int(tokens[0, ctx]) == int(nxt(tokens[0, ctx - 1], torch.tensor(ctx - 1))), ctx
+if cp > 1:
+    dist.barrier()
+    dist.destroy_process_group()
+print("OK", rank)
+"""
+
+
+@pytest.mark.parametrize("idx", [0, 1, 2])
+def test_decode_loop_matches_the_references_own_loop(tmp_path, idx):
+    """generate_tokens_probs_and_return_on_first_stage (no-cache CP path, M/inference/text_generation/generation.py:33-280)
+    against a fixture made by running the REFERENCE's loop — with its get_batch_on_this_cp_rank and sync_output — on CP gloo
+    ranks under a stub Megatron (oracle/make_golden.py:golden_decode_loop): the same logit-mask positions on every rank at
+    every step and the same generated tokens, including the reference's off-by-one block at ctx % (S/2CP) == 0
+    (its fixture leaves the true continuation exactly there); reference_compat=False stays on it."""
+    from conftest import load_golden
+    case = load_golden("decode_loop.pt")["cases"][idx]
+    path = tmp_path / "case.pt"
+    torch.save(case, path)
+    script = tmp_path / "worker.py"
+    script.write_text(_DECODE_WORKER)
+    port = _free_port()
+    procs = []
+    for r in range(case["cp"]):
+        env = dict(os.environ, RANK=str(r), WORLD_SIZE=str(case["cp"]), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   VITA_ROOT=ROOT, VITA_CASE=str(path))
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE,
+                                      stderr=subprocess.STDOUT, text=True))
+    for p in procs:
+        out, _ = p.communicate(timeout=300)
+        assert p.returncode == 0 and "OK" in out, out
+
+
 def test_tensor_parallel_shards_roundtrip():
     from long_vita_amd import tensor_parallel as tpar
     from oracle import llm as ollm
