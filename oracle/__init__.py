@@ -17,7 +17,8 @@ Pinning status ("how do we know the restatement is right"):
     / apply / CP slice, RMSNorm, embedding scatter (3 forms), logits-masked linear fwd + bwd,
     pixel-shuffle, HF InternViT layer / full ViT / projector, Pillow resize / tiling / frame selection,
     get_external_inputs token surgery, and the decode-time logit-mask rule + sync_output order + block pick
-    (the reference's decode loop run as CP gloo processes, decode_loop.pt).
+    (the reference's decode loop run as CP gloo processes, decode_loop.pt), loss_func (its source executed on
+    gloo ranks, loss_func.pt).
   * Restated but only cross-checked (no runnable reference): unfused attention math
     (M/core/transformer/dot_product_attention.py needs Megatron objects) — checked against
     torch SDPA and the HF ViT `_naive_attn`; decoder-layer assembly — checked against

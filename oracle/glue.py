@@ -178,6 +178,22 @@ def masked_linear_bwd(grad_output: torch.Tensor, inp: torch.Tensor, weight: torc
 # --------------------------------------------------------------------------------------------
 # a13 — decode-time logit-mask rule and CP logits re-assembly
 # --------------------------------------------------------------------------------------------
+def loss_func(losses_per_rank, masks_per_rank, is_instruction: bool):
+    """M/pretrain_long_vita.py:778-838 for all CP ranks at once (DP = 1).  Per rank: [sum(loss * mask), sum(mask)] with the
+    mask shifted by one under --is-instruction-dataset (:793-796); the pair is all-reduced over the CP group (:801-803); the
+    rank returns (loss_sum * CP, token count, reporting pair) (:833-838).  With --logit-mask the caller passes a ones mask one
+    wider than the selected rows (forward_step :866-867), i.e. every selected row but the shifted-out one counts."""
+    cp = len(losses_per_rank)
+    parts = []
+    for losses, mask in zip(losses_per_rank, masks_per_rank):
+        m = (mask[..., 1:] if is_instruction else mask).reshape(-1).float()
+        parts.append(torch.cat([torch.sum(losses.float().view(-1) * m).view(1), m.sum().view(1)]))
+    tot = parts[0].clone()
+    for p_ in parts[1:]:
+        tot = tot + p_
+    return tot[0] * cp, tot[1].to(torch.int), (tot[0], tot[1])
+
+
 def cp_logit_mask_positions(context_length: int, local_len: int, cp_size: int, reference_compat: bool = True):
     """M/inference/text_generation/generation.py:141-165,195.  Returns (sorted local positions marked
     True in logit_mask, block index picked from the all-gathered [b, 2*CP, V] logits).

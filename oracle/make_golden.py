@@ -588,27 +588,84 @@ def _decode_worker(rank: int, case: dict, port: int, out_dir: str):
 def golden_decode_loop():
     """The reference's own decode loop on CP = 1 / 2 / 4 gloo ranks with a position-revealing fake model: per step the
     logit-mask positions of every rank, and the tokens it generates (which encode the block sync_output + the picker chose)."""
-    import socket
-    import tempfile
-
-    import torch.multiprocessing as mp
     out = {"cases": []}
     for case in DECODE_CASES:
-        with socket.socket() as so:
-            so.bind(("127.0.0.1", 0))
-            port = so.getsockname()[1]
-        with tempfile.TemporaryDirectory() as d:
-            ctx = mp.get_context("spawn")
-            procs = [ctx.Process(target=_decode_worker, args=(r, case, port, d)) for r in range(case["cp"])]
-            [p_.start() for p_ in procs]
-            [p_.join(600) for p_ in procs]
-            assert all(p_.exitcode == 0 for p_ in procs), [p_.exitcode for p_ in procs]
-            ranks = [torch.load(os.path.join(d, f"rank{r}.pt")) for r in range(case["cp"])]
+        ranks = _run_ranks(_decode_worker, case)
         for r_ in ranks[1:]:
             assert torch.equal(r_["tokens"], ranks[0]["tokens"])     # every rank generated the same text
         out["cases"].append(dict(case, prompt=ranks[0]["prompt"], lengths=ranks[0]["lengths"], tokens=ranks[0]["tokens"],
                                  masks=[r_["masks"] for r_ in ranks]))
     torch.save(out, os.path.join(OUT, "decode_loop.pt"))
+
+
+LOSS_CASES = [dict(name="cp1_instruction", cp=1, instruction=True, n=[9], ones_mask=False),
+              dict(name="cp2_logit_mask", cp=2, instruction=True, n=[6, 11], ones_mask=True),      # forward_step :866-867
+              dict(name="cp4_plain", cp=4, instruction=False, n=[5, 8, 3, 7], ones_mask=False)]
+
+
+def loss_case_inputs(case: dict, rank: int):
+    """Per-token losses [1, n_r] and the loss mask of one rank ([1, n_r + 1] when the instruction shift applies)."""
+    g = torch.Generator().manual_seed(1000 + 17 * rank + len(case["name"]))
+    n = case["n"][rank]
+    losses = torch.rand(1, n, generator=g) * 9.0
+    width = n + 1 if case["instruction"] else n
+    mask = torch.ones(1, width) if case["ones_mask"] else (torch.rand(1, width, generator=g) > 0.4).float()
+    return losses, mask
+
+
+def _loss_worker(rank: int, case: dict, port: int, out_dir: str):
+    """The reference's loss_func (M/pretrain_long_vita.py:778-838) — its source text is taken from the file and executed as
+    is (the module itself cannot be imported: it pulls the whole Megatron / data stack) on gloo ranks."""
+    import ast
+
+    import torch.distributed as dist
+    cp = case["cp"]
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=cp)
+    dp_group = None
+    for r in range(cp):                                            # DP = 1: every rank is its own data-parallel group
+        grp = dist.new_group([r])
+        if r == rank:
+            dp_group = grp
+    path = os.path.join(REF, "long_vita_megatron", "pretrain_long_vita.py")
+    src = open(path).read()
+    fn = next(n_ for n_ in ast.parse(src).body if isinstance(n_, ast.FunctionDef) and n_.name == "loss_func")
+    args = types.SimpleNamespace(is_instruction_dataset=case["instruction"], context_parallel_size=cp, save=out_dir,
+                                 check_for_nan_in_loss_and_grad=True)
+    mpu = types.SimpleNamespace(get_context_parallel_group=lambda: None, get_data_parallel_group=lambda: dp_group)
+    ns = {"torch": torch, "os": os, "get_args": lambda: args, "mpu": mpu, "LOSS_PRINT_ONCE": True}
+    exec(compile(ast.get_source_segment(src, fn), path, "exec"), ns)
+    losses, mask = loss_case_inputs(case, rank)
+    with cpu_as_cuda():
+        loss, ntok, report = ns["loss_func"](mask.clone(), losses.clone())
+    torch.save(dict(loss=loss, num_tokens=ntok, report=[x.clone() for x in report["lm loss"]]), os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def _run_ranks(worker, case):
+    import socket
+    import tempfile
+
+    import torch.multiprocessing as mp
+    with socket.socket() as so:
+        so.bind(("127.0.0.1", 0))
+        port = so.getsockname()[1]
+    with tempfile.TemporaryDirectory() as d:
+        ctx = mp.get_context("spawn")
+        procs = [ctx.Process(target=worker, args=(r, case, port, d)) for r in range(case["cp"])]
+        [p_.start() for p_ in procs]
+        [p_.join(600) for p_ in procs]
+        assert all(p_.exitcode == 0 for p_ in procs), [p_.exitcode for p_ in procs]
+        return [torch.load(os.path.join(d, f"rank{r}.pt")) for r in range(case["cp"])]
+
+
+def golden_loss_func():
+    out = {"cases": []}
+    for case in LOSS_CASES:
+        ranks = _run_ranks(_loss_worker, case)
+        ins = [loss_case_inputs(case, r) for r in range(case["cp"])]
+        out["cases"].append(dict(case, losses=[i[0] for i in ins], masks=[i[1] for i in ins], out=ranks))
+    torch.save(out, os.path.join(OUT, "loss_func.pt"))
 
 
 def _tree_map(p, f):
@@ -626,7 +683,7 @@ def main():
     for name, fn in [("cp_slice", golden_cp_slice), ("rope_rmsnorm", golden_rope_rmsnorm),
                      ("embedding_scatter", golden_embedding_scatter), ("masked_linear", golden_masked_linear),
                      ("hf_vit", golden_hf_vit), ("image_processor", golden_image_processor),
-                     ("external_inputs", golden_external_inputs), ("decode_loop", golden_decode_loop)]:
+                     ("external_inputs", golden_external_inputs), ("decode_loop", golden_decode_loop), ("loss_func", golden_loss_func)]:
         if only and name not in only:
             continue
         fn()
