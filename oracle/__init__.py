@@ -19,9 +19,9 @@ Pinning status ("how do we know the restatement is right"):
     get_external_inputs token surgery, and the decode-time logit-mask rule + sync_output order + block pick
     (the reference's decode loop run as CP gloo processes, decode_loop.pt), loss_func (its source executed on
     gloo ranks, loss_func.pt).
-  * Restated but only cross-checked (no runnable reference): unfused attention math
-    (M/core/transformer/dot_product_attention.py needs Megatron objects) — checked against
-    torch SDPA and the HF ViT `_naive_attn`; decoder-layer assembly — checked against
+    The unfused attention math (M/core/transformer/dot_product_attention.py:151-291, run with a stand-in
+    `self`, unfused_attention.pt) is pinned the same way.
+  * Restated but only cross-checked (no runnable reference): decoder-layer assembly — checked against
     transformers' Qwen2 (5.x installed, reference pins >=4.48.3).
     For these rows parity is "unpinned against the reference itself".
 """

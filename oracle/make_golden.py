@@ -598,6 +598,48 @@ def golden_decode_loop():
     torch.save(out, os.path.join(OUT, "decode_loop.pt"))
 
 
+ATTN_CASES = [dict(name="llm_gqa_causal", sq=48, b=1, np=8, ng=2, hn=16, causal=True),
+              dict(name="vit_mha_full", sq=17, b=2, np=4, ng=4, hn=8, causal=False)]
+
+
+def attn_case_inputs(case: dict):
+    g = torch.Generator().manual_seed(4242 + case["sq"])
+    q = torch.randn(case["sq"], case["b"], case["np"], case["hn"], generator=g)
+    k = torch.randn(case["sq"], case["b"], case["ng"], case["hn"], generator=g)
+    v = torch.randn(case["sq"], case["b"], case["ng"], case["hn"], generator=g)
+    return q, k, v
+
+
+def golden_unfused_attention():
+    """The reference's unfused core attention (M/core/transformer/dot_product_attention.py:151-291: GQA repeat_interleave,
+    baddbmm with 1/norm_factor, softmax, bmm, [sq, b, hp] layout) run with a stand-in `self`.  The one external piece is
+    Megatron's `scale_mask_softmax`; its torch path (Megatron-LM core_r0.7.0 megatron/core/fusions/fused_softmax.py,
+    forward_torch_softmax with attention_mask_func: masked_fill(mask, -10000.0), softmax over the last dim) is restated here."""
+    dpa = importlib.import_module("long_vita_megatron.core.transformer.dot_product_attention")
+    STATE["args"].use_flash_attn = False
+    dpa.parallel_state = types.SimpleNamespace(get_global_memory_buffer=lambda: types.SimpleNamespace(
+        get_tensor=lambda shape, dtype, name: torch.empty(shape, dtype=dtype)))
+
+    def scale_mask_softmax(scores, mask):
+        if mask is not None:
+            scores = scores.masked_fill(mask, -10000.0)
+        return torch.nn.Softmax(dim=-1)(scores)
+
+    fwd = dpa.dot_product_attention_forward_wrapper(lambda *a_, **k_: None)
+    out = {"cases": []}
+    for case in ATTN_CASES:
+        q, k, v = attn_case_inputs(case)
+        me = types.SimpleNamespace(num_attention_heads_per_partition=case["np"], num_query_groups_per_partition=case["ng"],
+                                   alibi=None, norm_factor=case["hn"] ** 0.5, attn_logit_softcapping=None, square_alibi_mask=False,
+                                   scale_mask_softmax=scale_mask_softmax, attention_dropout=lambda x: x,
+                                   config=types.SimpleNamespace(sequence_parallel=False),
+                                   hidden_size_per_partition=case["np"] * case["hn"])
+        mask = torch.triu(torch.ones(case["sq"], case["sq"], dtype=torch.bool), 1)[None, None] if case["causal"] else None
+        ctx = fwd(me, q.clone(), k.clone(), v.clone(), mask, None, None)
+        out["cases"].append(dict(case, out=ctx.clone()))
+    torch.save(out, os.path.join(OUT, "unfused_attention.pt"))
+
+
 LOSS_CASES = [dict(name="cp1_instruction", cp=1, instruction=True, n=[9], ones_mask=False),
               dict(name="cp2_logit_mask", cp=2, instruction=True, n=[6, 11], ones_mask=True),      # forward_step :866-867
               dict(name="cp4_plain", cp=4, instruction=False, n=[5, 8, 3, 7], ones_mask=False)]
@@ -683,7 +725,7 @@ def main():
     for name, fn in [("cp_slice", golden_cp_slice), ("rope_rmsnorm", golden_rope_rmsnorm),
                      ("embedding_scatter", golden_embedding_scatter), ("masked_linear", golden_masked_linear),
                      ("hf_vit", golden_hf_vit), ("image_processor", golden_image_processor),
-                     ("external_inputs", golden_external_inputs), ("decode_loop", golden_decode_loop), ("loss_func", golden_loss_func)]:
+                     ("external_inputs", golden_external_inputs), ("decode_loop", golden_decode_loop), ("loss_func", golden_loss_func), ("unfused_attention", golden_unfused_attention)]:
         if only and name not in only:
             continue
         fn()
