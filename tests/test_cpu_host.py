@@ -280,6 +280,36 @@ def test_packed_segments_from_position_ids():
     assert s2.tolist() == [0] * 10 + [10] * 15 + [25] * 7 and e2.tolist() == [10] * 10 + [25] * 15 + [32] * 7
 
 
+def test_packed_segments_match_transformers_varlen_preparation():
+    """The third-party step behind the reference's packed path: M/core/transformer/dot_product_attention.py:374-390 calls
+    transformers' _flash_attention_forward(position_ids=...), which derives the flash_attn_varlen cu_seqlens with
+    prepare_fa_kwargs_from_position_ids (transformers >= 4.48.3 pinned by the reference, 5.x installed).  The segment
+    bounds the HIP kernels get are the same partition, for random packings incl. length-1 samples."""
+    from transformers.modeling_flash_attention_utils import prepare_fa_kwargs_from_position_ids
+
+    from long_vita_amd import training_utils as tu
+    g = torch.Generator().manual_seed(11)
+    for _ in range(20):
+        S = int(torch.randint(8, 200, (1,), generator=g))
+        n_cut = int(torch.randint(1, 6, (1,), generator=g))
+        cuts = sorted(set([0] + torch.randint(1, S, (n_cut,), generator=g).tolist()))
+        pos = torch.cat([torch.arange(b - a) for a, b in zip(cuts, cuts[1:] + [S])])
+        (cu, _), (max_len, _) = prepare_fa_kwargs_from_position_ids(pos[None])
+        assert cu.tolist() == cuts + [S]
+        try:
+            tu.set_position_ids(pos[:, None])
+            seg = tu.get_packed_segments()
+        finally:
+            tu.set_position_ids(None)
+        if len(cuts) == 1:
+            assert seg is None                                        # monotonic: transformers stays on the dense path too
+            continue
+        start, end = seg
+        for a, b in zip(cu.tolist()[:-1], cu.tolist()[1:]):
+            assert start[a:b].tolist() == [a] * (b - a) and end[a:b].tolist() == [b] * (b - a)
+        assert int(max_len) == int((end - start).max())
+
+
 _TPCP_WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["VITA_ROOT"])
