@@ -186,9 +186,11 @@ def load_hf_safetensors(path: str) -> Dict[str, torch.Tensor]:
     return sd
 
 
-def load_mcore_checkpoint(path: str, iteration: Optional[int] = None) -> Dict[str, torch.Tensor]:
+def load_mcore_checkpoint(path: str, iteration: Optional[int] = None, swiglu_fc1: Optional[bool] = None) -> Dict[str, torch.Tensor]:
     """<path>/latest_checkpointed_iteration.txt + iter_XXXXXXX/mp_rank_YY/model_optim_rng.pt (M/training/checkpointing.py
-    layout, pipeline size 1) -> merged 'model' state dict."""
+    layout, pipeline size 1) -> merged 'model' state dict.  swiglu_fc1: are the un-prefixed linear_fc1 shards [gate; up]
+    pairs?  Default: yes, unless this is the stand-alone ViT checkpoint L/ckpt_converter_intern_vit.py writes (the one
+    `--vit-load` points at; top-level conv1 / class_token, GELU MLP, no `vision_model.` prefix)."""
     if iteration is None:
         tag = open(os.path.join(path, "latest_checkpointed_iteration.txt")).read().strip()
         it_dir = "release" if tag == "release" else f"iter_{int(tag):07d}"
@@ -199,4 +201,6 @@ def load_mcore_checkpoint(path: str, iteration: Optional[int] = None) -> Dict[st
         raise FileNotFoundError(f"no mp_rank_XX directories under {os.path.join(path, it_dir)}")
     shards = [torch.load(os.path.join(path, it_dir, r, "model_optim_rng.pt"), map_location="cpu", weights_only=False)["model"]
               for r in ranks]
-    return merge_tp_shards(shards)
+    if swiglu_fc1 is None:
+        swiglu_fc1 = "conv1.weight" not in shards[0]
+    return merge_tp_shards(shards, swiglu_fc1=swiglu_fc1)

@@ -640,6 +640,159 @@ def golden_unfused_attention():
     torch.save(out, os.path.join(OUT, "unfused_attention.pt"))
 
 
+VIT_CONVERT_SHAPES = {        # one InternViT-300M layer at full width (the converter hard-codes 16 heads x 64, hidden 1024)
+    "embeddings.class_embedding": (1, 1, 1024), "embeddings.position_embedding": (1, 1025, 1024),
+    "embeddings.patch_embedding.weight": (1024, 3, 14, 14), "embeddings.patch_embedding.bias": (1024,),
+    "encoder.layers.0.attn.qkv.weight": (3072, 1024), "encoder.layers.0.attn.qkv.bias": (3072,),
+    "encoder.layers.0.attn.proj.weight": (1024, 1024), "encoder.layers.0.attn.proj.bias": (1024,),
+    "encoder.layers.0.norm1.weight": (1024,), "encoder.layers.0.norm1.bias": (1024,),
+    "encoder.layers.0.mlp.fc1.weight": (4096, 1024), "encoder.layers.0.mlp.fc1.bias": (4096,),
+    "encoder.layers.0.mlp.fc2.weight": (1024, 4096), "encoder.layers.0.mlp.fc2.bias": (1024,),
+    "encoder.layers.0.norm2.weight": (1024,), "encoder.layers.0.norm2.bias": (1024,),
+    "encoder.layers.0.ls1": (1024,), "encoder.layers.0.ls2": (1024,)}
+LLM_CONVERT_DIMS = dict(hidden=64, heads=8, groups=2, head_dim=8, ffn=96, vocab=40, layers=2)
+
+
+def llm_convert_hf_state(seed: int = 31):
+    """A small Qwen2-shaped transformers state dict (names of Qwen2ForCausalLM)."""
+    d = LLM_CONVERT_DIMS
+    g = torch.Generator().manual_seed(seed)
+    r = lambda *shape: torch.randn(*shape, generator=g)
+    sd = {"model.embed_tokens.weight": r(d["vocab"], d["hidden"]), "model.norm.weight": r(d["hidden"]),
+          "lm_head.weight": r(d["vocab"], d["hidden"])}
+    for i in range(d["layers"]):
+        pre = f"model.layers.{i}."
+        sd.update({pre + "self_attn.q_proj.weight": r(d["heads"] * d["head_dim"], d["hidden"]),
+                   pre + "self_attn.q_proj.bias": r(d["heads"] * d["head_dim"]),
+                   pre + "self_attn.k_proj.weight": r(d["groups"] * d["head_dim"], d["hidden"]),
+                   pre + "self_attn.k_proj.bias": r(d["groups"] * d["head_dim"]),
+                   pre + "self_attn.v_proj.weight": r(d["groups"] * d["head_dim"], d["hidden"]),
+                   pre + "self_attn.v_proj.bias": r(d["groups"] * d["head_dim"]),
+                   pre + "self_attn.o_proj.weight": r(d["hidden"], d["heads"] * d["head_dim"]),
+                   pre + "mlp.gate_proj.weight": r(d["ffn"], d["hidden"]), pre + "mlp.up_proj.weight": r(d["ffn"], d["hidden"]),
+                   pre + "mlp.down_proj.weight": r(d["hidden"], d["ffn"]),
+                   pre + "input_layernorm.weight": r(d["hidden"]), pre + "post_attention_layernorm.weight": r(d["hidden"])})
+    return sd
+
+
+def golden_converters():
+    """(A) L/ckpt_converter_intern_vit.py:convert run on a marker state dict (every element encodes its tensor, row and
+    column), tensor-parallel size 2, --use-te: the fixture keeps, per written tensor and rank, which source rows / columns it
+    holds.  (B) R/tools/hf2mcore_long_vita.py:convert_checkpoint_from_transformers_to_megatron (+ safe_copy), source executed
+    on stand-in module trees: the Megatron-side language-model state dict it fills."""
+    import ast
+    import tempfile
+
+    # ---- (A) InternViT ------------------------------------------------------------------------------------------------
+    conv = importlib.import_module("long_vita_modellink.ckpt_converter_intern_vit")
+    names = list(VIT_CONVERT_SHAPES)
+    sd = {}
+    def two_d(shape):                       # leading singleton dims dropped; [rows, everything else]
+        shape = list(shape)
+        while len(shape) > 1 and shape[0] == 1:
+            shape.pop(0)
+        cols = 1
+        for x in shape[1:]:
+            cols *= x
+        return shape[0], cols
+
+    for tid, name in enumerate(names):
+        shape = VIT_CONVERT_SHAPES[name]
+        rows, cols = two_d(shape)
+        assert rows < 65536 and cols < 65536
+        mark = (tid << 32) + (torch.arange(rows, dtype=torch.float64)[:, None] * 65536.0) + torch.arange(cols, dtype=torch.float64)[None]
+        sd[name] = mark.reshape(shape)
+    fake = types.SimpleNamespace(state_dict=lambda: sd)
+    fake.cpu = lambda: fake
+    fake.eval = lambda: fake
+    import transformers
+    vit = {"names": names, "ranks": []}
+    with tempfile.TemporaryDirectory() as d, mock.patch.object(transformers.AutoModel, "from_pretrained", lambda *a_, **k_: fake), \
+            contextlib.redirect_stdout(open(os.devnull, "w")):
+        conv.convert("unused", d, 2, True)
+        assert open(os.path.join(d, "latest_checkpointed_iteration.txt")).read() == "1"
+        for i in range(2):
+            shard = torch.load(os.path.join(d, "iter_0000001", f"mp_rank_0{i}", "model_optim_rng.pt"), weights_only=False)["model"]
+            entry = {}
+            for name, t in shard.items():
+                if t is None:
+                    entry[name] = None                                  # TE _extra_state placeholders
+                    continue
+                flat = t.reshape(*two_d(t.shape))
+                v = flat.to(torch.int64)
+                tid = int(v[0, 0] >> 32)
+                rowmap = ((v[:, 0] >> 16) & 0xFFFF).tolist()      # the tensor is src[rowmap][:, colmap] of ONE source tensor
+                colmap = (v[0, :] & 0xFFFF).tolist()
+                assert torch.equal(v, (tid << 32) + (torch.tensor(rowmap)[:, None] << 16) + torch.tensor(colmap)[None])
+                entry[name] = dict(src=names[tid], shape=tuple(t.shape), rowmap=rowmap, colmap=colmap)
+            vit["ranks"].append(entry)
+
+    # ---- (B) Qwen2 LLM ------------------------------------------------------------------------------------------------
+    path = os.path.join(REF, "tools", "hf2mcore_long_vita.py")
+    src = open(path).read()
+    tree = ast.parse(src)
+    ns = {"torch": torch}
+    for fn in tree.body:
+        if isinstance(fn, ast.FunctionDef) and fn.name in ("safe_copy", "convert_checkpoint_from_transformers_to_megatron"):
+            exec(compile(ast.get_source_segment(src, fn), path, "exec"), ns)
+    dm = LLM_CONVERT_DIMS
+    hf_sd = llm_convert_hf_state()
+    P = lambda *shape: torch.nn.Parameter(torch.zeros(*shape))
+
+    class Holder(torch.nn.Module):
+        def __init__(self, **kw):
+            super().__init__()
+            for k_, v_ in kw.items():
+                setattr(self, k_, v_)
+
+    def lin(w, b=None):
+        h = Holder(weight=torch.nn.Parameter(w.clone()))
+        if b is not None:
+            h.bias = torch.nn.Parameter(b.clone())
+        return h
+
+    hf_layers = torch.nn.ModuleList()
+    for i in range(dm["layers"]):
+        pre = f"model.layers.{i}."
+        hf_layers.append(Holder(
+            self_attn=Holder(q_proj=lin(hf_sd[pre + "self_attn.q_proj.weight"], hf_sd[pre + "self_attn.q_proj.bias"]),
+                             k_proj=lin(hf_sd[pre + "self_attn.k_proj.weight"], hf_sd[pre + "self_attn.k_proj.bias"]),
+                             v_proj=lin(hf_sd[pre + "self_attn.v_proj.weight"], hf_sd[pre + "self_attn.v_proj.bias"]),
+                             o_proj=lin(hf_sd[pre + "self_attn.o_proj.weight"])),
+            mlp=Holder(gate_proj=lin(hf_sd[pre + "mlp.gate_proj.weight"]), up_proj=lin(hf_sd[pre + "mlp.up_proj.weight"]),
+                       down_proj=lin(hf_sd[pre + "mlp.down_proj.weight"])),
+            input_layernorm=lin(hf_sd[pre + "input_layernorm.weight"]),
+            post_attention_layernorm=lin(hf_sd[pre + "post_attention_layernorm.weight"])))
+    # the vision half of the function (:533-587) is for another ViT family: give it an empty one
+    vis = lambda: Holder(rotary_pos_emb=Holder(inv_freq=torch.zeros(2)), patch_embed=Holder(proj=lin(torch.zeros(2, 2))),
+                         blocks=torch.nn.ModuleList(), merger=Holder(ln_q=lin(torch.zeros(2), torch.zeros(2)),
+                                                                     mlp=torch.nn.ModuleList([lin(torch.zeros(2, 2), torch.zeros(2)), Holder(),
+                                                                                              lin(torch.zeros(2, 2), torch.zeros(2))])))
+    hfmodel = Holder(visual=vis(), model=Holder(embed_tokens=lin(hf_sd["model.embed_tokens.weight"]), layers=hf_layers,
+                                                norm=lin(hf_sd["model.norm.weight"])), lm_head=lin(hf_sd["lm_head.weight"]))
+    qkv_out = (dm["heads"] + 2 * dm["groups"]) * dm["head_dim"]
+    mg_layers = torch.nn.ModuleList([Holder(
+        self_attention=Holder(linear_qkv=Holder(layer_norm_weight=P(dm["hidden"]), weight=P(qkv_out, dm["hidden"]), bias=P(qkv_out)),
+                              linear_proj=Holder(weight=P(dm["hidden"], dm["heads"] * dm["head_dim"]))),
+        mlp=Holder(linear_fc1=Holder(layer_norm_weight=P(dm["hidden"]), weight=P(2 * dm["ffn"], dm["hidden"])),
+                   linear_fc2=Holder(weight=P(dm["hidden"], dm["ffn"])))) for _ in range(dm["layers"])])
+    mgvis = Holder(rotary_pos_emb=Holder(inv_freq=torch.zeros(2)), patch_embed=Holder(proj=lin(torch.zeros(2, 2))),
+                   decoder=Holder(layers=torch.nn.ModuleList(), final_layernorm=lin(torch.zeros(2), torch.zeros(2))),
+                   projection=Holder(encoder=Holder(linear_fc1=lin(torch.zeros(2, 2), torch.zeros(2)),
+                                                    linear_fc2=lin(torch.zeros(2, 2), torch.zeros(2)))))
+    mgvis.config = types.SimpleNamespace(hidden_size=2, num_query_groups=1, num_attention_heads=1)
+    mgmodel = Holder(vision_model=mgvis, language_model=Holder(
+        embedding=Holder(word_embeddings=Holder(weight=P(dm["vocab"], dm["hidden"]))),
+        decoder=Holder(layers=mg_layers, final_layernorm=Holder(weight=P(dm["hidden"]))),
+        output_layer=Holder(weight=P(dm["vocab"], dm["hidden"]))))
+    args = types.SimpleNamespace(fp16=False, bf16=False, num_attention_heads=dm["heads"], num_query_groups=dm["groups"],
+                                 hidden_size=dm["hidden"], untie_embeddings_and_output_weights=True)
+    ns["convert_checkpoint_from_transformers_to_megatron"](hfmodel, mgmodel, args)
+    mg_sd = {k_: v_.detach().clone() for k_, v_ in mgmodel.language_model.state_dict().items()}
+    assert all(float(v_.abs().sum()) > 0 for v_ in mg_sd.values())                 # every Megatron tensor was filled
+    torch.save(dict(vit=vit, llm=dict(dims=dm, megatron_state=mg_sd)), os.path.join(OUT, "converters.pt"))
+
+
 LOSS_CASES = [dict(name="cp1_instruction", cp=1, instruction=True, n=[9], ones_mask=False),
               dict(name="cp2_logit_mask", cp=2, instruction=True, n=[6, 11], ones_mask=True),      # forward_step :866-867
               dict(name="cp4_plain", cp=4, instruction=False, n=[5, 8, 3, 7], ones_mask=False)]
@@ -725,7 +878,8 @@ def main():
     for name, fn in [("cp_slice", golden_cp_slice), ("rope_rmsnorm", golden_rope_rmsnorm),
                      ("embedding_scatter", golden_embedding_scatter), ("masked_linear", golden_masked_linear),
                      ("hf_vit", golden_hf_vit), ("image_processor", golden_image_processor),
-                     ("external_inputs", golden_external_inputs), ("decode_loop", golden_decode_loop), ("loss_func", golden_loss_func), ("unfused_attention", golden_unfused_attention)]:
+                     ("external_inputs", golden_external_inputs), ("decode_loop", golden_decode_loop), ("loss_func", golden_loss_func), ("unfused_attention", golden_unfused_attention),
+                     ("converters", golden_converters)]:
         if only and name not in only:
             continue
         fn()

@@ -148,3 +148,57 @@ def test_intern_vit_layouts():
     got = ck.mcore_vit_to_params(merged, vcfg)
     want = {k: v for k, v in p.items() if not k.startswith("proj_")}
     assert _tree_equal(got, want)
+
+
+def test_vit_loader_reads_what_the_references_converter_writes(tmp_path):
+    """L/ckpt_converter_intern_vit.py:convert was run on a marker state dict (tensor-parallel size 2, --use-te); the fixture
+    (converters.pt) keeps, per written tensor and rank, which source rows / columns it holds.  Rebuild those two shard files
+    from a random transformers state dict, read them with load_mcore_checkpoint + mcore_vit_to_params, and get exactly what
+    hf_vit_to_params makes of the transformers names — names, the per-head [q|k|v] gather, chunk dims and the merge all agree
+    with the reference's own converter."""
+    from conftest import load_golden
+    from oracle.make_golden import VIT_CONVERT_SHAPES
+    g = load_golden("converters.pt")["vit"]
+    gen = torch.Generator().manual_seed(21)
+    hf = {k: torch.randn(*shape, generator=gen) for k, shape in VIT_CONVERT_SHAPES.items()}
+
+    def two_d(t):
+        while t.dim() > 1 and t.shape[0] == 1:
+            t = t[0]
+        return t.reshape(t.shape[0], -1)
+
+    root = tmp_path / "ckpt"
+    assert len(g["ranks"]) == 2
+    for r, entry in enumerate(g["ranks"]):
+        shard = {}
+        for name, e in entry.items():
+            if e is None:
+                shard[name] = None                                    # TE _extra_state placeholder, as written
+                continue
+            src = two_d(hf[e["src"]])
+            shard[name] = src[torch.tensor(e["rowmap"])][:, torch.tensor(e["colmap"])].reshape(e["shape"]).clone()
+        d = root / "iter_0000001" / f"mp_rank_{r:02d}"
+        os.makedirs(d)
+        torch.save({"model": shard}, d / "model_optim_rng.pt")
+    (root / "latest_checkpointed_iteration.txt").write_text("1")
+    vcfg = ovit.ViTConfig(num_layers=1)
+    got = ck.mcore_vit_to_params(ck.load_mcore_checkpoint(str(root)), vcfg)
+    want = ck.hf_vit_to_params(hf, vcfg)
+    assert _tree_equal(got, want)
+
+
+def test_llm_converter_matches_the_references_hf2mcore():
+    """R/tools/hf2mcore_long_vita.py:convert_checkpoint_from_transformers_to_megatron (source executed on stand-in module
+    trees, fixture converters.pt): the Megatron language-model state dict it fills from a transformers state dict is, tensor for
+    tensor, what hf_llm_to_params builds from the same state dict and what mcore_llm_to_params reads back."""
+    from conftest import load_golden
+    from oracle.make_golden import LLM_CONVERT_DIMS, llm_convert_hf_state
+    g = load_golden("converters.pt")["llm"]
+    assert g["dims"] == LLM_CONVERT_DIMS
+    dm = g["dims"]
+    cfg = ollm.LLMConfig(num_layers=dm["layers"], hidden=dm["hidden"], heads=dm["heads"], kv_groups=dm["groups"],
+                         head_dim=dm["head_dim"], ffn=dm["ffn"], vocab=dm["vocab"])
+    want = ck.mcore_llm_to_params(g["megatron_state"], cfg)
+    got = ck.hf_llm_to_params(llm_convert_hf_state(), cfg)
+    assert _tree_equal(got, want)
+    assert not torch.equal(got["lm_head"], got["embed"])             # --untie-embeddings-and-output-weights
