@@ -106,26 +106,26 @@ def prefill_step(model, tokens: torch.Tensor, context_length: int, external_inpu
 # the decode loop
 # ------------------------------------------------------------------------------------------------
 def _sample_strategy(logits: torch.Tensor, do_sample=False, top_k=0, top_p=0.0, temperature=1.0):
-    """:569-602 — greedy, or temperature / top-k / top-p sampling.  Sampling policy, not path arithmetic:
-    plain torch on the [b, vocab] row."""
+    """:473-512 (_sample_strategy + top_k_logits) — greedy, or temperature / top-k / top-p sampling.  Sampling policy, not
+    path arithmetic: plain torch on the [b, vocab] row.  Same filtering rules as the reference (top-k for top_k > 0: ties
+    with the k-th value survive; top-p for top_p > 0: the first token above the threshold is kept) and the same return value
+    (the filtered softmax when sampling, the untouched logits otherwise); the caller's tensor is never modified (the
+    reference divides an fp32 input in place)."""
     if not do_sample:
-        new = torch.argmax(logits, dim=-1)
-        return logits, new
+        return logits, torch.argmax(logits, dim=-1).view(-1)
     logits = logits.float().clone()
-    if temperature != 1.0:
-        logits.div_(temperature)
-    if top_k > 1:
+    logits /= temperature
+    if top_k > 0:
         kth = torch.topk(logits, top_k)[0][..., -1, None]
         logits[logits < kth] = float("-inf")
-    if 0.0 < top_p < 1.0:
-        srt, idx = torch.sort(logits, descending=True)
-        cum = torch.softmax(srt, dim=-1).cumsum(dim=-1)
-        drop = cum > top_p
+    if top_p > 0.0:
+        srt, idx = torch.sort(logits, descending=True, dim=-1)
+        drop = torch.cumsum(torch.softmax(srt, dim=-1), dim=-1) > top_p
         drop[..., 1:] = drop[..., :-1].clone()
         drop[..., 0] = False
-        logits[drop.scatter(1, idx, drop)] = float("-inf")
+        logits[drop.gather(-1, idx.argsort(dim=-1))] = float("-inf")      # un-sort the mask (the reference loops over rows)
     probs = torch.softmax(logits, dim=-1)
-    return logits, torch.multinomial(probs, 1).view(-1)
+    return probs, torch.multinomial(probs, num_samples=1).view(-1)
 
 
 def _cp_prefill_length(prompt_len: int, cp_size: int) -> int:

@@ -793,6 +793,42 @@ def golden_converters():
     torch.save(dict(vit=vit, llm=dict(dims=dm, megatron_state=mg_sd)), os.path.join(OUT, "converters.pt"))
 
 
+SAMPLING_CASES = [dict(top_k=0, top_p=0.0, temperature=1.0), dict(top_k=1, top_p=0.0, temperature=1.0),
+                  dict(top_k=5, top_p=0.0, temperature=0.7), dict(top_k=0, top_p=0.8, temperature=1.3),
+                  dict(top_k=12, top_p=0.5, temperature=1.0), dict(top_k=0, top_p=1.0, temperature=1.0),
+                  dict(top_k=3, top_p=0.0, temperature=1.0, ties=True)]
+
+
+def sampling_case_logits(i: int, case: dict):
+    g = torch.Generator().manual_seed(900 + i)
+    logits = torch.randn(3, 41, generator=g) * 2.5
+    if case.get("ties"):
+        logits[:, 5] = logits[:, 9] = logits.max(dim=-1).values - 0.5       # two equal candidates around the k-th value
+    return logits
+
+
+def golden_sampling():
+    """_sample_strategy + top_k_logits (M/inference/text_generation/generation.py:473-512), source executed: the filtered
+    distribution and, under a fixed torch seed, the sampled token; plus the greedy branch."""
+    import ast
+    import torch.nn.functional as F
+    path = os.path.join(REF, "long_vita_megatron", "inference", "text_generation", "generation.py")
+    src = open(path).read()
+    ns = {"torch": torch, "F": F}
+    for fn in ast.parse(src).body:
+        if isinstance(fn, ast.FunctionDef) and fn.name in ("_sample_strategy", "top_k_logits"):
+            exec(compile(ast.get_source_segment(src, fn), path, "exec"), ns)
+    out = []
+    for i, case in enumerate(SAMPLING_CASES):
+        logits = sampling_case_logits(i, case).bfloat16()            # the model hands over bf16 logits
+        torch.manual_seed(5 + i)
+        probs, tok = ns["_sample_strategy"](logits.clone(), True, top_k=case["top_k"], top_p=case["top_p"],
+                                            temperature=case["temperature"])
+        _, greedy = ns["_sample_strategy"](logits.clone(), False)
+        out.append(dict(case, probs=probs.clone(), token=tok.clone(), greedy=greedy.clone()))
+    torch.save(dict(cases=out), os.path.join(OUT, "sampling.pt"))
+
+
 LOSS_CASES = [dict(name="cp1_instruction", cp=1, instruction=True, n=[9], ones_mask=False),
               dict(name="cp2_logit_mask", cp=2, instruction=True, n=[6, 11], ones_mask=True),      # forward_step :866-867
               dict(name="cp4_plain", cp=4, instruction=False, n=[5, 8, 3, 7], ones_mask=False)]
@@ -879,7 +915,7 @@ def main():
                      ("embedding_scatter", golden_embedding_scatter), ("masked_linear", golden_masked_linear),
                      ("hf_vit", golden_hf_vit), ("image_processor", golden_image_processor),
                      ("external_inputs", golden_external_inputs), ("decode_loop", golden_decode_loop), ("loss_func", golden_loss_func), ("unfused_attention", golden_unfused_attention),
-                     ("converters", golden_converters)]:
+                     ("converters", golden_converters), ("sampling", golden_sampling)]:
         if only and name not in only:
             continue
         fn()

@@ -345,6 +345,30 @@ def test_tensor_x_context_parallel_groups_gloo_world4(tmp_path):
         assert p.returncode == 0 and "OK" in out, out
 
 
+def test_sample_strategy_matches_the_references_own_functions():
+    """_sample_strategy against the reference's _sample_strategy + top_k_logits executed from source (fixture sampling.pt):
+    the filtered distribution bit for bit (temperature, top-k incl. k = 1 and ties at the k-th value, top-p incl. p = 1 and
+    the kept first-above-threshold token), the token drawn under the same torch seed, the greedy branch, and — unlike an
+    fp32 input in the reference — an untouched caller tensor."""
+    from conftest import load_golden
+    from long_vita_amd.generation import _sample_strategy
+    from oracle.make_golden import SAMPLING_CASES, sampling_case_logits
+    g = load_golden("sampling.pt")["cases"]
+    assert len(g) == len(SAMPLING_CASES)
+    for i, c in enumerate(g):
+        logits = sampling_case_logits(i, c).bfloat16()
+        keep = logits.clone()
+        torch.manual_seed(5 + i)
+        probs, tok = _sample_strategy(logits, True, top_k=c["top_k"], top_p=c["top_p"], temperature=c["temperature"])
+        assert torch.equal(probs, c["probs"]), i
+        assert torch.equal(tok, c["token"]), i
+        same, greedy = _sample_strategy(logits, False)
+        assert same is logits and torch.equal(greedy, c["greedy"]) and torch.equal(logits, keep)
+        f32 = logits.float()
+        _sample_strategy(f32, True, top_k=c["top_k"], top_p=c["top_p"], temperature=2.0)
+        assert torch.equal(f32, keep.float())
+
+
 _DECODE_WORKER = r"""
 import os, sys, types, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["VITA_ROOT"])
