@@ -80,7 +80,7 @@ class Patch:
                 built.append(seg)
                 name = ".".join(built)
                 mod = types.ModuleType(name)
-                mod.__file__ = "long_vita_amd.dummy_module.py"
+                mod.__file__ = "mindspeed.dummy_module.py"               # the reference's marker string (:85)
                 sys.modules[name] = mod
                 if obj is not None:
                     setattr(obj, seg, mod)
@@ -104,21 +104,26 @@ class Patch:
                 original = None
             else:
                 raise RuntimeError(f"no exist {self.attr} of {owner}")
-        new = self.replacement if self.replacement is not None else original
+        # like the reference (:54-71) the patch function is cumulative: a patch that is re-applied after another wrapper
+        # was registered wraps the ALREADY wrapped function with every registered wrapper again
+        if self.replacement is None:
+            self.replacement = original
         for w in self.wrappers:
-            new = w(new)
+            self.replacement = w(self.replacement)
+        new = self.replacement
         if self.attr is not None:
             setattr(owner, self.attr, new)
-            if original is not None:
-                for mod in list(sys.modules.values()):
-                    if mod is None:
-                        continue
-                    try:
-                        held = mod.__dict__.get(self.attr) if hasattr(mod, "__dict__") else None
-                    except Exception:  # pragma: no cover - exotic module objects
-                        continue
-                    if held is original:
+            # identity match on the ORIGINAL object — None included (the reference compares id()s, :65-70), so a module
+            # that holds `attr = None` under the same name is redirected as well
+            for mod in list(sys.modules.values()):
+                if mod is None:
+                    continue
+                try:
+                    d = mod.__dict__ if hasattr(mod, "__dict__") else {}
+                    if self.attr in d and d[self.attr] is original:
                         setattr(mod, self.attr, new)
+                except Exception:  # pragma: no cover - exotic module objects
+                    continue
         self.applied = True
 
 

@@ -829,6 +829,86 @@ def golden_sampling():
     torch.save(dict(cases=out), os.path.join(OUT, "sampling.pt"))
 
 
+def patch_scenario(manager, Patch, tag: str):
+    """One script against a patch manager (the reference's M/patch_utils.py or the mirror): returns the observable outcomes."""
+    out = []
+
+    def rec(label, fn):
+        try:
+            out.append((label, repr(fn())))
+        except Exception as e:  # noqa: BLE001
+            out.append((label, f"{type(e).__name__}: {e}".replace(tag, "TAG").replace("oracle.make_golden.", "").replace("__main__.", "")))
+
+    manager.patches_info = {}
+    T, H = f"{tag}_target", f"{tag}_holder"
+    mod, holder = types.ModuleType(T), types.ModuleType(H)
+    mod.f = lambda x: x + 1
+    mod.g = lambda x: x + 2
+    mod.h = lambda x: x + 3
+    mod.nothing = None
+
+    class K:
+        def m(self, x):
+            return x * 2
+    mod.K = K
+    holder.f, holder.g = mod.f, mod.g                                  # `from target import f, g` made before patching
+    holder.brand_new = None                                            # same name, value None: id(None) matches (:65-70)
+    sys.modules[T], sys.modules[H] = mod, holder
+
+    def add_wrapper(fn):
+        return lambda x: fn(x) + 1000
+
+    def times_decorator(fn):
+        return lambda x: fn(x) * 3
+
+    def method_wrapper(fn):
+        return lambda self, x: fn(self, x) * 10
+
+    rec("register f", lambda: manager.register_patch(f"{T}.f", lambda x: x + 100))
+    rec("second outright f", lambda: manager.register_patch(f"{T}.f", lambda x: x))
+    rec("forced f", lambda: manager.register_patch(f"{T}.f", lambda x: x + 200, force_patch=True))
+    rec("wrapper on replaced f", lambda: manager.register_patch(f"{T}.f", add_wrapper))
+    rec("two wrappers g", lambda: (manager.register_patch(f"{T}.g", add_wrapper), manager.register_patch(f"{T}.g", times_decorator)))
+    rec("class attr", lambda: manager.register_patch(f"{T}.K.m", method_wrapper))
+    rec("dummy pkg", lambda: manager.register_patch(f"{tag}_missing.sub.fn", None, create_dummy=True))
+    rec("missing attr of module", lambda: manager.register_patch(f"{T}.brand_new", lambda: "made"))
+    rec("None on existing h", lambda: manager.register_patch(f"{T}.h", None))
+    rec("apply", lambda: manager.apply_patches())
+    rec("f", lambda: mod.f(1))
+    rec("holder.f", lambda: holder.f(1))
+    rec("g", lambda: mod.g(1))
+    rec("holder.g", lambda: holder.g(1))
+    rec("K.m", lambda: mod.K().m(3))
+    rec("dummy call", lambda: sys.modules[f"{tag}_missing.sub"].fn())
+    rec("dummy module file", lambda: sys.modules[f"{tag}_missing.sub"].__file__)
+    rec("brand_new", lambda: mod.brand_new())
+    rec("holder.brand_new", lambda: holder.brand_new())
+    rec("h", lambda: mod.h(1))
+    rec("apply again", lambda: manager.apply_patches())
+    rec("f after second apply", lambda: mod.f(1))
+    rec("re-register wrapper f", lambda: manager.register_patch(f"{T}.f", add_wrapper))
+    rec("apply third", lambda: manager.apply_patches())
+    rec("f after re-register", lambda: mod.f(1))
+    rec("missing module", lambda: Patch(f"{tag}_nowhere.x", lambda: 0, False).apply_patch())
+    rec("missing class attr", lambda: Patch(f"{T}.K.absent", lambda: 0, False).apply_patch())
+    rec("missing class attr dummy", lambda: Patch(f"{T}.K.absent2", None, True).apply_patch())
+    rec("absent2 call", lambda: mod.K.absent2())
+    rec("bare module", lambda: Patch(T, lambda: 0, False).apply_patch())
+    for k in [k for k in sys.modules if k.startswith(tag)]:
+        sys.modules.pop(k)
+    manager.patches_info = {}
+    return out
+
+
+def golden_patch_manager():
+    """M/patch_utils.py (stdlib only) loaded from its file and driven through patch_scenario."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location("vita_ref_patch_utils", os.path.join(REF, "long_vita_megatron", "patch_utils.py"))
+    ref = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(ref)
+    torch.save(dict(outcomes=patch_scenario(ref.MindSpeedPatchesManager, ref.Patch, "vitaref")), os.path.join(OUT, "patch_manager.pt"))
+
+
 LOSS_CASES = [dict(name="cp1_instruction", cp=1, instruction=True, n=[9], ones_mask=False),
               dict(name="cp2_logit_mask", cp=2, instruction=True, n=[6, 11], ones_mask=True),      # forward_step :866-867
               dict(name="cp4_plain", cp=4, instruction=False, n=[5, 8, 3, 7], ones_mask=False)]
@@ -915,7 +995,7 @@ def main():
                      ("embedding_scatter", golden_embedding_scatter), ("masked_linear", golden_masked_linear),
                      ("hf_vit", golden_hf_vit), ("image_processor", golden_image_processor),
                      ("external_inputs", golden_external_inputs), ("decode_loop", golden_decode_loop), ("loss_func", golden_loss_func), ("unfused_attention", golden_unfused_attention),
-                     ("converters", golden_converters), ("sampling", golden_sampling)]:
+                     ("converters", golden_converters), ("sampling", golden_sampling), ("patch_manager", golden_patch_manager)]:
         if only and name not in only:
             continue
         fn()

@@ -97,6 +97,20 @@ def test_patch_manager_semantics():
     aspm.patches_info = {}
 
 
+def test_patch_manager_behaves_like_the_references_patch_utils():
+    """The same 30-step script (oracle/make_golden.py:patch_scenario) was run against the reference's M/patch_utils.py
+    loaded from its file (fixture patch_manager.pt): outright / forced / wrapper / decorator registration, stacking order,
+    class attributes, identity propagation into modules that imported the original (None included), dummy packages,
+    missing modules / attributes, and the cumulative re-application quirk — every observable outcome is equal."""
+    from conftest import load_golden
+    from long_vita_amd.patch_utils import MindSpeedPatchesManager as aspm, Patch
+    from oracle.make_golden import patch_scenario
+    want = load_golden("patch_manager.pt")["outcomes"]
+    got = patch_scenario(aspm, Patch, "vitamirror")
+    assert len(want) == 30
+    assert got == want, [(a, b) for a, b in zip(got, want) if a != b]
+
+
 def test_adaptor_registers_reference_targets_with_dummy_megatron():
     """With fabricated megatron modules the adaptor lands its replacements on the reference's dotted
     names (M/megatron_adaptor.py:21-22,93-94,105-106)."""
