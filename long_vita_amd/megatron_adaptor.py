@@ -8,8 +8,16 @@ reference patches on the prefill path:
   megatron.core.tensor_parallel.layers.ColumnParallelLinear                                  (:105-106)
   megatron.core.models.common.embeddings.rotary_pos_embedding.apply_rotary_pos_emb           (K8; the reference
         leaves RotaryEmbedding unpatched, :102-103, and relies on apex's fused kernel)
-  megatron.inference.text_generation.generation.generate_tokens_probs_and_return_on_first_stage's helpers
-        (get_batch_on_this_cp_rank / sync_output, :141-147) via long_vita_amd.generation
+  megatron.inference.text_generation.generation.generate_tokens_probs_and_return_on_first_stage   (:143; the CP-aware
+        decode loop of long_vita_amd.generation with get_args() / get_tokenizer() feeding its keyword arguments)
+  megatron.inference.text_generation.forward_step.ForwardStep.__init__                          (:145, wrapper carrying
+        `external_inputs` into the InferenceParams)
+
+Targets of the reference that stay Megatron-resident (not arithmetic of this path): the two layer-spec builders and
+TransformerConfig (:81-97 — they need Megatron's ModuleSpec classes; INTEGRATION.md §2 shows the spec a maintainer returns),
+ensure_directory_exists, tokenisation, beam search, the pipelining forward steps (identical to upstream), parse_args,
+build_tokenizer.  `tests/test_cpu_host.py` checks every name registered here against the reference's own call sites
+(fixture adaptor_targets.pt).
 
 Megatron-LM is not installable in the build container, so the registration is
 guarded: without `megatron` the module is importable and `PATCHES` lists what would be applied;
@@ -45,11 +53,41 @@ def dot_product_attention_forward_wrapper(fn):
     return wrapper
 
 
+def inference_forward_step_init_wrapper(fn):
+    """M/inference/text_generation/forward_step.py:29-39: ForwardStep(model, batch, seq, external_inputs=...) keeps the
+    request's external inputs on the InferenceParams the model later reads (gpt_vl_model.py:261-266)."""
+    @wraps(fn)
+    def wrapper(self, *args, **kwargs):
+        external_inputs = kwargs.pop("external_inputs", None)
+        fn(self, *args, **kwargs)
+        self.inference_params.external_inputs = external_inputs
+
+    return wrapper
+
+
+def generate_tokens_probs_and_return_on_first_stage(model, tokens, lengths, return_output_log_probs=False, do_sample=False,
+                                                    top_k=0, top_p=0.0, temperature=1.0,
+                                                    use_eod_token_for_early_termination=True, external_inputs=None):
+    """The reference's signature (M/inference/text_generation/generation.py:33-42).  What it reads from Megatron's globals
+    (:71-76,87-90: args.use_kv_cache, args.logit_mask, args.eos_id or tokenizer.eod) becomes the keyword arguments of
+    long_vita_amd.generation's loop; reference_compat keeps the reference's block pick unless
+    args.vita_fix_cp_logit_block is set."""
+    from megatron.training import get_args, get_tokenizer
+
+    from . import generation
+    args = get_args()
+    termination_id = args.eos_id if hasattr(args, "eos_id") else get_tokenizer().eod
+    return generation.generate_tokens_probs_and_return_on_first_stage(
+        model, tokens, lengths, return_output_log_probs=return_output_log_probs, do_sample=do_sample, top_k=top_k, top_p=top_p,
+        temperature=temperature, use_eod_token_for_early_termination=use_eod_token_for_early_termination,
+        external_inputs=external_inputs, use_kv_cache=bool(args.use_kv_cache), logit_mask=bool(args.logit_mask),
+        termination_id=termination_id, reference_compat=not getattr(args, "vita_fix_cp_logit_block", False))
+
+
 def _targets():
     from .language_model_embedding import LanguageModelEmbedding
     from .layers import ColumnParallelLinear
     from .rotary_pos_embedding import apply_rotary_pos_emb
-    from . import generation
     return [
         ("megatron.core.transformer.dot_product_attention.DotProductAttention.forward",
          dot_product_attention_forward_wrapper),
@@ -57,11 +95,14 @@ def _targets():
          LanguageModelEmbedding),
         ("megatron.core.tensor_parallel.layers.ColumnParallelLinear", ColumnParallelLinear),
         ("megatron.core.models.common.embeddings.rotary_pos_embedding.apply_rotary_pos_emb", apply_rotary_pos_emb),
-        ("megatron.inference.text_generation.generation.get_batch_on_this_cp_rank",
-         generation.get_batch_on_this_cp_rank),
-        ("megatron.inference.text_generation.generation.sync_output", generation.sync_output),
+        ("megatron.inference.text_generation.generation.generate_tokens_probs_and_return_on_first_stage",
+         generate_tokens_probs_and_return_on_first_stage),
+        ("megatron.inference.text_generation.forward_step.ForwardStep.__init__", inference_forward_step_init_wrapper),
     ]
 
+
+# registered here but not by the reference (it leaves Megatron's RoPE in place and relies on apex's fused kernel, :102-103)
+EXTRA_TARGETS = ("megatron.core.models.common.embeddings.rotary_pos_embedding.apply_rotary_pos_emb",)
 
 PATCHES = [name for name, _ in _targets()]
 

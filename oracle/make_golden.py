@@ -909,6 +909,35 @@ def golden_patch_manager():
     torch.save(dict(outcomes=patch_scenario(ref.MindSpeedPatchesManager, ref.Patch, "vitaref")), os.path.join(OUT, "patch_manager.pt"))
 
 
+def golden_adaptor_targets():
+    """The plugin surface as the reference spells it: every `aspm.register_patch('<dotted target>', <replacement>)` call
+    site of M/megatron_adaptor.py (read with ast — importing the file would run it against a real Megatron), grouped by the
+    function that makes it, plus the functions exe_adaptation actually calls, and the direct attribute assignments."""
+    import ast
+    path = os.path.join(REF, "long_vita_megatron", "megatron_adaptor.py")
+    src = open(path).read()
+    tree = ast.parse(src)
+    groups, assigns = {}, []
+    for fn in [n_ for n_ in tree.body if isinstance(n_, ast.FunctionDef)]:
+        calls = []
+        for node in ast.walk(fn):
+            if (isinstance(node, ast.Call) and isinstance(node.func, ast.Attribute) and node.func.attr == "register_patch"
+                    and node.args and isinstance(node.args[0], ast.Constant) and isinstance(node.args[0].value, str)):
+                calls.append((node.lineno, node.args[0].value, ast.unparse(node.args[1]) if len(node.args) > 1 else None,
+                              {k_.arg: ast.unparse(k_.value) for k_ in node.keywords}))
+            if isinstance(node, ast.Assign) and isinstance(node.targets[0], ast.Attribute) and not isinstance(node.value, ast.Constant):
+                tgt = ast.unparse(node.targets[0])
+                if tgt.startswith("megatron."):
+                    assigns.append((node.lineno, tgt, ast.unparse(node.value)))
+        groups[fn.name] = [c[1:] for c in sorted(calls)]
+    exe = next(n_ for n_ in tree.body if isinstance(n_, ast.FunctionDef) and n_.name == "exe_adaptation")
+    called = [n_.func.id for n_ in ast.walk(exe) if isinstance(n_, ast.Call) and isinstance(n_.func, ast.Name) and n_.func.id in groups]
+    called = [c for c in groups if c in called]                       # source order of the definitions
+    live = [t for c in called + ["exe_adaptation"] for t in groups[c]]
+    torch.save(dict(groups=groups, called=called, live_targets=live, assignments=[a_[1:] for a_ in sorted(assigns)]),
+               os.path.join(OUT, "adaptor_targets.pt"))
+
+
 LOSS_CASES = [dict(name="cp1_instruction", cp=1, instruction=True, n=[9], ones_mask=False),
               dict(name="cp2_logit_mask", cp=2, instruction=True, n=[6, 11], ones_mask=True),      # forward_step :866-867
               dict(name="cp4_plain", cp=4, instruction=False, n=[5, 8, 3, 7], ones_mask=False)]
@@ -995,7 +1024,8 @@ def main():
                      ("embedding_scatter", golden_embedding_scatter), ("masked_linear", golden_masked_linear),
                      ("hf_vit", golden_hf_vit), ("image_processor", golden_image_processor),
                      ("external_inputs", golden_external_inputs), ("decode_loop", golden_decode_loop), ("loss_func", golden_loss_func), ("unfused_attention", golden_unfused_attention),
-                     ("converters", golden_converters), ("sampling", golden_sampling), ("patch_manager", golden_patch_manager)]:
+                     ("converters", golden_converters), ("sampling", golden_sampling), ("patch_manager", golden_patch_manager),
+                     ("adaptor_targets", golden_adaptor_targets)]:
         if only and name not in only:
             continue
         fn()

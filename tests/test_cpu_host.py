@@ -136,10 +136,75 @@ def test_adaptor_registers_reference_targets_with_dummy_megatron():
         assert sys.modules["megatron.core.tensor_parallel.layers"].ColumnParallelLinear is ColumnParallelLinear
         assert DotProductAttention.forward.__name__ == "forward" and DotProductAttention.forward is not None
         assert DotProductAttention.forward.__wrapped__.__qualname__.endswith("DotProductAttention.forward")
+        # the decode loop lands on the reference's target (:143) and takes its switches from Megatron's globals (:71-76)
+        gen_mod = sys.modules["megatron.inference.text_generation.generation"]
+        assert gen_mod.generate_tokens_probs_and_return_on_first_stage is ad.generate_tokens_probs_and_return_on_first_stage
+        V = 13
+        nxt = lambda tok, pos: (tok * 7 + pos * 3 + 1) % V
+        full = [4, 2, 9]
+        while len(full) < 12:
+            full.append(int(nxt(torch.tensor(full[-1]), torch.tensor(len(full) - 1))))
+        stop = next(i for i in range(5, 12) if full[i] not in full[3:i])          # first generated token that is new
+        training = types.ModuleType("megatron.training")
+        training.get_args = lambda: types.SimpleNamespace(use_kv_cache=False, logit_mask=True, eos_id=full[stop])
+        training.get_tokenizer = lambda: types.SimpleNamespace(eod=-1)
+        sys.modules["megatron.training"] = training
+
+        def model(tokens, position_ids, attention_mask, inference_params=None):
+            sel = inference_params.logit_mask[0].nonzero().flatten()
+            return torch.nn.functional.one_hot(nxt(tokens[0, sel], position_ids[0, sel]), V).float()[None]
+        tokens = torch.zeros(1, 12, dtype=torch.long)
+        tokens[0, :3] = torch.tensor(full[:3])
+        steps = list(gen_mod.generate_tokens_probs_and_return_on_first_stage(model, tokens, torch.tensor([3])))
+        assert steps[-1][0][0].tolist() == full[:stop + 1] and stop < 11          # stops at args.eos_id
+        # ForwardStep(..., external_inputs=...) (:145): the wrapper pops the keyword and hangs it on the InferenceParams
+        fs_mod = sys.modules["megatron.inference.text_generation.forward_step"]
+
+        class UpstreamForwardStep:
+            def __init__(self, model, max_batch_size, max_sequence_length):
+                self.inference_params = types.SimpleNamespace(external_inputs="unset")
+        UpstreamForwardStep.__init__ = ad.inference_forward_step_init_wrapper(UpstreamForwardStep.__init__)
+        assert UpstreamForwardStep(None, 1, 8, external_inputs={"images": 1}).inference_params.external_inputs == {"images": 1}
+        assert UpstreamForwardStep(None, 1, 8).inference_params.external_inputs is None
+        assert fs_mod.ForwardStep.__init__ is not None
     finally:
         for k in [k for k in sys.modules if k == "megatron" or k.startswith("megatron.")]:
             sys.modules.pop(k)
         aspm.patches_info = {}
+
+
+def test_adaptor_target_names_are_the_references_call_sites():
+    """Every dotted name the adaptor registers is one the reference registers (M/megatron_adaptor.py call sites read with
+    ast, fixture adaptor_targets.pt) with the same kind of replacement (wrapper vs outright), except the documented extra;
+    the reference targets left to Megatron are spelled out."""
+    from conftest import load_golden
+    import long_vita_amd.megatron_adaptor as ad
+    g = load_golden("adaptor_targets.pt")
+    live = {t[0]: t[1] for t in g["live_targets"]}
+    assert len(live) == 16 and "mcore_parallel_state_adaptation" not in g["called"]          # defined, never called (:158)
+    mine = dict(ad._targets())
+    for name, obj in mine.items():
+        if name in ad.EXTRA_TARGETS:
+            continue
+        assert name in live, name
+        ref_is_wrapper = live[name].endswith(("wrapper", "decorator"))
+        assert obj.__name__.endswith(("wrapper", "decorator")) == ref_is_wrapper, name
+        assert obj.__name__ == live[name], (name, obj.__name__, live[name])               # same replacement names too
+    left = sorted(set(live) - set(mine))
+    assert left == sorted([
+        "megatron.core.models.gpt.gpt_layer_specs.get_gpt_layer_local_spec",
+        "megatron.core.models.gpt.gpt_layer_specs.get_gpt_layer_with_transformer_engine_spec",
+        "megatron.core.transformer.transformer_config.TransformerConfig",
+        "megatron.training.checkpointing.ensure_directory_exists",
+        "megatron.inference.text_generation.tokenization.tokenize_prompts",
+        "megatron.inference.text_generation.tokenization._tokenize_prompts_and_batch",
+        "megatron.inference.text_generation.generation.beam_search_and_return_on_first_stage",
+        "megatron.inference.text_generation.forward_step._no_pipelining_forward_step",
+        "megatron.inference.text_generation.forward_step._with_pipelining_forward_step",
+        "megatron.training.arguments.parse_args", "megatron.training.global_vars.build_tokenizer"])
+    assert [a[0] for a in g["assignments"]] == ["megatron.legacy.data.data_samplers.build_pretraining_data_loader",
+                                                "megatron.training.training.build_pretraining_data_loader",
+                                                "megatron.core.optimizer._get_param_groups"]
 
 
 # ---------------------------------------------------------------------------------------------
