@@ -938,6 +938,23 @@ def golden_adaptor_targets():
                os.path.join(OUT, "adaptor_targets.pt"))
 
 
+def golden_packed_positions():
+    """--reset-position-ids --reset-attention-mask (stage-2 packing): M/training/utils.py:get_ltor_masks_and_position_ids
+    (:192-250) on token rows with EOD tokens -> the position ids with resets and the block-diagonal causal mask;
+    compute_actual_seq_len (:53-57) on those position ids."""
+    utils = importlib.import_module("long_vita_megatron.training.utils")
+    EOD = 3
+    g = torch.Generator().manual_seed(8)
+    rows = []
+    for seq, eods in [(24, [5, 6, 17]), (32, [0, 9, 31]), (16, []), (40, [7, 8, 9, 30])]:
+        data = torch.randint(4, 100, (1, seq), generator=g)
+        data[0, eods] = EOD
+        mask, loss_mask, pos = utils.get_ltor_masks_and_position_ids(data, EOD, True, True, True)
+        rows.append(dict(data=data, eod=EOD, attention_mask=mask.clone(), loss_mask=loss_mask.clone(), position_ids=pos.clone(),
+                         actual_seq_len=utils.compute_actual_seq_len(pos[0])))
+    torch.save(dict(rows=rows), os.path.join(OUT, "packed_positions.pt"))
+
+
 LOSS_CASES = [dict(name="cp1_instruction", cp=1, instruction=True, n=[9], ones_mask=False),
               dict(name="cp2_logit_mask", cp=2, instruction=True, n=[6, 11], ones_mask=True),      # forward_step :866-867
               dict(name="cp4_plain", cp=4, instruction=False, n=[5, 8, 3, 7], ones_mask=False)]
@@ -1025,7 +1042,7 @@ def main():
                      ("hf_vit", golden_hf_vit), ("image_processor", golden_image_processor),
                      ("external_inputs", golden_external_inputs), ("decode_loop", golden_decode_loop), ("loss_func", golden_loss_func), ("unfused_attention", golden_unfused_attention),
                      ("converters", golden_converters), ("sampling", golden_sampling), ("patch_manager", golden_patch_manager),
-                     ("adaptor_targets", golden_adaptor_targets)]:
+                     ("adaptor_targets", golden_adaptor_targets), ("packed_positions", golden_packed_positions)]:
         if only and name not in only:
             continue
         fn()

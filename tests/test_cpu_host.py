@@ -389,6 +389,41 @@ def test_packed_segments_match_transformers_varlen_preparation():
         assert int(max_len) == int((end - start).max())
 
 
+def test_packed_segments_reproduce_the_references_reset_attention_mask():
+    """Stage-2 packing end to end on the host side: the reference's get_ltor_masks_and_position_ids (--reset-position-ids
+    --reset-attention-mask, M/training/utils.py:192-250) turned token rows with EOD tokens into position ids with resets and
+    a block-diagonal causal mask, and compute_actual_seq_len (:53-57) into sample ends (fixture packed_positions.pt).  The
+    segment bounds the HIP kernels get from those position ids describe exactly that mask and those ends — EOD as its own
+    length-1 sample, consecutive EODs, EOD in the first and in the last position included."""
+    from conftest import load_golden
+    from long_vita_amd import training_utils as tu
+    from oracle.attention import core_attention
+    rows = load_golden("packed_positions.pt")["rows"]
+    assert len(rows) == 4
+    for r in rows:
+        pos, ref_mask = r["position_ids"], r["attention_mask"][0, 0]            # True = masked
+        S = pos.shape[1]
+        try:
+            tu.set_position_ids(pos.transpose(0, 1).contiguous())
+            seg = tu.get_packed_segments()
+        finally:
+            tu.set_position_ids(None)
+        q, k = torch.arange(S)[:, None], torch.arange(S)[None, :]
+        if seg is None:
+            assert r["actual_seq_len"] == [S] and torch.equal(ref_mask, k > q)
+            continue
+        start, end = seg[0].long(), seg[1].long()
+        allowed = (k <= q) & (k >= start[:, None])
+        assert torch.equal(~ref_mask, allowed)
+        assert sorted(set(end.tolist())) == r["actual_seq_len"]
+        # and the oracle's varlen rule (what the GPU tests compare the kernels with) is the same mask
+        cu = torch.tensor([0] + r["actual_seq_len"], dtype=torch.int32)
+        x = torch.randn(S, 1, 2, S, generator=torch.Generator().manual_seed(S))
+        v = torch.eye(S)[:, None, None, :].expand(S, 1, 2, S).contiguous()        # values = one-hot keys: output = probabilities
+        probs = core_attention(x, x, v, causal=True, cu_seqlens=cu).view(S, 2, S)
+        assert torch.equal(probs[:, 0] > 0, allowed)
+
+
 _TPCP_WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["VITA_ROOT"])
