@@ -125,43 +125,65 @@ def merge_tp_shards(shards: List[Dict[str, torch.Tensor]], swiglu_fc1: bool = Tr
 def mcore_llm_to_params(sd: Dict[str, torch.Tensor], cfg, prefix: str = "") -> dict:
     """Megatron-core GPTModel names with the TE layer spec (layer norms folded into the following linear,
     M/core/models/gpt/gpt_layer_specs.py:35-49; names as in R/tools/hf2mcore_long_vita.py:590-617)."""
-    def g(name):
-        return sd[prefix + name]
+    def g(*names):
+        for name in names:                       # TE-spec name first, then the local-spec name
+            if prefix + name in sd:              # (M/ckpt_convert_modellink_to_megatron_with_te.py:37-41 renames one into the other)
+                return sd[prefix + name]
+        raise KeyError(prefix + names[0])
 
     embed = g("embedding.word_embeddings.weight")
     p = {"embed": embed, "final_ln": g("decoder.final_layernorm.weight"),
          "lm_head": sd.get(prefix + "output_layer.weight", embed), "layers": []}
     for i in range(cfg.num_layers):
         pre = f"decoder.layers.{i}."
-        p["layers"].append({"ln1": g(pre + "self_attention.linear_qkv.layer_norm_weight"),
+        p["layers"].append({"ln1": g(pre + "self_attention.linear_qkv.layer_norm_weight", pre + "input_layernorm.weight"),
                             "qkv_w": g(pre + "self_attention.linear_qkv.weight"),
                             "qkv_b": g(pre + "self_attention.linear_qkv.bias"),
                             "o_w": g(pre + "self_attention.linear_proj.weight"),
-                            "ln2": g(pre + "mlp.linear_fc1.layer_norm_weight"),
+                            "ln2": g(pre + "mlp.linear_fc1.layer_norm_weight", pre + "pre_mlp_layernorm.weight"),
                             "fc1_w": g(pre + "mlp.linear_fc1.weight"), "fc2_w": g(pre + "mlp.linear_fc2.weight")})
     # the vocabulary is padded to a multiple of 128 * TP on the Megatron side (--make-vocab-size-divisible-by)
     return p
 
 
 def mcore_vit_to_params(sd: Dict[str, torch.Tensor], vcfg, prefix: str = "") -> dict:
-    """Names written by L/ckpt_converter_intern_vit.py:76-141 with --use-te."""
-    def g(name):
-        return sd[prefix + name]
+    """Names written by L/ckpt_converter_intern_vit.py:76-141 (with --use-te, or the local-spec names without it)."""
+    def g(*names):
+        for name in names:
+            if prefix + name in sd:
+                return sd[prefix + name]
+        raise KeyError(prefix + names[0])
 
     p = {"conv_w": g("conv1.weight"), "conv_b": g("conv1.bias"), "cls": g("class_token").reshape(1, 1, -1),
          "pos": g("position_embeddings.weight"), "layers": []}
     for i in range(vcfg.num_layers):
         pre = f"decoder.layers.{i}."
         p["layers"].append({
-            "ln1_w": g(pre + "self_attention.linear_qkv.layer_norm_weight"),
-            "ln1_b": g(pre + "self_attention.linear_qkv.layer_norm_bias"),
+            "ln1_w": g(pre + "self_attention.linear_qkv.layer_norm_weight", pre + "input_layernorm.weight"),
+            "ln1_b": g(pre + "self_attention.linear_qkv.layer_norm_bias", pre + "input_layernorm.bias"),
             "qkv_w": g(pre + "self_attention.linear_qkv.weight"), "qkv_b": g(pre + "self_attention.linear_qkv.bias"),
             "proj_w": g(pre + "self_attention.linear_proj.weight"), "proj_b": g(pre + "self_attention.linear_proj.bias"),
             "ls1": g(pre + "ls1"),
-            "ln2_w": g(pre + "mlp.linear_fc1.layer_norm_weight"), "ln2_b": g(pre + "mlp.linear_fc1.layer_norm_bias"),
+            "ln2_w": g(pre + "mlp.linear_fc1.layer_norm_weight", pre + "pre_mlp_layernorm.weight"),
+            "ln2_b": g(pre + "mlp.linear_fc1.layer_norm_bias", pre + "pre_mlp_layernorm.bias"),
             "fc1_w": g(pre + "mlp.linear_fc1.weight"), "fc1_b": g(pre + "mlp.linear_fc1.bias"),
             "fc2_w": g(pre + "mlp.linear_fc2.weight"), "fc2_b": g(pre + "mlp.linear_fc2.bias"), "ls2": g(pre + "ls2")})
     return p
+
+
+def split_llm_and_vit(sd: Dict[str, torch.Tensor]):
+    """A combined training checkpoint -> (language-model part, vision part), as M/ckpt_split_llm_and_vit.py:21-59 does it
+    per file: keys containing "unused" are dropped, keys containing "external_feature_model." go to the vision part with
+    everything up to and including that prefix removed."""
+    llm, vit = {}, {}
+    for k, v in sd.items():
+        if "unused" in k:
+            continue
+        if "external_feature_model." in k:
+            vit[k.split("external_feature_model.")[-1]] = v
+        else:
+            llm[k] = v
+    return llm, vit
 
 
 # ------------------------------------------------------------------------------------------------
@@ -196,7 +218,13 @@ def load_mcore_checkpoint(path: str, iteration: Optional[int] = None, swiglu_fc1
         it_dir = "release" if tag == "release" else f"iter_{int(tag):07d}"
     else:
         it_dir = f"iter_{iteration:07d}"
-    ranks = sorted(d for d in os.listdir(os.path.join(path, it_dir)) if re.fullmatch(r"mp_rank_\d\d", d))
+    dirs = os.listdir(os.path.join(path, it_dir))
+    ranks = sorted(d for d in dirs if re.fullmatch(r"mp_rank_\d\d", d))
+    if not ranks:                                  # Megatron appends the pipeline rank when PP > 1: mp_rank_TT_PPP
+        staged = sorted(d for d in dirs if re.fullmatch(r"mp_rank_\d\d_\d\d\d", d))
+        if any(not d.endswith("_000") for d in staged):
+            raise NotImplementedError("pipeline-parallel checkpoints are not merged here (this path runs PP = 1)")
+        ranks = staged
     if not ranks:
         raise FileNotFoundError(f"no mp_rank_XX directories under {os.path.join(path, it_dir)}")
     shards = [torch.load(os.path.join(path, it_dir, r, "model_optim_rng.pt"), map_location="cpu", weights_only=False)["model"]

@@ -955,6 +955,57 @@ def golden_packed_positions():
     torch.save(dict(rows=rows), os.path.join(OUT, "packed_positions.pt"))
 
 
+CKPT_SCRIPT_KEYS = ["embedding.word_embeddings.weight", "decoder.layers.0.input_layernorm.weight",
+                    "decoder.layers.0.self_attention.linear_qkv.weight", "decoder.layers.0.pre_mlp_layernorm.weight",
+                    "decoder.layers.0.mlp.linear_fc1.weight", "decoder.final_layernorm.weight", "output_layer.weight",
+                    "unused_parameter", "external_feature_model.vit.decoder.layers.0.input_layernorm.weight",
+                    "external_feature_model.vit.conv1.weight", "external_feature_model.projection.encoder.linear_fc1.weight"]
+
+
+def golden_ckpt_scripts():
+    """M/ckpt_convert_modellink_to_megatron_with_te.py:convert (imported) and M/ckpt_split_llm_and_vit.py (a script with
+    hard-coded paths: its three path constants are re-pointed, the rest of its source runs as is) on a two-rank checkpoint
+    directory whose tensors are their own key index: which keys / values end up where."""
+    import ast
+    import tempfile
+    conv = importlib.import_module("long_vita_megatron.ckpt_convert_modellink_to_megatron_with_te")
+
+    def write(root, it=7):
+        for r in range(2):
+            d = os.path.join(root, f"iter_{it:07d}", f"mp_rank_{r:02d}_000")
+            os.makedirs(d)
+            torch.save({"model": {k: torch.tensor([100 * r + i]) for i, k in enumerate(CKPT_SCRIPT_KEYS)}, "iteration": it},
+                       os.path.join(d, "model_optim_rng.pt"))
+        open(os.path.join(root, "latest_checkpointed_iteration.txt"), "w").write(str(it))
+
+    def read(root):
+        out = {}
+        for base, _dirs, files in os.walk(root):
+            for f in files:
+                if f.endswith(".pt"):
+                    sd = torch.load(os.path.join(base, f), weights_only=False)["model"]
+                    out[os.path.relpath(os.path.join(base, f), root)] = {k: int(v) for k, v in sd.items()}
+        return out
+
+    with tempfile.TemporaryDirectory() as d, contextlib.redirect_stdout(open(os.devnull, "w")):
+        src_dir, te_dir = os.path.join(d, "in"), os.path.join(d, "te")
+        write(src_dir)
+        conv.convert(src_dir, te_dir)
+        renamed = read(te_dir)
+        tracker = open(os.path.join(te_dir, "latest_checkpointed_iteration.txt")).read()
+        path = os.path.join(REF, "long_vita_megatron", "ckpt_split_llm_and_vit.py")
+        tree = ast.parse(open(path).read())
+        load = os.path.join(src_dir, "iter_0000007") + "/"
+        consts = {"CKPT_LOAD_DIR": load, "LLM_SAVE_DIR": os.path.join(d, "llm", "iter_0000007") + "/",
+                  "VIT_SAVE_DIR": os.path.join(d, "vit", "iter_0000007") + "/"}
+        for node in tree.body:
+            if isinstance(node, ast.Assign) and node.targets[0].id in consts:
+                node.value = ast.Constant(consts[node.targets[0].id])
+        exec(compile(ast.fix_missing_locations(tree), path, "exec"), {"__name__": "split"})
+        llm, vit = read(os.path.join(d, "llm")), read(os.path.join(d, "vit"))
+    torch.save(dict(keys=CKPT_SCRIPT_KEYS, renamed=renamed, tracker=tracker, llm=llm, vit=vit), os.path.join(OUT, "ckpt_scripts.pt"))
+
+
 LOSS_CASES = [dict(name="cp1_instruction", cp=1, instruction=True, n=[9], ones_mask=False),
               dict(name="cp2_logit_mask", cp=2, instruction=True, n=[6, 11], ones_mask=True),      # forward_step :866-867
               dict(name="cp4_plain", cp=4, instruction=False, n=[5, 8, 3, 7], ones_mask=False)]
@@ -1042,7 +1093,8 @@ def main():
                      ("hf_vit", golden_hf_vit), ("image_processor", golden_image_processor),
                      ("external_inputs", golden_external_inputs), ("decode_loop", golden_decode_loop), ("loss_func", golden_loss_func), ("unfused_attention", golden_unfused_attention),
                      ("converters", golden_converters), ("sampling", golden_sampling), ("patch_manager", golden_patch_manager),
-                     ("adaptor_targets", golden_adaptor_targets), ("packed_positions", golden_packed_positions)]:
+                     ("adaptor_targets", golden_adaptor_targets), ("packed_positions", golden_packed_positions),
+                     ("ckpt_scripts", golden_ckpt_scripts)]:
         if only and name not in only:
             continue
         fn()

@@ -202,3 +202,39 @@ def test_llm_converter_matches_the_references_hf2mcore():
     got = ck.hf_llm_to_params(llm_convert_hf_state(), cfg)
     assert _tree_equal(got, want)
     assert not torch.equal(got["lm_head"], got["embed"])             # --untie-embeddings-and-output-weights
+
+
+def test_checkpoint_scripts_of_the_reference(tmp_path):
+    """M/ckpt_convert_modellink_to_megatron_with_te.py and M/ckpt_split_llm_and_vit.py were run on a two-rank directory whose
+    tensors are their own key index (fixture ckpt_scripts.pt).  split_llm_and_vit makes the same two dictionaries; the
+    local-spec -> TE renames are exactly the alternative names mcore_llm_to_params accepts; a directory in Megatron's PP > 1
+    naming with only stage 000 loads, other stages are refused."""
+    from conftest import load_golden
+    g = load_golden("ckpt_scripts.pt")
+    assert g["tracker"] == "7"
+    for r in range(2):
+        sd = {k: torch.tensor([100 * r + i]) for i, k in enumerate(g["keys"])}
+        llm, vit = ck.split_llm_and_vit(sd)
+        assert {k: int(v) for k, v in llm.items()} == g["llm"][f"iter_0000007/mp_rank_{r:02d}_000/model_optim_rng.pt"]
+        assert {k: int(v) for k, v in vit.items()} == g["vit"][f"iter_0000007/mp_rank_{r:02d}/model_optim_rng.pt"]
+        ren = g["renamed"][f"iter_0000007/mp_rank_{r:02d}_000/model_optim_rng.pt"]
+        moved = {k: next(k2 for k2, v2 in ren.items() if v2 == int(v)) for k, v in sd.items() if k not in ren}
+        assert moved == {"decoder.layers.0.input_layernorm.weight": "decoder.layers.0.self_attention.linear_qkv.layer_norm_weight",
+                         "decoder.layers.0.pre_mlp_layernorm.weight": "decoder.layers.0.mlp.linear_fc1.layer_norm_weight"}
+    # both spellings read the same parameters
+    cfg1 = ollm.LLMConfig(num_layers=1, hidden=CFG.hidden, heads=CFG.heads, kv_groups=CFG.kv_groups, head_dim=CFG.head_dim,
+                          ffn=CFG.ffn, vocab=CFG.vocab)
+    p = ollm.init_llm_params(cfg1, seed=6, dtype=torch.bfloat16)
+    te = _mcore_names(p)
+    local = {moved_back: v for moved_back, v in ((next((a for a, b in moved.items() if b == k), k), v) for k, v in te.items())}
+    assert set(local) != set(te) and _tree_equal(ck.mcore_llm_to_params(local, cfg1), ck.mcore_llm_to_params(te, cfg1))
+    # Megatron's directory names when the pipeline rank is part of them
+    root = tmp_path / "ckpt"
+    d = root / "iter_0000007" / "mp_rank_00_000"
+    os.makedirs(d)
+    torch.save({"model": te}, d / "model_optim_rng.pt")
+    (root / "latest_checkpointed_iteration.txt").write_text("7")
+    assert _tree_equal(ck.mcore_llm_to_params(ck.load_mcore_checkpoint(str(root)), cfg1), p)
+    os.makedirs(root / "iter_0000007" / "mp_rank_00_001")
+    with pytest.raises(NotImplementedError):
+        ck.load_mcore_checkpoint(str(root))
