@@ -81,7 +81,8 @@ def get_external_inputs(tokens, image_list, image_path_list, video_path_list, to
                         video_frames_list: Optional[Sequence] = None, device="cuda",
                         cp_size: Optional[int] = None, cp_rank: Optional[int] = None, cp_seq_length: Optional[int] = None):
     """cp_size / cp_rank: per-rank loading (module docstring); cp_seq_length = the length the sequence is chunked at when
-    that is not the 64-padded row (generation._cp_prefill_length pads a KV-cache prefill to 2*CP*256)."""
+    that is not the 64-padded row (generation._cp_prefill_length pads a KV-cache prefill to 2*CP*256) — an int, or a
+    callable of the expanded row's token count when it depends on it."""
     per_rank = cp_size is not None and cp_size > 1
     if per_rank and (cp_rank is None or not 0 <= cp_rank < cp_size):
         raise ValueError("per-rank loading needs 0 <= cp_rank < cp_size")
@@ -173,7 +174,8 @@ def get_external_inputs(tokens, image_list, image_path_list, video_path_list, to
     token_lengths = [len(x) for x in tokens]
     tokens = [x + [pad_id] * (-(-len(x) // 64) * 64 - len(x)) for x in tokens]
     if per_rank:
-        seq_length = len(tokens[0]) if cp_seq_length is None else cp_seq_length
+        seq_length = len(tokens[0]) if cp_seq_length is None else (
+            cp_seq_length(token_lengths[0]) if callable(cp_seq_length) else cp_seq_length)
         keep = frames_on_this_cp_rank(image_indices[1, :, 0].tolist(), image_token_length, seq_length, cp_size, cp_rank)
         kept, at = [], 0
         for slot, entry in enumerate(images):
@@ -199,3 +201,48 @@ def get_external_inputs(tokens, image_list, image_path_list, video_path_list, to
     tokens = torch.tensor(tokens, dtype=torch.long, device=device)
     token_lengths = torch.tensor(token_lengths, dtype=torch.long, device=device)
     return external_inputs, tokens, token_lengths
+
+
+def request_tensors(prompt_ids: Sequence[int], tokens_to_generate: int, tokenizer, image_processor, *, max_generate_length: int = 128,
+                    image_list=None, image_path_list=None, video_path_list=None, video_frames_list=None, **kw):
+    """One tokenised prompt -> (tokens [1, S], lengths [1], external_inputs or None), the state MegatronModuleForCausalLM.generate
+    (module.py:270-360) hands to the decode loop: the prompt is first padded with pad_token_id to prompt + tokens_to_generate
+    (or max_generate_length; _tokenize_prompts_and_batch, M/inference/text_generation/tokenization.py:150-166), the media tags
+    are expanded on that padded row, and the true context length is the expanded length minus that padding (:357).  Prompt
+    templates / text tokenisation stay with the caller.  **kw goes to get_external_inputs (cp_size / cp_rank: per-rank
+    loading instead of the reference's rank-0 build + world broadcast, :340-360)."""
+    prompt = [int(t) for t in prompt_ids]
+    total = len(prompt) + tokens_to_generate if tokens_to_generate > 0 else max_generate_length
+    pad_length = total - len(prompt)
+    if pad_length < 0:
+        raise ValueError("the prompt is longer than max_generate_length")
+    device = kw.get("device", "cuda")
+    tokens = torch.tensor([prompt + [tokenizer.pad_token_id] * pad_length], dtype=torch.long)
+    if image_list is None and image_path_list is None and video_path_list is None and video_frames_list is None:
+        return tokens.to(device), torch.tensor([len(prompt)], dtype=torch.long, device=device), None
+    external_inputs, tokens, lengths = get_external_inputs(tokens, image_list, image_path_list, video_path_list, tokenizer,
+                                                           image_processor, video_frames_list=video_frames_list, **kw)
+    return tokens, lengths - pad_length, external_inputs
+
+
+def generate(model, prompt_ids: Sequence[int], tokens_to_generate: int, tokenizer, image_processor=None, *, do_sample=False,
+             top_k=0, top_p=0.0, temperature=1.0, return_output_log_probs=False, use_kv_cache=True, logit_mask=True,
+             termination_id=None, reference_compat=False, per_rank_loading=True, **media):
+    """The request -> token stream chain of MegatronModuleForCausalLM.generate (module.py:270-402) for one prompt: request_tensors
+    on every rank (with per_rank_loading each CP rank builds only its own frames; nothing is broadcast), then the decode loop.
+    Yields what generate_tokens_probs_and_return_on_first_stage yields."""
+    from . import generation, parallel_state as mpu
+    cp = mpu.get_context_parallel_world_size()
+    kw = dict(media)
+    if cp > 1 and per_rank_loading:
+        pad_length = tokens_to_generate if tokens_to_generate > 0 else max(kw.get("max_generate_length", 128) - len(prompt_ids), 0)
+        kw.update(cp_size=cp, cp_rank=mpu.get_context_parallel_rank())
+        if use_kv_cache:                  # the cached path prefills the prompt alone, padded to the kernels' chunk granularity
+            kw["cp_seq_length"] = lambda expanded: generation._cp_prefill_length(expanded - pad_length, cp)
+    tokens, lengths, ext = request_tensors(prompt_ids, tokens_to_generate, tokenizer, image_processor, **kw)
+    if termination_id is None:
+        termination_id = getattr(tokenizer, "eos_token_id", None)
+    yield from generation.generate_tokens_probs_and_return_on_first_stage(
+        model, tokens, lengths, return_output_log_probs=return_output_log_probs, do_sample=do_sample, top_k=top_k, top_p=top_p,
+        temperature=temperature, external_inputs=ext, use_kv_cache=use_kv_cache, logit_mask=logit_mask,
+        termination_id=termination_id, reference_compat=reference_compat)

@@ -719,6 +719,69 @@ def test_per_rank_frame_loading_equals_reference_selection(cp):
         get_external_inputs(torch.tensor([row]), image_list, None, None, Tok(), Proc(), cp_size=cp, cp_rank=cp, **kw)
 
 
+def test_request_to_token_stream_chain_on_the_host():
+    """inference_module.generate: prompt ids -> padded buffer (tokenization.py:150-166) -> tag expansion on the padded row ->
+    true context length = expanded length - padding (module.py:357) -> decode loop.  With a position-revealing fake model
+    the generated tokens are the true continuation of the EXPANDED prompt, and generation starts right behind it; the
+    cached-path chunk length reaches the per-rank loader as a function of the expanded length."""
+    import types as _t
+
+    from long_vita_amd import generation, inference_module as im
+    V = 900100
+    table = {im.IMG_TAG_TOKEN: 900001, im.VID_TAG_TOKEN: 900002, im.IMG_CONTEXT_TOKEN: 900003, im.IMG_START_TOKEN: 900004,
+             im.IMG_END_TOKEN: 900005, im.VID_CONTEXT_TOKEN: 900006, im.VID_START_TOKEN: 900007, im.VID_END_TOKEN: 900008,
+             im.PATCH_CONTEXT_TOKEN: 900009, im.PATCH_START_TOKEN: 900010, im.PATCH_END_TOKEN: 900011, "\n": 198}
+
+    class Tok:
+        pad_token_id, eos_token_id = 0, 77
+
+        def __call__(self, text, add_special_tokens=False):
+            return _t.SimpleNamespace(input_ids=[table[text]])
+
+    class Proc:
+        patch_size, image_size = 448, 2
+        seen = []
+
+        def process_images(self, lst):
+            Proc.seen.append(len(lst))
+            return torch.zeros(len(lst), 3, 2, 2)
+
+    nxt = lambda tok, pos: (tok * 7 + pos * 3 + 1) % 1000
+
+    def model(tokens, position_ids, attention_mask, inference_params=None):
+        sel = inference_params.logit_mask[0].nonzero().flatten()
+        return torch.nn.functional.one_hot(nxt(tokens[0, sel], position_ids[0, sel]), 1000).float()[None]
+
+    L, frames, gen_n = 4, 5, 9
+    prompt = [11, 12, table[im.VID_TAG_TOKEN], 13, 14, 15]
+    video = [torch.zeros(1, 1, 3) for _ in range(frames)]
+    kw = dict(video_frames_list=[video], image_token_length=L, max_num_frame=16, device="cpu")
+    tokens, lengths, ext = im.request_tensors(prompt, gen_n, Tok(), Proc(), **kw)
+    expanded = len(prompt) - 1 + frames * (L + 2)
+    assert int(lengths[0]) == expanded and tokens.shape[1] % 64 == 0 and tokens.shape[1] >= expanded + gen_n
+    assert ext["indices"].shape == (2, frames, L)
+    # the generation room is pad_token_id; the 64-padding behind it is eos because pad_token_id is falsy (module.py:684)
+    assert tokens[0, expanded:expanded + gen_n].eq(0).all() and tokens[0, expanded + gen_n:].eq(77).all()
+    out = list(im.generate(model, prompt, gen_n, Tok(), Proc(), use_kv_cache=False, termination_id=-1, **kw))
+    final = out[-1][0][0]
+    assert final.shape[0] == tokens.shape[1]                                  # runs to the end of the buffer without an eos
+    assert torch.equal(final[:expanded], tokens[0, :expanded])
+    for ctx in range(expanded, final.shape[0]):
+        assert int(final[ctx]) == int(nxt(final[ctx - 1], torch.tensor(ctx - 1)))
+    # text only: no padding to 64, no external inputs (module.py:321-334)
+    t2, l2, e2 = im.request_tensors([5, 6, 7], 4, Tok(), None, device="cpu")
+    assert t2.tolist() == [[5, 6, 7, 0, 0, 0, 0]] and l2.tolist() == [3] and e2 is None
+    t3, _, _ = im.request_tensors([5, 6, 7], 0, Tok(), None, max_generate_length=10, device="cpu")
+    assert t3.shape == (1, 10)
+    # per-rank loading on the cached path: the chunk length is a function of the expanded prompt, not of the buffer
+    cp = 2
+    want_S = generation._cp_prefill_length(expanded, cp)
+    seen = []
+    im.request_tensors(prompt, gen_n, Tok(), Proc(), cp_size=cp, cp_rank=1,
+                       cp_seq_length=lambda n: seen.append(n) or generation._cp_prefill_length(n - gen_n, cp), **kw)
+    assert seen == [expanded + gen_n] and want_S == 1024
+
+
 def test_c_abi_compiles_and_validates_from_plain_c(tmp_path):
     """include/vita_hip.h is C (gcc -std=c11 -Wall -Werror), the library resolves from C, argument validation answers without
     a GPU, and the ctypes struct mirrors have the sizes the C compiler gives the structs."""
