@@ -11,6 +11,11 @@ force_patch=False, create_dummy=False)` / `apply_patches()`):
     made before patching are redirected too;
   * create_dummy=True fabricates missing modules / attributes so that optional dependencies can be
     patched in before they exist.
+
+One deliberate difference: the identity scan reads each module's `__dict__` instead of calling `hasattr` on it.  The
+reference's `hasattr` (:65-70) makes lazy modules (transformers' `_LazyModule`) import optional dependencies and raises
+`ModuleNotFoundError` out of `apply_patches` when one is absent; for real module attributes the two agree
+(tests/golden/patch_manager.pt, made in a fresh interpreter for that reason).
 """
 from __future__ import annotations
 

@@ -900,13 +900,21 @@ def patch_scenario(manager, Patch, tag: str):
     return out
 
 
-def golden_patch_manager():
-    """M/patch_utils.py (stdlib only) loaded from its file and driven through patch_scenario."""
+def _patch_manager_inproc():
     import importlib.util
     spec = importlib.util.spec_from_file_location("vita_ref_patch_utils", os.path.join(REF, "long_vita_megatron", "patch_utils.py"))
     ref = importlib.util.module_from_spec(spec)
     spec.loader.exec_module(ref)
     torch.save(dict(outcomes=patch_scenario(ref.MindSpeedPatchesManager, ref.Patch, "vitaref")), os.path.join(OUT, "patch_manager.pt"))
+
+
+def golden_patch_manager():
+    """M/patch_utils.py (stdlib only) loaded from its file and driven through patch_scenario — in a fresh interpreter: the
+    reference probes EVERY imported module with hasattr (:65-70), and on transformers' lazy modules that probe imports
+    optional dependencies (torchvision ...) and raises, which is a property of the surrounding process, not of the manager."""
+    import subprocess
+    subprocess.run([sys.executable, "-m", "oracle.make_golden", "_patch_manager_inproc"], check=True,
+                   cwd=os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 
 
 def golden_adaptor_targets():
@@ -1088,6 +1096,8 @@ def main():
     os.makedirs(OUT, exist_ok=True)
     _install_stubs()
     only = set(sys.argv[1:])                              # python -m oracle.make_golden [fixture ...]
+    if only == {"_patch_manager_inproc"}:
+        return _patch_manager_inproc()
     for name, fn in [("cp_slice", golden_cp_slice), ("rope_rmsnorm", golden_rope_rmsnorm),
                      ("embedding_scatter", golden_embedding_scatter), ("masked_linear", golden_masked_linear),
                      ("hf_vit", golden_hf_vit), ("image_processor", golden_image_processor),
