@@ -46,8 +46,8 @@ def process_images(frames, image_size=448, normalize_type="imagenet") -> torch.T
 
 
 def to_model_dtype(images: torch.Tensor) -> torch.Tensor:
-    """M/tasks/inference/module.py:693"""
-    return torch.tensor(images, dtype=torch.bfloat16)
+    """M/tasks/inference/module.py:693 (`torch.tensor(images, dtype=torch.bfloat16)`: a copy with the RNE cast)"""
+    return images.detach().clone().to(torch.bfloat16) if isinstance(images, torch.Tensor) else torch.tensor(images, dtype=torch.bfloat16)
 
 
 def dynamic_preprocess(frame: np.ndarray, min_num=1, max_num=12, image_size=448, use_thumbnail=True):

@@ -63,6 +63,31 @@ def test_host_coefficient_table_reproduces_pillow(H, W, S):
     assert np.array_equal(res, opre.resize_u8(img, S, IMAGENET_DEFAULT_MEAN))
 
 
+def test_host_coefficient_table_random_sizes_vs_pillow():
+    """60 random (input size, output size) pairs from 1 px to 4K, up- and down-scaling: one horizontal pass with the host
+    table (bounds, 22-bit taps) equals Pillow's BICUBIC resize of a random row bit for bit — so the tap table, the only
+    host arithmetic of vita_frames_resize_norm, is Pillow's for every geometry, not only the tested frame sizes."""
+    from PIL import Image
+
+    from long_vita_amd.image_processor import pil_resample_table
+    rng = np.random.default_rng(2024)
+    sizes = [(1, 1), (1, 7), (7, 1), (2, 448), (448, 448), (4096, 448), (3, 2), (449, 448), (447, 448)]
+    while len(sizes) < 60:
+        a = int(rng.choice([rng.integers(1, 64), rng.integers(64, 1200), rng.integers(1200, 4097)]))
+        b = int(rng.choice([rng.integers(1, 64), rng.integers(64, 1200)]))
+        sizes.append((a, b))
+    for n_in, n_out in sizes:
+        row = rng.integers(0, 256, (3, n_in, 3), dtype=np.uint8)               # 3 image rows, so only the width is resized
+        want = np.asarray(Image.fromarray(row).resize((n_out, 3), Image.BICUBIC))
+        b, c, k = pil_resample_table(n_in, n_out)
+        got = np.empty((3, n_out, 3), np.uint8)
+        for xx in range(n_out):
+            x0, n = b[xx]
+            acc = (1 << 21) + (row[:, x0: x0 + n].astype(np.int64) * c[xx, :n, None]).sum(1)
+            got[:, xx] = np.clip(acc >> 22, 0, 255)
+        assert np.array_equal(got, want), (n_in, n_out)
+
+
 # ---------------------------------------------------------------------------------------------
 @pytest.fixture(scope="module")
 def proc_mod():
