@@ -1,0 +1,123 @@
+// Probe (gfx950): the flash-attention forward main loop as a ladder.  One workgroup of 8 waves per CU (two per SIMD, the
+// kernel's geometry: 256 query rows, 64-key tiles, d = 128).  Per key tile every wave issues 32 MFMAs (16 for K Q^T, 16 for
+// P V) and, switched on one at a time,
+//   VALU  the softmax mix behind the MFMAs (per MFMA: v_fma, v_exp, v_add, v_add and alternately v_cvt_pk / v_max3 = 160 per tile)
+//   KR    16 ds_read_b128       K fragments   (16 KiB per wave and tile)
+//   VR    32 ds_read_b64_tr_b16 V^T fragments (16 KiB per wave and tile)
+//   DMA   4 LDS-DMA pieces per wave (32 KiB of K/V per tile and CU, from an L2-resident window), vmcnt(0) before the barrier
+//   BAR   one s_barrier per tile
+// and reports the MFMA rate as PFLOP/s over 256 CUs (sustained, >= 5 ms).  The real kernel measures 1.08 PFLOP/s.
+//   hipcc --offload-arch=gfx950 -O3 attn_ladder.hip -o attn_ladder && ./attn_ladder
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+typedef __attribute__((__vector_size__(8 * sizeof(__bf16)))) __bf16 bf16x8;
+typedef __attribute__((__vector_size__(4 * sizeof(__bf16)))) __bf16 bf16x4;
+typedef __attribute__((__vector_size__(16 * sizeof(float)))) float f32x16;
+typedef __attribute__((address_space(3))) const bf16x8 lds_bf16x8;
+typedef __attribute__((address_space(3))) void lds_void;
+typedef __attribute__((address_space(1))) const void gbl_cvoid;
+
+template <int VALU, int KR, int VR, int DMA, int BAR>
+__global__ __launch_bounds__(512, 2) void probe(const char* __restrict__ win, float* sink, int tiles) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
+  const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+  for (int i = threadIdx.x; i < 16384; i += blockDim.x) ((float*)smem)[i] = 1e-4f * i;     // two 32 KiB K/V stages
+  __syncthreads();
+  f32x16 acc[6];
+  for (int i = 0; i < 6; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  bf16x8 q[8], kf[4];
+  for (int i = 0; i < 8; ++i) for (int j = 0; j < 8; ++j) q[i][j] = (__bf16)(1e-3f * (lane + i));
+  for (int i = 0; i < 4; ++i) kf[i] = q[i];
+  bf16x8 vf[4];
+  for (int i = 0; i < 4; ++i) vf[i] = q[i + 4];
+  float v[8];
+  for (int k = 0; k < 8; ++k) v[k] = lane * 1e-3f + k;
+  const float c1 = 1.0001f + lane * 1e-9f, c2 = 0.5f;
+  // the kernel's own LDS layouts (attn.hip: k_lds_off / v_lds_off for d = 128): a slot = [64 keys][256 B] K | the same for V
+  const int l31 = lane & 31, hi = lane >> 5, g16 = lane >> 4, i16 = lane & 15;
+  unsigned koff[8], voff[4];
+  for (int ds = 0; ds < 8; ++ds) koff[ds] = l31 * 256 + (((2 * ds + hi) ^ (l31 & 15)) << 4);
+  for (int db = 0; db < 4; ++db) {
+    const int key_l = 4 * (g16 >> 1) + (i16 >> 2), col = 32 * db + 16 * (g16 & 1) + 4 * (i16 & 3);
+    voff[db] = 16384 + key_l * 256 + ((((col >> 4)) ^ ((key_l & 3) << 1)) << 5) + (col & 15) * 2;
+  }
+  const char* gp = win + (size_t)blockIdx.x * 65536 + wave * 4096 + lane * 16;      // 4 x 1 KiB pieces per wave and tile
+  for (int t = 0; t < tiles; ++t) {
+    const unsigned st = (t & 1) * 32768;
+#pragma unroll
+    for (int u = 0; u < 32; ++u) {
+      if (u < 16) acc[u & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[u & 3], q[u & 7], acc[u & 1], 0, 0, 0);         // S^T
+      else acc[2 + (u & 3)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[u & 3], q[(u + 3) & 7], acc[2 + (u & 3)], 0, 0, 0);  // O^T
+      if (VALU) {
+        asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[u & 7]) : "v"(c1), "v"(c2));
+        asm volatile("v_exp_f32 %0, %0" : "+v"(v[(u + 3) & 7]));
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[(u + 5) & 7]) : "v"(c2));
+        if (u & 1) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(v[(u + 6) & 7]) : "v"(c2));
+        else asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(v[(u + 6) & 7]) : "v"(c1), "v"(c2));
+        asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[(u + 1) & 7]) : "v"(c1));
+      }
+      // every fragment is read three MFMAs ahead of the one MFMA that uses it (rings of four registers)
+      if (KR && (u + 3 < 16 || u >= 29)) {
+        const int f = (u + 3) & 31;                                         // K fragment f: key block f & 1, k-step f >> 1
+        const unsigned slot = u >= 29 ? (st ^ 32768) : st;                  // the first three of the NEXT tile
+        kf[f & 3] = *(lds_bf16x8*)(uintptr_t)(lds0 + slot + koff[f >> 1] + (f & 1) * 32 * 256);
+      }
+      if (VR && u >= 13 && u < 29) {                                        // V^T fragment g: two 8-byte transposed reads
+        typedef __attribute__((ext_vector_type(4))) short s16x4;
+        typedef __attribute__((ext_vector_type(8))) short s16x8;
+        typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+        const int g = u + 3 - 16;
+        const unsigned vp = lds0 + st + voff[g & 3] + 16 * (g >> 2) * 256;
+        const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(vp));
+        const s16x4 hi4 = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(vp + 8 * 256));
+        vf[(u + 3) & 3] = __builtin_bit_cast(bf16x8, __builtin_shufflevector(lo, hi4, 0, 1, 2, 3, 4, 5, 6, 7));
+      }
+      if (DMA && (u & 7) == 7)                                              // the other slot: this wave's piece u >> 3
+        __builtin_amdgcn_global_load_lds((gbl_cvoid*)(gp + (u >> 3) * 1024), (lds_void*)(uintptr_t)(lds0 + (st ^ 32768) + wave * 4096 + (u >> 3) * 1024), 16, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (DMA) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (BAR) __builtin_amdgcn_s_barrier();
+  }
+  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  float r = 0.f;
+  for (int i = 0; i < 6; ++i) r += acc[i][0];
+  for (int k = 0; k < 8; ++k) r += v[k];
+  if (r == 123.456f) sink[threadIdx.x] = r;
+}
+
+template <int VALU, int KR, int VR, int DMA, int BAR>
+void run(const char* what, const char* win, float* sink) {
+  auto k = probe<VALU, KR, VR, DMA, BAR>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  const int tiles = 6000;                                             // 6000 x 2048 MFMA cycles per SIMD: >= 5 ms
+  float best = 1e30f, ms = 0;
+  for (int rep = 0; rep < 3; ++rep) {
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(k, dim3(256), dim3(512), 72 * 1024, 0, win, sink, tiles);
+    (void)hipEventRecord(e1);
+    (void)hipDeviceSynchronize();
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    best = ms < best ? ms : best;
+  }
+  const double flop = 256.0 * 8 * (double)tiles * 32 * 2.0 * 32 * 32 * 16;
+  printf("%-64s %8.3f ms  %6.3f PFLOP/s\n", what, best, flop / (best * 1e-3) / 1e15);
+}
+
+int main() {
+  char* win; float* sink;
+  (void)hipMalloc(&win, 256 * 65536 + 65536); (void)hipMemset(win, 1, 256 * 65536 + 65536);
+  (void)hipMalloc(&sink, 4096);
+  run<0, 0, 0, 0, 0>("MFMA only (8 waves)", win, sink);
+  run<1, 0, 0, 0, 0>("+ softmax VALU mix", win, sink);
+  run<1, 1, 0, 0, 0>("+ K fragment reads", win, sink);
+  run<1, 1, 1, 0, 0>("+ V^T fragment reads (ds_read_b64_tr_b16)", win, sink);
+  run<1, 1, 1, 1, 0>("+ LDS-DMA of the next K/V tile", win, sink);
+  run<1, 1, 1, 1, 1>("+ one barrier per tile  (the kernel's structure)", win, sink);
+  run<0, 1, 1, 1, 1>("same without the softmax VALU", win, sink);
+  run<1, 0, 0, 1, 1>("same without fragment reads", win, sink);
+  return 0;
+}

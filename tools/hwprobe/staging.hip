@@ -21,16 +21,16 @@ typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
 
 template <int WAVES, int SLOTS, int R, int W, int G, int D, int CHAIN, int M16>
-__global__ __launch_bounds__(WAVES * 64, 1) void probe(const char* __restrict__ win, float* sink, int iters) {
+__global__ __launch_bounds__(WAVES * 64, WAVES / 4) void probe(const char* __restrict__ win, float* sink, int iters) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (int i = threadIdx.x; i < 32768; i += blockDim.x) ((float*)smem)[i] = 1e-4f * i;
   __syncthreads();
-  f32x16 acc[8];
-  f32x4 acc16[16];
-  for (int i = 0; i < 8; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
-  for (int i = 0; i < 16; ++i) for (int j = 0; j < 4; ++j) acc16[i][j] = 0.f;
+  f32x16 acc[4];                          // 4 independent accumulation chains (a chain is revisited every 128 cycles)
+  f32x4 acc16[8];
+  for (int i = 0; i < 4; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) acc16[i][j] = 0.f;
   bf16x8 fr[16];                          // a fragment is read 9 MFMAs before its first use (the GEMMs read one k-step ahead)
   for (int i = 0; i < 16; ++i) for (int j = 0; j < 8; ++j) fr[i][j] = (__bf16)(1e-3f * (lane + i));
   u32x4 g[16];
@@ -43,10 +43,10 @@ __global__ __launch_bounds__(WAVES * 64, 1) void probe(const char* __restrict__ 
 #pragma unroll
     for (int s = 0; s < SLOTS; ++s) {
       if (M16) {
-        acc16[(2 * s) & 15] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[s & 15], fr[(s + 3) & 15], acc16[(2 * s) & 15], 0, 0, 0);
-        acc16[(2 * s + 1) & 15] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[s & 15], fr[(s + 3) & 15], acc16[(2 * s + 1) & 15], 0, 0, 0);
+        acc16[(2 * s) & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[s & 15], fr[(s + 3) & 15], acc16[(2 * s) & 7], 0, 0, 0);
+        acc16[(2 * s + 1) & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fr[s & 15], fr[(s + 3) & 15], acc16[(2 * s + 1) & 7], 0, 0, 0);
       } else {
-        acc[s & 7] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s & 15], fr[(s + 3) & 15], acc[s & 7], 0, 0, 0);
+        acc[s & 3] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[s & 15], fr[(s + 3) & 15], acc[s & 3], 0, 0, 0);
       }
       if (R && (s * R) / SLOTS != ((s + 1) * R) / SLOTS)             // R of the SLOTS slots, evenly
         fr[(s + 12) & 15] = *(lds_bf16x8*)(uintptr_t)(rd + (((s * R) / SLOTS) & 3) * 4096);
@@ -71,8 +71,9 @@ __global__ __launch_bounds__(WAVES * 64, 1) void probe(const char* __restrict__ 
   }
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   float r = 0.f;
-  for (int i = 0; i < 8; ++i) r += acc[i][0];
-  for (int i = 0; i < 16; ++i) r += acc16[i][0] + (float)g[i][0];
+  for (int i = 0; i < 4; ++i) r += acc[i][0];
+  for (int i = 0; i < 8; ++i) r += acc16[i][0];
+  for (int i = 0; i < 16; ++i) r += (float)g[i][0];
   if (r == 123.456f) sink[threadIdx.x] = r;
 }
 
