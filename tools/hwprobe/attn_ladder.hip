@@ -18,15 +18,19 @@ typedef __attribute__((address_space(3))) const bf16x8 lds_bf16x8;
 typedef __attribute__((address_space(3))) void lds_void;
 typedef __attribute__((address_space(1))) const void gbl_cvoid;
 
-template <int VALU, int KR, int VR, int DMA, int BAR>
+// REP = 2: 64 query rows per wave (every fragment feeds two MFMAs, twice the softmax work per tile); M16 = 1: pairs of 16x16x32
+template <int VALU, int KR, int VR, int DMA, int BAR, int REP = 1, int M16 = 0>
 __global__ __launch_bounds__(512, 2) void probe(const char* __restrict__ win, float* sink, int tiles) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(uintptr_t)(__attribute__((address_space(3))) char*)smem;
   const int lane = threadIdx.x & 63, wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
   for (int i = threadIdx.x; i < 16384; i += blockDim.x) ((float*)smem)[i] = 1e-4f * i;     // two 32 KiB K/V stages
   __syncthreads();
+  typedef __attribute__((__vector_size__(4 * sizeof(float)))) float f32x4;
   f32x16 acc[6];
+  f32x4 acc16[8];
   for (int i = 0; i < 6; ++i) for (int j = 0; j < 16; ++j) acc[i][j] = 0.f;
+  for (int i = 0; i < 8; ++i) for (int j = 0; j < 4; ++j) acc16[i][j] = 0.f;
   bf16x8 q[8], kf[4];
   for (int i = 0; i < 8; ++i) for (int j = 0; j < 8; ++j) q[i][j] = (__bf16)(1e-3f * (lane + i));
   for (int i = 0; i < 4; ++i) kf[i] = q[i];
@@ -48,15 +52,24 @@ __global__ __launch_bounds__(512, 2) void probe(const char* __restrict__ win, fl
     const unsigned st = (t & 1) * 32768;
 #pragma unroll
     for (int u = 0; u < 32; ++u) {
-      if (u < 16) acc[u & 1] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kf[u & 3], q[u & 7], acc[u & 1], 0, 0, 0);         // S^T
-      else acc[2 + (u & 3)] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(vf[u & 3], q[(u + 3) & 7], acc[2 + (u & 3)], 0, 0, 0);  // O^T
-      if (VALU) {
-        asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[u & 7]) : "v"(c1), "v"(c2));
-        asm volatile("v_exp_f32 %0, %0" : "+v"(v[(u + 3) & 7]));
-        asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[(u + 5) & 7]) : "v"(c2));
-        if (u & 1) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(v[(u + 6) & 7]) : "v"(c2));
-        else asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(v[(u + 6) & 7]) : "v"(c1), "v"(c2));
-        asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[(u + 1) & 7]) : "v"(c1));
+#pragma unroll
+      for (int rep = 0; rep < REP; ++rep) {
+        const bf16x8 fa_ = u < 16 ? kf[u & 3] : vf[u & 3], fb_ = q[(u + 3 * rep) & 7];
+        if (M16) {
+          acc16[(2 * u + rep) & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_, fb_, acc16[(2 * u + rep) & 7], 0, 0, 0);
+          acc16[(2 * u + rep + 4) & 7] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa_, fb_, acc16[(2 * u + rep + 4) & 7], 0, 0, 0);
+        } else {
+          const int a = u < 16 ? ((u + rep) & 1) : 2 + ((u + rep) & 3);
+          acc[a] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa_, fb_, acc[a], 0, 0, 0);
+        }
+        if (VALU) {
+          asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[u & 7]) : "v"(c1), "v"(c2));
+          asm volatile("v_exp_f32 %0, %0" : "+v"(v[(u + 3) & 7]));
+          asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[(u + 5) & 7]) : "v"(c2));
+          if (u & 1) asm volatile("v_cvt_pk_bf16_f32 %0, %0, %1" : "+v"(v[(u + 6) & 7]) : "v"(c2));
+          else asm volatile("v_max3_f32 %0, %0, %1, %2" : "+v"(v[(u + 6) & 7]) : "v"(c1), "v"(c2));
+          asm volatile("v_add_f32 %0, %0, %1" : "+v"(v[(u + 1) & 7]) : "v"(c1));
+        }
       }
       // every fragment is read three MFMAs ahead of the one MFMA that uses it (rings of four registers)
       if (KR && (u + 3 < 16 || u >= 29)) {
@@ -84,16 +97,17 @@ __global__ __launch_bounds__(512, 2) void probe(const char* __restrict__ win, fl
   asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
   float r = 0.f;
   for (int i = 0; i < 6; ++i) r += acc[i][0];
+  for (int i = 0; i < 8; ++i) r += acc16[i][0];
   for (int k = 0; k < 8; ++k) r += v[k];
   if (r == 123.456f) sink[threadIdx.x] = r;
 }
 
-template <int VALU, int KR, int VR, int DMA, int BAR>
+template <int VALU, int KR, int VR, int DMA, int BAR, int REP = 1, int M16 = 0>
 void run(const char* what, const char* win, float* sink) {
-  auto k = probe<VALU, KR, VR, DMA, BAR>;
+  auto k = probe<VALU, KR, VR, DMA, BAR, REP, M16>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(k), hipFuncAttributeMaxDynamicSharedMemorySize, 72 * 1024);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
-  const int tiles = 6000;                                             // 6000 x 2048 MFMA cycles per SIMD: >= 5 ms
+  const int tiles = 6000 / REP;                                       // 6000 x 2048 MFMA cycles per SIMD: >= 5 ms
   float best = 1e30f, ms = 0;
   for (int rep = 0; rep < 3; ++rep) {
     (void)hipEventRecord(e0);
@@ -103,7 +117,7 @@ void run(const char* what, const char* win, float* sink) {
     (void)hipEventElapsedTime(&ms, e0, e1);
     best = ms < best ? ms : best;
   }
-  const double flop = 256.0 * 8 * (double)tiles * 32 * 2.0 * 32 * 32 * 16;
+  const double flop = 256.0 * 8 * (double)tiles * 32 * REP * 2.0 * 32 * 32 * 16;
   printf("%-64s %8.3f ms  %6.3f PFLOP/s\n", what, best, flop / (best * 1e-3) / 1e15);
 }
 
@@ -119,5 +133,10 @@ int main() {
   run<1, 1, 1, 1, 1>("+ one barrier per tile  (the kernel's structure)", win, sink);
   run<0, 1, 1, 1, 1>("same without the softmax VALU", win, sink);
   run<1, 0, 0, 1, 1>("same without fragment reads", win, sink);
+  // not yet run (added after the first measurement): the two levers
+  run<0, 0, 0, 0, 0, 1, 1>("MFMA only, 16x16x32 pairs", win, sink);
+  run<1, 1, 1, 1, 1, 1, 1>("the kernel's structure with 16x16x32 pairs", win, sink);
+  run<1, 1, 1, 1, 1, 2, 0>("64 query rows per wave (each fragment feeds two MFMAs)", win, sink);
+  run<1, 1, 1, 1, 1, 2, 1>("64 rows per wave and 16x16x32 pairs", win, sink);
   return 0;
 }
