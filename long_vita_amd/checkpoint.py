@@ -97,11 +97,22 @@ _COLUMN = ("linear_qkv.weight", "linear_qkv.bias", "linear_fc1.weight", "linear_
 _ROW = ("linear_proj.weight", "linear_fc2.weight")
 
 
-def merge_tp_shards(shards: List[Dict[str, torch.Tensor]], swiglu_fc1: bool = True,
-                    vision_prefix: str = "vision_model") -> Dict[str, torch.Tensor]:
+_VISION_MARKS = ("external_feature_model.", "vision_model", "vision_projection.")
+
+
+def _is_vision_key(name: str) -> bool:
+    """Keys of the ViT / projector inside a combined checkpoint (`external_feature_model.vit.*`,
+    `external_feature_model.vision_projection.*`: M/pretrain_long_vita.py:381,436) or after M/ckpt_split_llm_and_vit.py
+    stripped that prefix (`vit.*`, `vision_projection.*`).  Their MLPs are GELU: linear_fc1 is NOT a [gate; up] pair."""
+    return name.startswith("vit.") or any(m in name for m in _VISION_MARKS)
+
+
+def merge_tp_shards(shards: List[Dict[str, torch.Tensor]], swiglu_fc1: bool = True) -> Dict[str, torch.Tensor]:
     """Inverse of Megatron's tensor-parallel partitioning: column-parallel tensors (and the vocab-parallel embedding /
     output layer) are concatenated on dim 0, row-parallel weights on dim 1, everything else is replicated.  A SwiGLU
-    linear_fc1 shard is [gate_shard; up_shard], so its halves are merged separately (the ViT's GELU fc1 is plain)."""
+    linear_fc1 shard is [gate_shard; up_shard], so its halves are merged separately — decided per key: only the
+    decoder's (LLM) linear_fc1 is gated; the ViT's and the projector's fc1 (GELU) are plain column-parallel, whatever
+    prefix they carry.  swiglu_fc1=False: no key is gated (the stand-alone ViT checkpoint, whose layers are un-prefixed)."""
     if len(shards) == 1:
         return dict(shards[0])
     out = {}
@@ -110,7 +121,7 @@ def merge_tp_shards(shards: List[Dict[str, torch.Tensor]], swiglu_fc1: bool = Tr
             continue
         parts = [s[name] for s in shards]
         if any(name.endswith(sfx) for sfx in _COLUMN):
-            if swiglu_fc1 and name.endswith("linear_fc1.weight") and vision_prefix not in name:
+            if swiglu_fc1 and name.endswith("linear_fc1.weight") and not _is_vision_key(name):
                 halves = [p.chunk(2, dim=0) for p in parts]
                 out[name] = torch.cat([h[0] for h in halves] + [h[1] for h in halves], dim=0)
             else:
@@ -229,6 +240,6 @@ def load_mcore_checkpoint(path: str, iteration: Optional[int] = None, swiglu_fc1
         raise FileNotFoundError(f"no mp_rank_XX directories under {os.path.join(path, it_dir)}")
     shards = [torch.load(os.path.join(path, it_dir, r, "model_optim_rng.pt"), map_location="cpu", weights_only=False)["model"]
               for r in ranks]
-    if swiglu_fc1 is None:
+    if swiglu_fc1 is None:      # stand-alone ViT checkpoint: top-level conv1.weight, every un-prefixed layer is a ViT layer
         swiglu_fc1 = "conv1.weight" not in shards[0]
     return merge_tp_shards(shards, swiglu_fc1=swiglu_fc1)

@@ -204,7 +204,13 @@ class TrainStep:
         # ---- forward -------------------------------------------------------------------------------
         proj = None
         efd = None
-        if external_inputs:
+        # A CP rank whose two zig-zag chunks hold text only gets no src / tgt indices from get_batch_on_this_cp_rank
+        # (M/training/utils.py:295,310-311).  The reference then runs the ViT over ALL frames and takes the
+        # `features.mean() * 0` branch (language_model_embedding.py:132-134): nothing is scattered and the projector's
+        # gradient is exactly zero.  Here that rank skips the encoder and contributes zero projector gradients, so the
+        # collectives of the step (K/V gathers, reduce-scatters, allreduce_grads) stay consistent across ranks.
+        text_only_rank = bool(external_inputs) and cp > 1 and "external_src_indices" not in batch
+        if external_inputs and not text_only_rank:
             vis = m.external_feature_model
             images = batch["external_images"]
             vit_out = torch.cat([vis.vit(ch) for ch in torch.split(images, vis.cfg.chunk_frames, dim=0)], 0)
@@ -282,6 +288,11 @@ class TrainStep:
             d_feats = torch.zeros(feats.shape[0] * L, c.hidden, dtype=h.dtype, device=h.device)
             ops.row_scatter_(d_feats, src, ops.row_gather(dh, tgt))
             self._projector_backward(m.external_feature_model, proj, d_feats, grads)
+        elif text_only_rank:
+            vp = m.external_feature_model.p
+            grads["projector"] = {"proj_fc2": torch.zeros_like(vp["proj_fc2"]), "proj_fc1": torch.zeros_like(vp["proj_fc1"]),
+                                  "proj_ln_w": torch.zeros(vp["proj_ln_w"].numel(), dtype=torch.float32, device=h.device),
+                                  "proj_ln_b": torch.zeros(vp["proj_ln_b"].numel(), dtype=torch.float32, device=h.device)}
         ops.row_scatter_add_f32_(d_embed, tok_idx, dh)
         grads["embed"] = d_embed
         return loss, grads

@@ -90,6 +90,48 @@ def test_mcore_checkpoint_directory_roundtrip(tmp_path, tp):
     assert _tree_equal(ck.mcore_llm_to_params(merged, CFG), p)
 
 
+@pytest.mark.parametrize("form", ["combined", "split"])
+def test_tp2_merge_with_the_references_vision_prefixes(form):
+    """at TP = 2 the GELU fc1 of the ViT (`external_feature_model.vit.*`, M/pretrain_long_vita.py:381) and of
+    the projector (`external_feature_model.vision_projection.*`, :436) is plain column-parallel — only the decoder's fc1 is a
+    [gate; up] pair.  Combined checkpoint and the two halves M/ckpt_split_llm_and_vit.py writes (`vit.*`, `vision_projection.*`)."""
+    g = torch.Generator().manual_seed(5)
+    rn = lambda *s: torch.randn(*s, generator=g)                                       # noqa: E731
+    full = {"decoder.layers.0.mlp.linear_fc1.weight": rn(16, 4), "decoder.layers.0.mlp.linear_fc2.weight": rn(4, 8),
+            "external_feature_model.vit.conv1.weight": rn(6, 3, 2, 2),
+            "external_feature_model.vit.decoder.layers.0.mlp.linear_fc1.weight": rn(12, 6),
+            "external_feature_model.vit.decoder.layers.0.mlp.linear_fc1.bias": rn(12),
+            "external_feature_model.vit.decoder.layers.0.mlp.linear_fc2.weight": rn(6, 12),
+            "external_feature_model.vision_projection.encoder.linear_fc1.weight": rn(8, 24),
+            "external_feature_model.vision_projection.encoder.linear_fc2.weight": rn(4, 8)}
+
+    def split(sd):
+        shards = [dict(), dict()]
+        for name, t in sd.items():
+            for r in range(2):
+                if name.endswith("linear_fc1.weight") and name.startswith("decoder."):   # SwiGLU: gate / up split apart
+                    a, b = t.chunk(2, 0)
+                    shards[r][name] = torch.cat([a.chunk(2, 0)[r], b.chunk(2, 0)[r]])
+                elif name.endswith(("linear_fc1.weight", "linear_fc1.bias")):
+                    shards[r][name] = t.chunk(2, 0)[r].clone()
+                elif name.endswith("linear_fc2.weight"):
+                    shards[r][name] = t.chunk(2, 1)[r].clone()
+                else:
+                    shards[r][name] = t.clone()
+        return shards
+
+    if form == "combined":
+        merged = ck.merge_tp_shards(split(full))
+        assert set(merged) == set(full) and all(torch.equal(merged[k], full[k]) for k in full)
+    else:
+        llm, vit = ck.split_llm_and_vit(full)
+        assert all(k.startswith(("vit.", "vision_projection.")) for k in vit)
+        for part in (llm, vit):
+            shards = split(part)
+            merged = ck.merge_tp_shards(shards)
+            assert all(torch.equal(merged[k], part[k]) for k in part), form
+
+
 def test_hf_safetensors_sharded_directory(tmp_path):
     from safetensors.torch import save_file
     p = ollm.init_llm_params(CFG, seed=4, dtype=torch.bfloat16)

@@ -190,6 +190,63 @@ def test_train_step_with_projector(amd):
         assert rel_l2(g["projector"][k], g_ref[k]) < 6e-2, (k, rel_l2(g["projector"][k], g_ref[k]))
 
 
+def test_train_step_cp_with_a_text_only_rank(amd, monkeypatch):
+    """under CP a rank whose two zig-zag chunks hold no visual token gets no src / tgt indices
+    (M/training/utils.py:295,310-311).  The reference runs on (`features.mean() * 0`, language_model_embedding.py:132-134);
+    so must the step: rank 1 of CP = 2 owns chunks {1, 2} of a 2048-token row whose one frame sits in chunk 0."""
+    cp, S, cfgd = 2, 2048, SMALL
+    ocfg = ollm.LLMConfig(**cfgd)
+    p = ollm.init_llm_params(ocfg, seed=12)
+    vcfg = ovit.ViTConfig(num_layers=1, llm_hidden=cfgd["hidden"])
+    vp = ovit.init_vit_params(vcfg, seed=13)
+    tokens, ext = amd["syn"].make_request(S, 1, seed=5, device="cpu")          # context tokens at 1..256 < 512 = chunk 0
+    tokens = tokens % cfgd["vocab"]
+    gen = torch.Generator().manual_seed(2)
+    labels = torch.randint(0, cfgd["vocab"], (1, S), generator=gen)
+    loss_mask = torch.zeros(1, S)
+    loss_mask[0, S - 120:] = 1
+    loss_mask[0, 700:740] = 1                                                   # answer tokens on the text-only rank too
+    with torch.no_grad():
+        x = ovit.vit_embed(ext["images"], vp, vcfg)
+        for lp in vp["layers"]:
+            x = ovit.vit_layer(x, lp, vcfg)
+    proj_keys = ("proj_ln_w", "proj_ln_b", "proj_fc1", "proj_fc2")
+    pall = dict(p)
+    for k in proj_keys:
+        pall[k] = vp[k]
+
+    def feature_fn(pp):
+        q = dict(vp)
+        for k in proj_keys:
+            q[k] = pp[k]
+        return ovit.vit_project(x, q, vcfg)
+
+    loss_ref, g_ref = otrain.loss_and_grads(tokens, labels, loss_mask, pall, ocfg, cp_size=cp, feature_fn=feature_fn,
+                                            indices=ext["indices"])
+    V, G = amd["vision"], amd["gpt"]
+    vis = V.MegatronVisionModel.from_oracle_layout(V.VisionConfig(num_layers=1, llm_hidden=cfgd["hidden"]), vp, DEV)
+    base = G.GPTVLModel.from_oracle_layout(G.GPTConfig(**cfgd), p, vis, DEV)
+    ext_d = {"images": ext["images"].to(DEV), "indices": ext["indices"].to(DEV)}
+    seen = {}
+
+    def rank_fn(r):
+        m = G.GPTVLModel(base.cfg, base.p, vis)
+        batch = amd["train"].training_utils.get_batch_on_this_cp_rank(
+            {"tokens": tokens.to(DEV), "external_images": ext_d["images"], "external_indices": ext_d["indices"]}, seq_length=S)
+        seen[r] = "external_src_indices" in batch
+        loss, g = amd["train"].TrainStep(m).forward_backward(tokens.to(DEV), labels.to(DEV), loss_mask.to(DEV), dict(ext_d))
+        amd["train"].allreduce_grads(g)
+        return loss, g
+
+    outs = _run_ranks(cp, rank_fn, amd, monkeypatch)
+    assert seen == {0: True, 1: False}                                          # rank 1 really is text-only
+    assert float(outs[0][0]) == float(outs[1][0])
+    assert abs(float(outs[0][0]) - float(loss_ref)) < 2e-2 * abs(float(loss_ref))
+    _check_grads(outs[0][1], g_ref, 5e-2)
+    for k in proj_keys:
+        assert rel_l2(outs[1][1]["projector"][k], g_ref[k]) < 6e-2, k
+
+
 def test_train_step_packed_samples_vs_autograd(amd):
     """Stage-2 packing (--reset-position-ids): three samples in one 1024-token row.  RoPE restarts per sample and the
     attention is block-diagonal, forward and backward; the same model without the resets gives a
