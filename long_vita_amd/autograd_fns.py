@@ -1,0 +1,314 @@
+"""torch.autograd bridges over libvita_hip.so for the Megatron-constructible modules (layers.py,
+language_model_embedding.py, dot_product_attention.py, rotary_pos_embedding.py).
+
+Megatron gets its backward from autograd over its modules (`ctx.save_for_backward`,
+M/core/tensor_parallel/layers.py:382); a module that replaces one of them therefore has to be an autograd node.
+Every forward and backward below is a library kernel — the same calls the explicit sweep of training.TrainStep makes.
+"""
+from __future__ import annotations
+
+from typing import Optional
+
+import torch
+import torch.distributed as dist
+
+from . import ops, parallel_state as mpu
+
+
+# ------------------------------------------------------------------------------------------------
+# GEMM helpers shared with training.TrainStep (one NT GEMM serves forward, dgrad and wgrad)
+# ------------------------------------------------------------------------------------------------
+def transpose(x: torch.Tensor) -> torch.Tensor:
+    return ops.transpose(x)
+
+
+def pad_rows(x: torch.Tensor, mult: int = 64) -> torch.Tensor:
+    """Zero rows up to a multiple of `mult` (the contraction length of a wgrad GEMM is the row count)."""
+    m = x.shape[0]
+    if m % mult == 0:
+        return x
+    out = torch.zeros((m + mult - m % mult,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    out[:m] = x
+    return out
+
+
+def dgrad(dy: torch.Tensor, w: torch.Tensor, out=None, epilogue=ops.EPI_NONE, residual=None) -> torch.Tensor:
+    """grad_input = grad_output.matmul(weight)  (layers.py:444):  dy [M, N], w [N, K] -> [M, K]."""
+    return ops.gemm(dy, transpose(w), epilogue, residual=residual, out=out)
+
+
+def wgrad(dy_t: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """grad_weight = grad_output.t().matmul(total_input)  (layers.py:522-523): dy_t [N, M], x [M, K] -> [N, K]."""
+    return ops.gemm(dy_t, transpose(x))
+
+
+def bias_grad(dy_t: torch.Tensor) -> torch.Tensor:
+    """grad_bias = grad_output.sum(dim=0) (layers.py:524) as a GEMM against a block of ones: dy_t [N, M] -> [N]."""
+    ones = torch.ones(4, dy_t.shape[1], dtype=dy_t.dtype, device=dy_t.device)
+    return ops.gemm(dy_t, ones)[:, 0].contiguous()
+
+
+def _tp():
+    return mpu.get_tensor_model_parallel_world_size(), mpu.get_tensor_model_parallel_group()
+
+
+# ------------------------------------------------------------------------------------------------
+# LinearWithGradAccumulationAndAsyncCommunication (M/core/tensor_parallel/layers.py:366-534), logit_mask included
+# ------------------------------------------------------------------------------------------------
+class LinearFn(torch.autograd.Function):
+    """input [s, b, c] (sequence-parallel: the rank's s / TP rows), weight [n, c], bias [n] | None ->
+    output [s' , b, n] with s' = the logit-masked row count, else the (gathered) sequence length."""
+
+    @staticmethod
+    def forward(ctx, input, weight, bias, allreduce_dgrad, sequence_parallel, logit_mask):
+        ctx.save_for_backward(input, weight, logit_mask)
+        ctx.use_bias = bias is not None
+        ctx.allreduce_dgrad, ctx.sequence_parallel = allreduce_dgrad, sequence_parallel
+        total_input = _gather_sequence(input) if sequence_parallel else input                     # :392-400
+        s, b, c = total_input.shape
+        x = total_input.reshape(s * b, c)
+        if logit_mask is not None:                                                                 # :402-407
+            if b != 1:
+                raise AssertionError("logit_mask requires batch 1 (gpt_vl_model.py:329)")
+            x = ops.row_gather(x.contiguous(), ops.mask_to_index(logit_mask.transpose(0, 1).reshape(-1)))
+        m = x.shape[0]
+        if m <= 16 and bias is None:
+            out = ops.gemm_skinny(x, weight)
+        else:
+            out = ops.gemm(x, weight, ops.EPI_BIAS if bias is not None else ops.EPI_NONE, bias)   # :409-411
+        return out.view(m // b, b, -1)
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        input, weight, logit_mask = ctx.saved_tensors
+        tp, group = _tp()
+        total_input = _gather_sequence(input) if ctx.sequence_parallel else input                 # :435-452
+        s, b, c = total_input.shape
+        go = grad_output.reshape(-1, grad_output.shape[-1]).contiguous()
+        grad_input = dgrad(go, weight)                                                             # :453
+        x = total_input.reshape(s * b, c)
+        if logit_mask is not None:                                                                 # :455-466
+            idx = ops.mask_to_index(logit_mask.transpose(0, 1).reshape(-1))
+            full = torch.zeros(s * b, c, dtype=grad_input.dtype, device=grad_input.device)
+            grad_input = ops.row_scatter_(full, idx, grad_input)
+            x = ops.row_gather(x.contiguous(), idx)
+        grad_input = grad_input.view(s, b, c)
+        if ctx.allreduce_dgrad and tp > 1:                                                        # :475-481
+            dist.all_reduce(grad_input, group=group)
+        if ctx.sequence_parallel:                                                                 # :483-494
+            sub = torch.empty(input.shape, dtype=input.dtype, device=input.device)
+            dist.reduce_scatter_tensor(sub, grad_input.contiguous(), group=group)
+            grad_input = sub
+        grad_weight = grad_bias = None
+        if ctx.needs_input_grad[1] or ctx.use_bias:
+            go_t = transpose(pad_rows(go))
+            if ctx.needs_input_grad[1]:
+                grad_weight = wgrad(go_t, pad_rows(x.contiguous()))                               # :522-523
+            if ctx.use_bias:
+                grad_bias = bias_grad(go_t)                                                       # :524
+        return grad_input, grad_weight, grad_bias, None, None, None
+
+
+def _gather_sequence(x: torch.Tensor) -> torch.Tensor:
+    """[s / TP, b, c] -> [s, b, c] over the tensor-parallel group (layers.py:392-399: _all_gather_base along dim 0)."""
+    tp, group = _tp()
+    if tp == 1:
+        return x
+    out = torch.empty((x.shape[0] * tp,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+    dist.all_gather_into_tensor(out, x.contiguous(), group=group)
+    return out
+
+
+class ReduceFromTP(torch.autograd.Function):
+    """reduce_from_tensor_model_parallel_region: all-reduce forward, identity backward (RowParallelLinear.forward :1097)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        tp, group = _tp()
+        if tp > 1:
+            x = x.contiguous()
+            dist.all_reduce(x, group=group)
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        return g
+
+
+class ReduceScatterToSP(torch.autograd.Function):
+    """reduce_scatter_to_sequence_parallel_region: reduce-scatter along dim 0 forward, all-gather backward (:1095)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        tp, group = _tp()
+        if tp == 1:
+            return x
+        out = torch.empty((x.shape[0] // tp,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
+        dist.reduce_scatter_tensor(out, x.contiguous(), group=group)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        return _gather_sequence(g)
+
+
+class CopyToTP(torch.autograd.Function):
+    """copy_to_tensor_model_parallel_region: identity forward, all-reduce backward (ColumnParallelLinear.forward :872)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        return x
+
+    @staticmethod
+    def backward(ctx, g):
+        tp, group = _tp()
+        if tp > 1:
+            g = g.contiguous()
+            dist.all_reduce(g, group=group)
+        return g
+
+
+class GatherFromTP(torch.autograd.Function):
+    """gather_from_tensor_model_parallel_region: all-gather along the last dim forward, split backward (:896-899)."""
+
+    @staticmethod
+    def forward(ctx, x):
+        tp, group = _tp()
+        if tp == 1:
+            return x
+        flat = torch.empty((tp,) + tuple(x.shape), dtype=x.dtype, device=x.device)
+        dist.all_gather_into_tensor(flat.view(-1), x.contiguous().view(-1), group=group)
+        return flat.movedim(0, -2).reshape(*x.shape[:-1], tp * x.shape[-1])
+
+    @staticmethod
+    def backward(ctx, g):
+        tp, _ = _tp()
+        if tp == 1:
+            return g
+        r = mpu.get_tensor_model_parallel_rank()
+        n = g.shape[-1] // tp
+        return g[..., r * n:(r + 1) * n].contiguous()
+
+
+# ------------------------------------------------------------------------------------------------
+# norms
+# ------------------------------------------------------------------------------------------------
+class RMSNormFn(torch.autograd.Function):
+    """RMSNorm.forward (M/core/transformer/custom_layers/transformer_engine.py:74-79) + vita_rmsnorm_bwd."""
+
+    @staticmethod
+    def forward(ctx, x, weight, eps):
+        ctx.save_for_backward(x, weight)
+        ctx.eps = eps
+        return ops.rmsnorm(x, weight, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dw = torch.zeros(weight.numel(), dtype=torch.float32, device=x.device)
+        xc = x.contiguous()
+        dx = ops.rmsnorm_bwd(dy.contiguous(), xc, weight, ctx.eps, dw)
+        return dx.view_as(x), dw.to(weight.dtype), None
+
+
+# ------------------------------------------------------------------------------------------------
+# SwiGLU (bias-free gated linear unit of the decoder MLP: Megatron's MLP.forward glu closure)
+# ------------------------------------------------------------------------------------------------
+class SwiGLUFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, y):
+        ctx.save_for_backward(y)
+        two_f = y.shape[-1]
+        return ops.swiglu(y.reshape(-1, two_f).contiguous()).view(*y.shape[:-1], two_f // 2)
+
+    @staticmethod
+    def backward(ctx, da):
+        (y,) = ctx.saved_tensors
+        two_f = y.shape[-1]
+        return ops.swiglu_bwd(y.reshape(-1, two_f).contiguous(), da.reshape(-1, two_f // 2).contiguous()).view_as(y)
+
+
+# ------------------------------------------------------------------------------------------------
+# RoPE (apply_rotary_pos_emb_bshd, rotary_pos_embedding.py:181-204); the backward is the rotation by -theta
+# ------------------------------------------------------------------------------------------------
+class RopeFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, t, cos, sin):
+        ctx.save_for_backward(cos, sin)
+        out = t.contiguous().clone()
+        s, b, h, d = out.shape
+        ops.rope_apply_(out.view(s * b, h, d), cos, sin)
+        return out
+
+    @staticmethod
+    def backward(ctx, g):
+        cos, sin = ctx.saved_tensors
+        g = g.contiguous().clone()
+        s, b, h, d = g.shape
+        ops.rope_apply_(g.view(s * b, h, d), cos, sin, sign=-1)
+        return g, None, None
+
+
+# ------------------------------------------------------------------------------------------------
+# core attention (CP = 1; causal, d = 128: vita_flash_attn_fwd / vita_flash_attn_bwd)
+# ------------------------------------------------------------------------------------------------
+class FlashAttnFn(torch.autograd.Function):
+    """q [1, S, Hq, D], k / v [1, S, Hkv, D] -> [1, S, Hq, D]."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, softmax_scale):
+        o, lse = ops.flash_attn(q, k, v, causal=True, softmax_scale=softmax_scale, return_lse=True)
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.softmax_scale = softmax_scale
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        q, k, v, o, lse = ctx.saved_tensors
+        dq, dk, dv = ops.flash_attn_bwd(q, k, v, o, d_o.contiguous(), lse, softmax_scale=ctx.softmax_scale)
+        return dq, dk, dv, None
+
+
+# ------------------------------------------------------------------------------------------------
+# embedding lookup + visual-token scatter (language_model_embedding.py:102-142)
+# ------------------------------------------------------------------------------------------------
+class EmbeddingScatterFn(torch.autograd.Function):
+    """weight [V_local, h], ids [b * s] int64 (already made local; -1 = not on this rank), feats [N * L, h] | None,
+    tgt / src int64 index vectors | None  ->  [b * s, h].  Backward: fp32 scatter-add into the weight gradient for the
+    rows that kept their word embedding, a row gather for the features."""
+
+    @staticmethod
+    def forward(ctx, weight, ids, feats, tgt, src):
+        n, h = ids.numel(), weight.shape[1]
+        keep = ids >= 0
+        if bool(keep.all()):
+            we = ops.row_gather(weight, ids)
+        else:                                   # vocab-parallel: rows of other ranks stay zero, the caller all-reduces
+            we = torch.zeros(n, h, dtype=weight.dtype, device=weight.device)
+            sel = ops.mask_to_index(keep)
+            if sel.numel():
+                ops.row_scatter_(we, sel, ops.row_gather(weight, ids[sel].contiguous()))
+        if feats is not None and tgt is not None:
+            ops.row_scatter_(we, tgt, feats, src)
+        ctx.save_for_backward(ids, tgt, src)
+        ctx.wshape, ctx.wdtype = tuple(weight.shape), weight.dtype
+        ctx.fshape = None if feats is None else tuple(feats.shape)
+        return we
+
+    @staticmethod
+    def backward(ctx, g):
+        ids, tgt, src = ctx.saved_tensors
+        g = g.contiguous()
+        d_weight = d_feats = None
+        if ctx.needs_input_grad[0]:
+            tok = ids.clone()
+            if tgt is not None:
+                tok[tgt] = -1                                                      # overwritten rows: no embedding gradient
+            acc = torch.zeros(ctx.wshape, dtype=torch.float32, device=g.device)
+            ops.row_scatter_add_f32_(acc, tok, g)
+            d_weight = acc.to(ctx.wdtype)
+        if ctx.fshape is not None and ctx.needs_input_grad[2] and tgt is not None:
+            d_feats = torch.zeros(ctx.fshape, dtype=g.dtype, device=g.device)
+            rows = ops.row_gather(g, tgt)
+            ops.row_scatter_(d_feats, src if src is not None else torch.arange(tgt.numel(), device=g.device), rows)
+        return d_weight, None, d_feats, None, None

@@ -1,43 +1,306 @@
-"""ColumnParallelLinear with `logit_mask` — mirror of M/core/tensor_parallel/layers.py:825-904
-(forward) / :402-412 (masked select + GEMM) at TP=1."""
+"""Tensor-parallel linears and norms of the decoder layer as Megatron-constructible, HIP-backed `torch.nn.Module`s.
+
+Mirrors (constructor signatures, parameter names, `(output, bias)` returns, error behaviour):
+  ColumnParallelLinear            M/core/tensor_parallel/layers.py:650-904 (forward with `logit_mask` :825-904)
+  RowParallelLinear               M/core/tensor_parallel/layers.py:921-1115
+  LayerNormColumnParallelLinear   TELayerNormColumnParallelLinear as the TE layer spec uses it
+                                  (M/core/models/gpt/gpt_layer_specs.py:39,93-104; parameters `layer_norm_weight`, `weight`, `bias`
+                                  — the names M/ckpt_convert_modellink_to_megatron_with_te.py:37-41 converts to)
+  Norm                            PTNorm / TENorm (M/core/transformer/custom_layers/transformer_engine.py:13-51): RMSNorm | LayerNorm
+so `ModuleSpec` / `build_module` construct them exactly as they construct Megatron's own, `state_dict()` carries
+Megatron's keys, and every forward / backward is a libvita_hip.so kernel through autograd_fns.  `--sequence-parallel`
+(layers.py:392-399,483-494,1095): the column-parallel linears all-gather their input along the sequence over the
+tensor-parallel group (RCCL), the row-parallel linears reduce-scatter their output.
+"""
 from __future__ import annotations
 
-from typing import Optional
+from typing import Callable, Optional
 
 import torch
+from torch.nn import Parameter
 
-from . import ops
+from . import autograd_fns as F_, ops, parallel_state as mpu
 
 
-class ColumnParallelLinear:
-    def __init__(self, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor] = None,
-                 skip_bias_add: bool = False):
-        self.weight, self.bias, self.skip_bias_add = weight, bias, skip_bias_add
+def _divide(n: int, d: int) -> int:
+    if n % d:
+        raise ValueError(f"{n} is not divisible by {d}")
+    return n // d
+
+
+def _alloc(config, *shape) -> torch.Tensor:
+    """Parameters live on the current HIP device unless `config.use_cpu_initialization` (layers.py:744-775)."""
+    dtype = getattr(config, "params_dtype", torch.bfloat16)
+    if getattr(config, "use_cpu_initialization", False):
+        return torch.empty(*shape, dtype=dtype)
+    return torch.empty(*shape, dtype=dtype, device=torch.cuda.current_device())
+
+
+def _add_extra_state_hook(module: torch.nn.Module) -> None:
+    """layers.py:819-823: checkpoints written without TE have no `_extra_state` entry."""
+    module._register_load_state_dict_pre_hook(
+        lambda state_dict, prefix, *args, **kwargs: state_dict.setdefault(f"{prefix}_extra_state"))
+
+
+class _TEStateMixin:
+    def set_extra_state(self, state):
+        """Extra state is ignored (layers.py:911-912)."""
+
+    def get_extra_state(self):
+        """Keep compatibility with TE state dicts (layers.py:914-916)."""
+        return None
+
+
+class ColumnParallelLinear(_TEStateMixin, torch.nn.Module):
+    """Y = X A^T + b with A split along its rows (output features) over the tensor-parallel group."""
+
+    def __init__(self, input_size, output_size, *, config, init_method: Optional[Callable], bias=True, gather_output=False,
+                 stride=1, keep_master_weight_for_test=False, skip_bias_add=False, skip_weight_param_allocation: bool = False,
+                 embedding_activation_buffer=None, grad_output_buffer=None, is_expert: bool = False,
+                 tp_comm_buffer_name: str = None, disable_grad_reduce: bool = False):
+        super().__init__()
+        if is_expert or embedding_activation_buffer is not None or grad_output_buffer is not None:
+            raise NotImplementedError("MoE experts / deferred embedding wgrad are not on the Long-VITA path")
+        self.input_size, self.output_size = input_size, output_size
+        self.gather_output, self.skip_bias_add, self.config = gather_output, skip_bias_add, config
+        self.disable_grad_reduce = disable_grad_reduce
+        world = mpu.get_tensor_model_parallel_world_size()
+        self.output_size_per_partition = _divide(output_size, world)
+        if not skip_weight_param_allocation:
+            self.weight = Parameter(_alloc(config, self.output_size_per_partition, input_size))
+            if getattr(config, "perform_initialization", True) and init_method is not None:
+                with torch.no_grad():
+                    init_method(self.weight)
+            setattr(self.weight, "allreduce", True)
+            setattr(self.weight, "tensor_model_parallel", True)
+            setattr(self.weight, "partition_dim", 0)
+            setattr(self.weight, "partition_stride", stride)
+        else:
+            self.weight = None
+        if bias:
+            self.bias = Parameter(_alloc(config, self.output_size_per_partition))
+            with torch.no_grad():
+                self.bias.zero_()                                                    # "Always initialize bias to zero."
+            setattr(self.bias, "allreduce", True)
+            setattr(self.bias, "tensor_model_parallel", True)
+            setattr(self.bias, "partition_dim", 0)
+            setattr(self.bias, "partition_stride", stride)
+        else:
+            self.register_parameter("bias", None)
+        self.sequence_parallel = bool(getattr(config, "sequence_parallel", False)) and world > 1   # :790-796
+        self.allreduce_dgrad = world > 1 and not self.sequence_parallel
+        if getattr(config, "gradient_accumulation_fusion", False):
+            raise RuntimeError("gradient_accumulation_fusion needs APEX's fused_weight_gradient_mlp_cuda, which does not exist "
+                               "on this platform; run without it")                   # :800-811
+        _add_extra_state_hook(self)
+
+    @classmethod
+    def from_weight(cls, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor] = None, skip_bias_add: bool = False):
+        """Stand-alone driver (gpt_vl_model.GPTVLModel): wrap existing (frozen, inference) tensors."""
+        self = cls.__new__(cls)
+        torch.nn.Module.__init__(self)
+        self.input_size = None if weight is None else weight.shape[1]
+        self.output_size_per_partition = None if weight is None else weight.shape[0]
+        self.output_size = None
+        self.gather_output, self.skip_bias_add, self.config = False, skip_bias_add, None
+        self.disable_grad_reduce, self.sequence_parallel, self.allreduce_dgrad = False, False, False
+        self.weight = None if weight is None else Parameter(weight, requires_grad=False)
+        if bias is None:
+            self.register_parameter("bias", None)
+        else:
+            self.bias = Parameter(bias, requires_grad=False)
+        return self
 
     def forward(self, input_: torch.Tensor, weight: Optional[torch.Tensor] = None, logit_mask=None):
-        """input_ [s, b, hidden] -> (output [n_sel or s, b, out], bias_or_None)."""
+        """input_ [s, b, hidden] -> (output [n_sel or s, b, out / TP], bias or None)  (layers.py:825-904)."""
         if weight is None:
             if self.weight is None:
                 raise RuntimeError("weight was not supplied to ColumnParallelLinear forward pass "
                                    "and skip_weight_param_allocation is True.")
             weight = self.weight
-        elif self.weight is not None and tuple(weight.shape) != tuple(self.weight.shape):
-            raise RuntimeError(f"supplied weight's shape is {tuple(weight.shape)}, "
-                               f"not {tuple(self.weight.shape)} as expected")
-        s, b, c = input_.shape
-        x = input_.reshape(s * b, c)
-        if logit_mask is not None:
-            # masked_select(input, logit_mask.T.unsqueeze(2)).reshape(-1, b, c)  (:402-407), b == 1
-            if b != 1:
-                raise AssertionError("logit_mask requires batch 1 (gpt_vl_model.py:329)")
-            idx = ops.mask_to_index(logit_mask.transpose(0, 1).reshape(-1))
-            x = ops.row_gather(x.contiguous(), idx)
-        bias = None if self.skip_bias_add else self.bias
-        m = x.shape[0]
-        if m <= 16 and bias is None:
-            out = ops.gemm_skinny(x, weight)
+        elif self.output_size_per_partition is not None:
+            expected_shape = (self.output_size_per_partition, self.input_size)
+            if tuple(weight.shape) != expected_shape:
+                raise RuntimeError(f"supplied weight's shape is {tuple(weight.shape)}, not {expected_shape} as expected")
+        bias = self.bias if not self.skip_bias_add else None
+        if self.allreduce_dgrad or self.sequence_parallel or self.disable_grad_reduce:
+            input_parallel = input_
         else:
-            out = ops.gemm(x, weight, ops.EPI_BIAS if bias is not None else ops.EPI_NONE, bias)
-        return out.view(m // b, b, -1), (self.bias if self.skip_bias_add else None)
+            input_parallel = F_.CopyToTP.apply(input_)                               # :872
+        output_parallel = F_.LinearFn.apply(input_parallel, weight, bias, self.allreduce_dgrad, self.sequence_parallel,
+                                            logit_mask)
+        if self.gather_output:
+            assert not self.sequence_parallel                                         # :897
+            output = F_.GatherFromTP.apply(output_parallel)
+        else:
+            output = output_parallel
+        return output, (self.bias if self.skip_bias_add else None)
 
-    __call__ = forward
+
+class RowParallelLinear(_TEStateMixin, torch.nn.Module):
+    """Y = X A^T + b with A split along its columns (input features); partial sums are reduced over the TP group."""
+
+    def __init__(self, input_size: int, output_size: int, *, config, init_method: Optional[Callable], bias: bool,
+                 input_is_parallel: bool, skip_bias_add: bool, stride: int = 1, keep_master_weight_for_test: bool = False,
+                 is_expert: bool = False, tp_comm_buffer_name: str = None):
+        super().__init__()
+        if is_expert:
+            raise NotImplementedError("MoE experts are not on the Long-VITA path")
+        self.input_size, self.output_size = input_size, output_size
+        self.input_is_parallel, self.skip_bias_add, self.config = input_is_parallel, skip_bias_add, config
+        world = mpu.get_tensor_model_parallel_world_size()
+        self.sequence_parallel = bool(getattr(config, "sequence_parallel", False)) and world > 1
+        if getattr(config, "sequence_parallel", False) and not input_is_parallel:
+            raise RuntimeError("To enable `sequence_parallel`, `input_is_parallel` must be `True`")   # :968-969
+        if not input_is_parallel and world > 1:
+            raise NotImplementedError("scatter_to_tensor_model_parallel_region (input_is_parallel=False) is not on this path")
+        self.input_size_per_partition = _divide(input_size, world)
+        self.weight = Parameter(_alloc(config, output_size, self.input_size_per_partition))
+        if getattr(config, "perform_initialization", True) and init_method is not None:
+            with torch.no_grad():
+                init_method(self.weight)
+        setattr(self.weight, "allreduce", True)
+        setattr(self.weight, "tensor_model_parallel", True)
+        setattr(self.weight, "partition_dim", 1)
+        setattr(self.weight, "partition_stride", stride)
+        if bias:
+            self.bias = Parameter(_alloc(config, output_size))
+            with torch.no_grad():
+                self.bias.zero_()
+            setattr(self.bias, "allreduce", True)
+            setattr(self.bias, "sequence_parallel", self.sequence_parallel)
+        else:
+            self.register_parameter("bias", None)
+        if getattr(config, "gradient_accumulation_fusion", False):
+            raise RuntimeError("gradient_accumulation_fusion needs APEX's fused_weight_gradient_mlp_cuda, which does not exist "
+                               "on this platform; run without it")
+        _add_extra_state_hook(self)
+
+    def forward(self, input_: torch.Tensor):
+        """input_ [s, b, in / TP] -> (output [s (/ TP with sequence parallelism), b, out], bias or None)  (:1059-1115)."""
+        output_parallel = F_.LinearFn.apply(input_, self.weight, None, False, False, None)
+        if self.sequence_parallel:
+            output_ = F_.ReduceScatterToSP.apply(output_parallel)                    # :1095
+        else:
+            output_ = F_.ReduceFromTP.apply(output_parallel)                         # :1097
+        if not self.skip_bias_add:
+            if self.bias is not None:                                                 # not on the Long-VITA path (no linear bias)
+                s, b, n = output_.shape
+                output_ = BiasAddFn.apply(output_, self.bias)
+            return output_, None
+        return output_, self.bias
+
+
+class BiasAddFn(torch.autograd.Function):
+    """output + bias behind a row-parallel reduction (layers.py:1099): vita_gemm is not involved, so the add is the
+    library's bias epilogue applied through an identity-free path: y = x + b rounded once to bf16."""
+
+    @staticmethod
+    def forward(ctx, x, bias):
+        y = x.contiguous().clone()
+        rows = y.numel() // y.shape[-1]
+        ops.add_(y.view(rows, -1), bias.expand(rows, -1).contiguous())
+        return y
+
+    @staticmethod
+    def backward(ctx, g):
+        g2 = g.reshape(-1, g.shape[-1]).contiguous()
+        return g, F_.bias_grad(F_.transpose(F_.pad_rows(g2)))
+
+
+class RMSNorm(torch.nn.Module):
+    """M/core/transformer/custom_layers/transformer_engine.py:54-79 (same constructor and `weight` parameter)."""
+
+    def __init__(self, dim: int, eps: float = 1e-6, sequence_parallel: bool = False, config=None):
+        super().__init__()
+        self.eps = eps
+        self.weight = Parameter(torch.ones(dim) if config is None else torch.ones_like(_alloc(config, dim)))
+        setattr(self.weight, "sequence_parallel", sequence_parallel)
+
+    def forward(self, x):
+        return F_.RMSNormFn.apply(x, self.weight, self.eps)
+
+
+class LayerNorm(torch.nn.Module):
+    """torch.nn.LayerNorm's parameters (`weight`, `bias`) with the library's forward (inference: the frozen ViT's norms)."""
+
+    def __init__(self, normalized_shape: int, eps: float = 1e-5, config=None):
+        super().__init__()
+        self.eps = eps
+        self.weight = Parameter(torch.ones(normalized_shape) if config is None else torch.ones_like(_alloc(config, normalized_shape)))
+        self.bias = Parameter(torch.zeros_like(self.weight))
+
+    def forward(self, x):
+        if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
+            raise NotImplementedError("LayerNorm backward is only built for the projector (training.TrainStep); the ViT is frozen")
+        return ops.layernorm(x, self.weight, self.bias, self.eps)
+
+
+class Norm:
+    """PTNorm / TENorm: `Norm(config=..., hidden_size=..., eps=...)` returns the instance the config asks for (:13-51)."""
+
+    def __new__(cls, config, hidden_size: int, eps: float = 1e-5):
+        if config.normalization == "LayerNorm":
+            return LayerNorm(hidden_size, eps=eps, config=config)
+        if config.normalization == "RMSNorm":
+            return RMSNorm(dim=hidden_size, eps=eps, sequence_parallel=getattr(config, "sequence_parallel", False), config=config)
+        raise Exception("Only LayerNorm and RMSNorm are curently supported")
+
+
+class LayerNormColumnParallelLinear(_TEStateMixin, torch.nn.Module):
+    """norm(x) -> column-parallel linear in one module (TELayerNormColumnParallelLinear): vita_rmsnorm_fwd -> vita_gemm_bf16.
+    Under sequence parallelism the norm runs on the rank's sequence shard and the normed rows are all-gathered (TE order)."""
+
+    def __init__(self, input_size: int, output_size: int, *, config, init_method: Optional[Callable], gather_output: bool,
+                 bias: bool, skip_bias_add: bool, is_expert: bool, skip_weight_param_allocation: bool = False,
+                 tp_comm_buffer_name: str = None):
+        super().__init__()
+        if gather_output:
+            raise ValueError("Transformer Engine linear layers do not support gather_output = True")
+        if is_expert:
+            raise ValueError("Transformer Engine linear layers do not yet support MoE")
+        self.config = config
+        self.eps = config.layernorm_epsilon
+        self.normalization = getattr(config, "normalization", "RMSNorm")
+        self.layer_norm_weight = Parameter(torch.ones_like(_alloc(config, input_size)))
+        setattr(self.layer_norm_weight, "sequence_parallel", getattr(config, "sequence_parallel", False))
+        if self.normalization == "LayerNorm":
+            self.layer_norm_bias = Parameter(torch.zeros_like(self.layer_norm_weight))
+            setattr(self.layer_norm_bias, "sequence_parallel", getattr(config, "sequence_parallel", False))
+        else:
+            self.register_parameter("layer_norm_bias", None)
+        inner = ColumnParallelLinear(input_size, output_size, config=config, init_method=init_method, bias=bias,
+                                     gather_output=False, skip_bias_add=skip_bias_add,
+                                     skip_weight_param_allocation=skip_weight_param_allocation)
+        # TE's flat parameter names (`weight`, `bias` beside `layer_norm_weight`)
+        self.weight, self.bias = inner.weight, inner.bias
+        if inner.bias is None:
+            self.register_parameter("bias", None)
+        self._linear = [inner]                      # not a submodule: its parameters are registered here
+
+    def forward(self, x: torch.Tensor):
+        if self.normalization == "RMSNorm":
+            xn = F_.RMSNormFn.apply(x, self.layer_norm_weight, self.eps)
+        else:
+            if torch.is_grad_enabled() and x.requires_grad:
+                raise NotImplementedError("LayerNorm backward is not built (decoder layers use RMSNorm)")
+            xn = ops.layernorm(x, self.layer_norm_weight, self.layer_norm_bias, self.eps)
+        lin = self._linear[0]
+        lin.weight, lin.bias = self.weight, self.bias      # (re-bound after load_state_dict / .to())
+        return lin(xn)
+
+
+def get_bias_dropout_add(training: bool, fused: bool):
+    """megatron.core.fusions.fused_bias_dropout.get_bias_dropout_add for this path: no linear bias, dropout 0 (stage-3
+    `--attention-dropout 0.0 --hidden-dropout 0.0`): residual + x as one library kernel when nothing needs a gradient;
+    anything else (a bias, dropout > 0, autograd) takes Megatron's unfused torch expression."""
+    def _bda(x_with_bias, residual, prob):
+        x, bias = x_with_bias
+        if bias is None and (prob == 0.0 or not training) and not (torch.is_grad_enabled() and (x.requires_grad or residual.requires_grad)):
+            return ops.add_(x.contiguous().clone(), residual.contiguous())
+        if bias is not None:
+            x = x + bias
+        out = torch.nn.functional.dropout(x, p=prob, training=training)
+        return residual + out
+
+    return _bda

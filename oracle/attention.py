@@ -27,8 +27,9 @@ def core_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bo
     vf = v.float().permute(1, 2, 0, 3)
     scores = torch.matmul(qf, kf.transpose(-1, -2)) * scale          # [b, np, sq, sk]
     if causal:
-        qp = torch.arange(sq) if q_pos is None else q_pos
-        kp = torch.arange(sk) if k_pos is None else k_pos
+        dev = q.device                                   # (the tensors' device: the 16K / 48-layer parity test evaluates this on the GPU)
+        qp = torch.arange(sq, device=dev) if q_pos is None else q_pos.to(dev)
+        kp = torch.arange(sk, device=dev) if k_pos is None else k_pos.to(dev)
         mask = kp[None, :] > qp[:, None]
         scores = scores.masked_fill(mask[None, None], float("-inf"))
     if cu_seqlens is not None:

@@ -1,0 +1,493 @@
+// Stand-alone candidate for the next flash-attention forward (gfx950), round 2.  The ladder (attn_ladder.hip, run in round 2)
+// says: 64 query rows per wave with 32x32x16 MFMAs lifts the structure's ceiling from 1.30 to 1.52 PFLOP/s; 16x16x32 does not.
+//
+//   * one workgroup = 4 waves (one per SIMD, 512 registers each) = 256 query rows of one query head; a wave owns 64 rows =
+//     two 32-row blocks qb; 64-key tiles; every K and V^T fragment feeds two MFMAs (qb = 0, 1)
+//   * register classes: O^T (2 x 4 x 16 = 128) lives in AGPRs and is touched by MFMAs only (inline asm, "+a"); the Q fragments
+//     (64) are pinned in AGPRs and used as MFMA B operands from there; S^T (two tiles in flight, 2 x 64) is produced by builtin
+//     MFMAs in VGPR form (-mllvm -amdgpu-mfma-vgpr-form=1) so that the softmax reads it without accumulator moves
+//   * in-wave software pipeline (one wave per SIMD: MFMA || VALU overlap only exists inside one instruction stream):
+//       phase 1: 32 MFMAs  S(t+1) = K(t+1) Q^T   ||  exp / row-sum / bf16 pack of the last (8 - NF2) P fragments of tile t
+//       phase 2: 32 MFMAs  O += V(t)^T P(t)^T    ||  row maximum, new running max of tile t+1, its first NF2 P fragments
+//     fillers are dealt to the MFMA slots by weight; sched_barrier(0) after every slot keeps the order
+//   * K / V tiles HBM/L2 -> LDS by LDS-DMA, separate K and V rings of two 16 KiB slots, one barrier per tile; the library's
+//     swizzled layouts (conflict-free ds_read_b128 / ds_read_b64_tr_b16)
+//   * running maximum exact per tile (as the shipped kernel); O is rescaled only when some row's maximum moved (wave-uniform)
+// Self-checking (naive kernel, sampled rows, all heads), times S = 16K and 128K.
+//   hipcc --offload-arch=gfx950 -O3 -fno-honor-nans -mllvm -amdgpu-mfma-vgpr-form=1 attn64.hip -o attn64 && ./attn64
+#include <hip/hip_runtime.h>
+#include <cstdio>
+#include <cstdint>
+#include <cstdlib>
+#include <cstring>
+#include <cmath>
+#include <vector>
+typedef unsigned short bf16_t;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(16))) float f32x16;
+typedef __attribute__((ext_vector_type(4))) unsigned int u32x4;
+typedef __attribute__((ext_vector_type(2))) unsigned int u32x2;
+typedef __attribute__((ext_vector_type(4))) short s16x4;
+typedef __attribute__((ext_vector_type(8))) short s16x8;
+typedef __attribute__((address_space(3))) const bf16x8 lds_bf16x8;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(1))) const void gvoid;
+typedef __attribute__((address_space(3))) void lvoid;
+
+constexpr int D = 128, KVT = 64, ROWB = D * 2, TILEB = KVT * ROWB;     // 16 KiB per K (or V) tile
+constexpr int LDS_K = 0, LDS_V = 2 * TILEB, LDS_BYTES = 4 * TILEB;      // K ring [2] | V ring [2]
+
+__device__ __forceinline__ unsigned pack2(float lo, float hi) {
+  bf16x2 v; v[0] = (__bf16)lo; v[1] = (__bf16)hi;
+  return *reinterpret_cast<unsigned*>(&v);
+}
+__device__ __forceinline__ float swap32_max(float x) {
+  const unsigned xi = __float_as_uint(x);
+  auto r = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float swap32_sum(float x) {
+  const unsigned xi = __float_as_uint(x);
+  auto r = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// ---- filler schedule: units dealt to the 32 MFMA slots of a phase by cumulative weight ---------------------------------
+// phase 2 units: 0..31 max3 steps (weight 1), 32..33 finish-max of block 0 / 1 (weight 6), then 8 * NF2 exp units (weight 7/2)
+// phase 1 units: 8 * (8 - NF2) exp units
+struct SlotMap { int first[33]; };
+constexpr int unit_w2(int u) { return u < 32 ? 2 : (u < 34 ? 12 : ((u & 1) ? 6 : 8)); }     // (34 is even: half 0 first)
+template <int NF2>
+constexpr SlotMap make_map2() {
+  SlotMap m{};
+  const int n = 34 + 8 * NF2;
+  int tot = 0;
+  for (int u = 0; u < n; ++u) tot += unit_w2(u);
+  int acc = 0, u = 0;
+  for (int s = 0; s < 32; ++s) {
+    m.first[s] = u;
+    const int lim = (tot * (s + 1) + 31) / 32;
+    while (u < n && acc + unit_w2(u) <= lim) { acc += unit_w2(u); ++u; }
+  }
+  m.first[32] = n;
+  return m;
+}
+template <int NF2>
+constexpr SlotMap make_map1() {
+  SlotMap m{};
+  const int n = 8 * (8 - NF2);
+  for (int s = 0; s <= 32; ++s) m.first[s] = (n * s) / 32;
+  return m;
+}
+
+// NOPS: pad VALU -> asm-MFMA operand reads with s_nop 1 (the hazard recognizer does not look into inline asm)
+// ABL (timing-only ablations, results wrong): 1 = no LDS-DMA in the loop, 2 = no vmcnt wait / barrier per tile, 4 = no softmax VALU,
+// 8 = no fragment reads in the loop (one K / V^T fragment reused)
+template <int NF2, bool NOPS, bool PIN = true, int ABL = 0>
+__global__ __launch_bounds__(256, 1) void attn64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
+                                                        const bf16_t* __restrict__ V, bf16_t* __restrict__ O, int S, int Hq,
+                                                        int Hkv, float scale_log2e) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int nq = S / 256;
+  const int head = blockIdx.x % Hq, qt = nq - 1 - blockIdx.x / Hq;          // heaviest query tiles first
+  const int kvh = head / (Hq / Hkv);
+  const int q0 = qt * 256, q_off = q0 + wave * 64;                           // first query row of the workgroup / of this wave
+  const int n_tiles = q0 / KVT + 4;
+  const int64_t k_rs = (int64_t)Hkv * D;                                     // K / V row stride (elements)
+
+  // ---- Q fragments (B operand of S^T = K Q^T): block qb, k-step ds: query q_off + 32 qb + l31, d = 16 ds + 8 hi .. + 7 ----
+  bf16x8 qf[2][8];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int ds = 0; ds < 8; ++ds)
+      qf[qb][ds] = *(const bf16x8*)(Q + ((int64_t)(q_off + 32 * qb + l31) * Hq + head) * D + 16 * ds + 8 * hi);
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int ds = 0; ds < 8; ++ds) asm volatile("" : "+a"(qf[qb][ds]));      // live in AGPRs from here on
+
+  // ---- LDS fragment offsets (the library's layouts) -----------------------------------------------------------------------
+  unsigned koff[8], voff[4];
+#pragma unroll
+  for (int ds = 0; ds < 8; ++ds) koff[ds] = l31 * ROWB + (((2 * ds + hi) ^ (l31 & 15)) << 4);       // + 32 kb rows: immediate
+  {
+    const int g16 = lane >> 4, i16 = lane & 15, key_l = 4 * (g16 >> 1) + (i16 >> 2);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      const int col = 32 * db + 16 * (g16 & 1) + 4 * (i16 & 3);
+      voff[db] = key_l * ROWB + (((col >> 4) ^ ((key_l & 3) << 1)) << 5) + (col & 15) * 2;
+    }
+  }
+  // ---- LDS-DMA: wave w moves pieces 4w .. 4w+3 (1 KiB = 4 rows) of K and of V; swizzle on the SOURCE address -------------
+  unsigned dk_off[4], dv_off[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = (wave * 4 + q) * 4 + (lane >> 4), ps = lane & 15;
+    const int ks = ps ^ (row & 15);
+    const int vs = (((ps >> 1) ^ ((row & 3) << 1)) << 1) | (ps & 1);
+    dk_off[q] = (unsigned)((row * k_rs + ks * 8) * 2);   // bytes
+    dv_off[q] = (unsigned)((row * k_rs + vs * 8) * 2);
+  }
+  // buffer descriptors: SGPR base + per-tile SGPR offset + the lane's 32-bit offset -> no address arithmetic in the loop
+  const int kv_bytes = (int)((int64_t)S * k_rs * 2);
+  const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(K + (int64_t)kvh * D), 0, kv_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(V + (int64_t)kvh * D), 0, kv_bytes, 0x00020000);
+  const int tile_bytes = (int)(KVT * k_rs * 2);
+  auto dma_k = [&](int t, int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lvoid*)(uintptr_t)(lds0 + LDS_K + slot * TILEB + (wave * 4 + q) * 1024), 16,
+                                               dk_off[q], t * tile_bytes, 0, 0);
+  };
+  auto dma_v = [&](int t, int slot) __attribute__((always_inline)) {
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lvoid*)(uintptr_t)(lds0 + LDS_V + slot * TILEB + (wave * 4 + q) * 1024), 16,
+                                               dv_off[q], t * tile_bytes, 0, 0);
+  };
+
+  // ---- state ----------------------------------------------------------------------------------------------------------
+  f32x16 o[2][4];                                    // O^T[qb][db]: d = 32 db + (r & 3) + 8 (r >> 2) + 4 hi, query 32 qb + l31 (AGPRs)
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[qb][db][r] = 0.f;
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int db = 0; db < 4; ++db) asm volatile("" : "+a"(o[qb][db]));
+  f32x16 sb[2][2][2];                                // S^T[parity][qb][kb]: key 32 kb + (r & 3) + 8 (r >> 2) + 4 hi
+  unsigned pk[2][2][4][4];                           // packed P^T[parity][qb][frag f][4 dwords]; frag f = regs 8 (f & 1) .. of kb = f >> 1
+  float m_run[2] = {-1.0e30f, -1.0e30f}, l_run[2] = {0.f, 0.f}, m_neg[2], alpha[2] = {1.f, 1.f}, mxc[4];
+
+  constexpr SlotMap MAP1 = make_map1<NF2>(), MAP2 = make_map2<NF2>();
+
+  // exp half-units (64 per tile): h -> fragment g = h >> 3 (need order of P V: g = 2 f + qb), element pair pr = (h >> 1) & 3;
+  // half 0: the two fma + exp2 of the pair, half 1: row sum, bf16 pack (so an exp2 result is never consumed by the next instruction)
+  float ea = 0.f, eb = 0.f;
+  auto exp_half = [&](int par, int h) __attribute__((always_inline)) {
+    const int g = h >> 3, pr = (h >> 1) & 3, qb = g & 1, f = g >> 1, kb = f >> 1, r = 8 * (f & 1) + 2 * pr;
+    if ((h & 1) == 0) {
+      ea = __builtin_amdgcn_exp2f(fmaf(sb[par][qb][kb][r], scale_log2e, m_neg[qb]));
+      eb = __builtin_amdgcn_exp2f(fmaf(sb[par][qb][kb][r + 1], scale_log2e, m_neg[qb]));
+    } else {
+      l_run[qb] += ea;
+      l_run[qb] += eb;
+      pk[par][qb][f][pr] = pack2(ea, eb);
+      asm volatile("" :: "v"(pk[par][qb][f][pr]), "v"(l_run[qb]));              // computed HERE (no sinking past the phase)
+    }
+  };
+  // S^T(next) = K Q^T: slot = 4 ds + 2 kb + qb; K fragment (kb, ds) read two fragments ahead through a ring of four
+  auto k_frag = [&](unsigned kslot, int i) __attribute__((always_inline)) {        // i = 2 ds + kb
+    return *(lds_bf16x8*)(uintptr_t)(kslot + koff[i >> 1] + (i & 1) * 32 * ROWB);
+  };
+  auto v_frag = [&](unsigned vslot, int i) __attribute__((always_inline)) {        // i = 4 t + db
+    const unsigned va = vslot + voff[i & 3] + 16 * (i >> 2) * ROWB;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(va));
+    const s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(va + 8 * ROWB));
+    return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, c, 0, 1, 2, 3, 4, 5, 6, 7));
+  };
+
+  // ---- the two phases -------------------------------------------------------------------------------------------------
+  // phase 1: S(par ^ 1) = K(kslot) Q^T  ||  exp units NF2*8 .. 63 of tile `par`
+  auto phase1 = [&](int par, unsigned kslot, bool has_next) __attribute__((always_inline)) {
+    bf16x8 kr[4];
+    if (has_next) { kr[0] = k_frag(kslot, 0); kr[1] = k_frag(kslot, 1); if (ABL & 8) { kr[2] = kr[0]; kr[3] = kr[1]; } }
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      const int i = s >> 1, qb = s & 1, ds = i >> 1, kb = i & 1;
+      if (has_next) {
+        if (qb == 0 && i + 2 < 16 && !(ABL & 8)) kr[(i + 2) & 3] = k_frag(kslot, i + 2);
+        if (ds == 0) {
+          f32x16 z;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) z[r] = 0.f;
+          sb[par ^ 1][qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[i & 3], qf[qb][ds], z, 0, 0, 0);
+        } else {
+          sb[par ^ 1][qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[i & 3], qf[qb][ds], sb[par ^ 1][qb][kb], 0, 0, 0);
+        }
+      }
+#pragma unroll
+      for (int u = MAP1.first[s]; u < MAP1.first[s + 1]; ++u) if (!(ABL & 4)) exp_half(par, 8 * NF2 + u);
+      if (PIN) __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // phase 2: O += V(vslot)^T P(par)^T  ||  (has_next) row max / running max of tile par ^ 1 and its first NF2 fragments
+  auto phase2 = [&](int par, unsigned vslot, bool has_next) __attribute__((always_inline)) {
+    bf16x8 vr[4];
+    vr[0] = v_frag(vslot, 0); vr[1] = v_frag(vslot, 1);
+    if (ABL & 8) { vr[2] = vr[0]; vr[3] = vr[1]; }
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      const int i = s >> 1, qb = s & 1, t = i >> 2, db = i & 3;
+      if (qb == 0 && i + 2 < 16 && !(ABL & 8)) vr[(i + 2) & 3] = v_frag(vslot, i + 2);
+      {
+        const u32x4 w = {pk[par][qb][t][0], pk[par][qb][t][1], pk[par][qb][t][2], pk[par][qb][t][3]};
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, w);
+        if (NOPS) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o[qb][db]) : "v"(vr[i & 3]), "v"(pf));
+        else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o[qb][db]) : "v"(vr[i & 3]), "v"(pf));
+      }
+      if (has_next && !(ABL & 4)) {
+        const int np = par ^ 1;
+#pragma unroll
+        for (int u = MAP2.first[s]; u < MAP2.first[s + 1]; ++u) {
+          if (u < 32) {                              // max3 steps: four chains (qb, half): chain c = u & 3, step u >> 2
+            const int c = u & 3, st = u >> 2, qb2 = c >> 1, kb2 = c & 1, r = 2 * st;
+            const float a = sb[np][qb2][kb2][r], b = sb[np][qb2][kb2][r + 1];
+            mxc[c] = st == 0 ? fmaxf(a, b) : fmaxf(fmaxf(a, b), mxc[c]);
+          } else if (u < 34) {                       // finish: block qb2
+            const int qb2 = u - 32;
+            const float mx = swap32_max(fmaxf(mxc[2 * qb2], mxc[2 * qb2 + 1]));
+            const float m_new = fmaxf(m_run[qb2], mx * scale_log2e);
+            alpha[qb2] = __builtin_amdgcn_exp2f(m_run[qb2] - m_new);
+            m_run[qb2] = m_new;
+            m_neg[qb2] = -m_new;
+            l_run[qb2] *= alpha[qb2];
+          } else {
+            exp_half(np, u - 34);
+          }
+        }
+      }
+      if (PIN) __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // start of the softmax of tile `par` outside the pipeline (prologue) -- same units, program order
+  auto start_sm = [&](int par) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 0; u < 34 + 8 * NF2; ++u) {
+      if (u < 32) {
+        const int c = u & 3, st = u >> 2, qb2 = c >> 1, kb2 = c & 1, r = 2 * st;
+        const float a = sb[par][qb2][kb2][r], b = sb[par][qb2][kb2][r + 1];
+        mxc[c] = st == 0 ? fmaxf(a, b) : fmaxf(fmaxf(a, b), mxc[c]);
+      } else if (u < 34) {
+        const int qb2 = u - 32;
+        const float mx = swap32_max(fmaxf(mxc[2 * qb2], mxc[2 * qb2 + 1]));
+        const float m_new = fmaxf(m_run[qb2], mx * scale_log2e);
+        alpha[qb2] = __builtin_amdgcn_exp2f(m_run[qb2] - m_new);
+        m_run[qb2] = m_new;
+        m_neg[qb2] = -m_new;
+        l_run[qb2] *= alpha[qb2];
+      } else {
+        exp_half(par, u - 34);
+      }
+    }
+  };
+  // causal mask of tile t in buffer `par` (applied to every tile of the masked tail; a key past the row costs one v_cndmask)
+  auto mask_tile = [&](int par, int t) __attribute__((always_inline)) {
+    const int kv_off = t * KVT;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int lim = q_off + 32 * qb + l31 - kv_off;                         // key <= lim visible
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int key = 32 * kb + (r & 3) + 8 * (r >> 2) + 4 * hi;
+          if (key > lim) sb[par][qb][kb][r] = -INFINITY;
+        }
+    }
+  };
+  // O *= alpha (rare: only when a row maximum moved); all PV MFMAs that precede it have been issued
+  auto rescale_o = [&]() __attribute__((always_inline)) {
+    if (!__all(alpha[0] == 1.0f && alpha[1] == 1.0f)) {
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                     // asm MFMA -> accumulator read
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[qb][db][r] *= alpha[qb];
+          asm volatile("" : "+a"(o[qb][db]));
+        }
+      asm volatile("s_nop 7" ::: "memory");                                   // accumulator write -> asm MFMA read
+    }
+  };
+
+  // ---- prologue ---------------------------------------------------------------------------------------------------------
+  dma_k(0, 0); dma_v(0, 0);
+  if (n_tiles > 1) dma_k(1, 1);
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  {                                                  // S(0) into buffer 0 (phase 1 without fillers: par = 1 -> writes par ^ 1 = 0)
+    bf16x8 kr[4];
+    kr[0] = k_frag(lds0 + LDS_K, 0); kr[1] = k_frag(lds0 + LDS_K, 1);
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      const int i = s >> 1, qb = s & 1, ds = i >> 1, kb = i & 1;
+      if (qb == 0 && i + 2 < 16) kr[(i + 2) & 3] = k_frag(lds0 + LDS_K, i + 2);
+      if (ds == 0) {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+        sb[0][qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[i & 3], qf[qb][ds], z, 0, 0, 0);
+      } else {
+        sb[0][qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[i & 3], qf[qb][ds], sb[0][qb][kb], 0, 0, 0);
+      }
+    }
+  }
+  __syncthreads();                                  // every wave has read K(0): its ring slot may be refilled
+  if (n_tiles == 4) mask_tile(0, 0);
+  start_sm(0);
+  // (O is zero: no rescale needed for tile 0)
+
+  // ---- main loop: two tiles per trip so that the buffer parity is a compile-time constant; n_tiles is even --------------------
+  // full(par, t): tile t sits in buffer `par`; K(t+2) -> K ring slot par, V(t+1) -> V ring slot par ^ 1
+  auto full = [&](int par, int t, bool more_k, bool masked) __attribute__((always_inline)) {
+    if (!(ABL & 1)) {
+      if (more_k) dma_k(t + 2, par);                 // K(t) in that slot was last read before the previous barrier
+      dma_v(t + 1, par ^ 1);
+    }
+    phase1(par, lds0 + LDS_K + (par ^ 1) * TILEB, true);
+    if (ABL & 4) {
+#pragma unroll
+      for (int a = 0; a < 4; ++a) asm volatile("" :: "v"(sb[par ^ 1][a >> 1][a & 1]));
+    }
+    if (masked) mask_tile(par ^ 1, t + 1);
+    phase2(par, lds0 + LDS_V + par * TILEB, true);
+    rescale_o();
+    if (!(ABL & 2)) {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    }
+  };
+  int t = 0;
+  for (; t < n_tiles - 6; t += 2) {                  // tiles t + 1 <= n - 5 lie wholly below the workgroup's first row
+    full(0, t, true, false);
+    full(1, t + 1, true, false);
+  }
+  for (; t + 2 < n_tiles; t += 2) {                  // the last four tiles cross the diagonal of some wave
+    full(0, t, true, true);
+    full(1, t + 1, true, true);
+  }
+  full(0, t, false, true);
+  phase1(1, 0, false);                               // last tile: the rest of its softmax, then P V
+  phase2(1, lds0 + LDS_V + TILEB, false);
+
+  // ---- epilogue: O[query][head][d] = O^T / l -------------------------------------------------------------------------------
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const float l_tot = swap32_sum(l_run[qb]);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    bf16_t* op = O + ((int64_t)(q_off + 32 * qb + l31) * Hq + head) * D;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int d = 32 * db + 8 * rg + 4 * hi;
+        const u32x2 w = {pack2(o[qb][db][rg * 4 + 0] * inv, o[qb][db][rg * 4 + 1] * inv),
+                         pack2(o[qb][db][rg * 4 + 2] * inv, o[qb][db][rg * 4 + 3] * inv)};
+        *reinterpret_cast<u32x2*>(op + d) = w;
+      }
+  }
+}
+
+__global__ void naive_attn(const bf16_t* Q, const bf16_t* K, const bf16_t* V, float* out, const int* rows, int nrows, int S, int Hq,
+                           int Hkv, float scale) {
+  const int ri = blockIdx.x, head = blockIdx.y, d = threadIdx.x;           // one block per (sampled row, head), 128 threads = d
+  const int q = rows[ri], kvh = head / (Hq / Hkv);
+  __shared__ float red[128];
+  auto bf = [](bf16_t h) { return __uint_as_float((unsigned)h << 16); };
+  const bf16_t* qp = Q + ((int64_t)q * Hq + head) * D;
+  float m = -1e30f, l = 0.f, acc = 0.f;
+  for (int k = 0; k <= q; ++k) {
+    red[d] = bf(qp[d]) * bf(K[((int64_t)k * Hkv + kvh) * D + d]);
+    __syncthreads();
+    for (int st = 64; st > 0; st >>= 1) { if (d < st) red[d] += red[d + st]; __syncthreads(); }
+    const float sc = red[0] * scale;
+    __syncthreads();
+    const float mn = fmaxf(m, sc), a = expf(m - mn), p = expf(sc - mn);
+    l = l * a + p;
+    acc = acc * a + p * bf(V[((int64_t)k * Hkv + kvh) * D + d]);
+    m = mn;
+  }
+  out[((int64_t)ri * Hq + head) * D + d] = acc / l;
+}
+
+static bf16_t f2bf(float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (bf16_t)(u >> 16); }
+static float bf2f(bf16_t h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
+
+template <int NF2, bool NOPS, bool PIN = true, int ABL = 0>
+static int run(int S, int Hq, int Hkv, int nrows_check, float qscale) {
+  const size_t nq = (size_t)S * Hq * D, nkv = (size_t)S * Hkv * D;
+  std::vector<bf16_t> hQ(nq), hK(nkv), hV(nkv);
+  unsigned s = 777u + S;
+  auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
+  for (auto& x : hQ) x = f2bf(rnd() * qscale);
+  for (auto& x : hK) x = f2bf(rnd() * qscale);
+  for (auto& x : hV) x = f2bf(rnd() * 2.f);
+  bf16_t *dQ, *dK, *dV, *dO; float* dRef; int* dRows;
+  (void)hipMalloc(&dQ, nq * 2); (void)hipMalloc(&dK, nkv * 2); (void)hipMalloc(&dV, nkv * 2); (void)hipMalloc(&dO, nq * 2);
+  (void)hipMemcpy(dQ, hQ.data(), nq * 2, hipMemcpyHostToDevice);
+  (void)hipMemcpy(dK, hK.data(), nkv * 2, hipMemcpyHostToDevice);
+  (void)hipMemcpy(dV, hV.data(), nkv * 2, hipMemcpyHostToDevice);
+  (void)hipMemset(dO, 0xff, nq * 2);
+  const float scale = 1.0f / sqrtf((float)D);
+  auto kern = attn64_kernel<NF2, NOPS, PIN, ABL>;
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  const int grid = (S / 256) * Hq;
+  hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
+  float best = 1e30f, ms = 0;
+  for (int rep = 0; rep < 3; ++rep) {
+    (void)hipEventRecord(e0);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS_BYTES, 0, dQ, dK, dV, dO, S, Hq, Hkv, scale * 1.4426950408889634f);
+    (void)hipEventRecord(e1);
+    if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
+    (void)hipEventElapsedTime(&ms, e0, e1);
+    best = ms < best ? ms : best;
+  }
+  const int lim = S < 4096 ? S : 4096;
+  std::vector<int> rows;
+  for (int i = 0; i < nrows_check; ++i) rows.push_back((int)(((int64_t)i * 2654435761u) % lim));   // early rows: cheap to check
+  const int fixed[] = {0, 31, 32, 63, 64, 127, 128, 255, lim - 129, lim - 1, lim - 33, lim - 65};
+  for (int i = 0; i < 12 && i < nrows_check; ++i) rows[i] = fixed[i] < 0 ? 0 : fixed[i];
+  const int nr = (int)rows.size();
+  (void)hipMalloc(&dRef, (size_t)nr * Hq * D * 4); (void)hipMalloc(&dRows, nr * 4);
+  (void)hipMemcpy(dRows, rows.data(), nr * 4, hipMemcpyHostToDevice);
+  hipLaunchKernelGGL(naive_attn, dim3(nr, Hq), dim3(128), 0, 0, dQ, dK, dV, dRef, dRows, nr, S, Hq, Hkv, scale);
+  std::vector<float> ref((size_t)nr * Hq * D); std::vector<bf16_t> hO(nq);
+  (void)hipMemcpy(ref.data(), dRef, ref.size() * 4, hipMemcpyDeviceToHost);
+  (void)hipMemcpy(hO.data(), dO, nq * 2, hipMemcpyDeviceToHost);
+  double max_err = 0; long bad = 0;
+  for (int i = 0; i < nr; ++i)
+    for (int h = 0; h < Hq; ++h)
+      for (int d = 0; d < D; ++d) {
+        const float want = ref[((size_t)i * Hq + h) * D + d], got = bf2f(hO[((size_t)rows[i] * Hq + h) * D + d]);
+        const double err = fabs(got - want);
+        if (err > max_err) max_err = err;
+        if (!(err < 2e-2)) ++bad;                                          // |V| <= 1, P rounded to bf16: abs error ~ 4e-3
+      }
+  const double pairs = (double)S * (S + 1) / 2;
+  printf("NF2=%d nops=%d pin=%d abl=%2d qs=%4.1f S=%6d Hq=%d Hkv=%d  %9.3f ms  %7.1f TFLOP/s   checked %d rows x %d heads: max abs err %.2e, %ld bad\n", NF2,
+         (int)NOPS, (int)PIN, ABL, qscale, S, Hq, Hkv, best, 4.0 * D * Hq * pairs / (best * 1e-3) / 1e12, nr, Hq, max_err, bad);
+  (void)hipFree(dQ); (void)hipFree(dK); (void)hipFree(dV); (void)hipFree(dO); (void)hipFree(dRef); (void)hipFree(dRows);
+  return ABL ? 0 : bad != 0;
+}
+
+int main(int argc, char** argv) {
+  int rc = 0;
+  // correctness first: one query tile, a few tiles, peaked scores (qscale 12: row maxima move, O is rescaled), then speed
+  rc |= run<3, false>(256, 5, 1, 64, 2.f);
+  rc |= run<3, false>(2048, 10, 2, 96, 12.f);
+  rc |= run<3, false>(131072, 40, 8, 16, 2.f);
+  // ablation ladder at 128K (timing only)
+  run<3, false, true, 1>(131072, 40, 8, 16, 2.f);
+  run<3, false, true, 2>(131072, 40, 8, 16, 2.f);
+  run<3, false, true, 3>(131072, 40, 8, 16, 2.f);
+  run<3, false, true, 4>(131072, 40, 8, 16, 2.f);
+  run<3, false, true, 8>(131072, 40, 8, 16, 2.f);
+  run<3, false, true, 12>(131072, 40, 8, 16, 2.f);
+  run<3, false, true, 7>(131072, 40, 8, 16, 2.f);
+  run<3, false, true, 11>(131072, 40, 8, 16, 2.f);
+  run<3, false, true, 15>(131072, 40, 8, 16, 2.f);
+  printf(rc ? "FAILED\n" : "all checks passed\n");
+  return rc;
+}
