@@ -37,7 +37,7 @@ typedef __attribute__((address_space(1))) const void gvoid;
 typedef __attribute__((address_space(3))) void lvoid;
 
 constexpr int D = 128, KVT = 64, ROWB = D * 2, TILEB = KVT * ROWB;     // 16 KiB per K (or V) tile
-constexpr int LDS_K = 0, LDS_V = 2 * TILEB, LDS_BYTES = 4 * TILEB;      // K ring [2] | V ring [2]
+constexpr int LDS_K = 0, LDS_V = 2 * TILEB, LDS_BYTES = 5 * TILEB;      // K ring [2] | V ring [2 or 3]
 
 __device__ __forceinline__ unsigned pack2(float lo, float hi) {
   bf16x2 v; v[0] = (__bf16)lo; v[1] = (__bf16)hi;
@@ -85,10 +85,16 @@ constexpr SlotMap make_map1() {
 // NOPS: pad VALU -> asm-MFMA operand reads with s_nop 1 (the hazard recognizer does not look into inline asm)
 // ABL (timing-only ablations, results wrong): 1 = no LDS-DMA in the loop, 2 = no vmcnt wait / barrier per tile, 4 = no softmax VALU,
 // 8 = no fragment reads in the loop (one K / V^T fragment reused)
-template <int NF2, bool NOPS, bool PIN = true, int ABL = 0>
+// SPREAD: the 8 LDS-DMA pieces of a tile go behind MFMAs of phase 1 (their issue cost, 60 - 180 cycles each, then overlaps the
+//         matrix pipe) instead of a burst in front of it;  SUMM: row sums by 8 more MFMAs against a `ones` V^T fragment (the sum
+//         row is row 0 of a fifth O^T block) instead of 64 v_add;  V3: V ring of three slots, V(t+2) issued in tile t, counted vmcnt
+// THR: lazy running maximum (log2 units).  0 = exact per tile.  > 0: the maximum (and with it O, l) only moves when some row of the
+//      wave exceeds it by more than 2^THR, so P <= 2^THR instead of <= 1 (bf16 / fp32 have the range; relative rounding is unchanged)
+//      and the 400-instruction accumulator rescale leaves the steady state (with exact maxima a 64-row wave hits it on ~20 % of tiles).
+template <int NF2, bool NOPS, bool PIN = true, int ABL = 0, bool SPREAD = false, bool SUMM = false, bool V3 = false, int THR = 0>
 __global__ __launch_bounds__(256, 1) void attn64_kernel(const bf16_t* __restrict__ Q, const bf16_t* __restrict__ K,
                                                         const bf16_t* __restrict__ V, bf16_t* __restrict__ O, int S, int Hq,
-                                                        int Hkv, float scale_log2e) {
+                                                        int Hkv, float scale_log2e, int hm) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
   const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
@@ -98,7 +104,8 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const bf16_t* __restrict
   const int kvh = head / (Hq / Hkv);
   const int q0 = qt * 256, q_off = q0 + wave * 64;                           // first query row of the workgroup / of this wave
   const int n_tiles = q0 / KVT + 4;
-  const int64_t k_rs = (int64_t)Hkv * D;                                     // K / V row stride (elements)
+  const int64_t k_rs = hm ? D : (int64_t)Hkv * D;                            // K / V row stride (elements); hm: K / V stored [Hkv][S][D]
+  const int64_t kv_head_off = hm ? (int64_t)kvh * S * D : (int64_t)kvh * D;
 
   // ---- Q fragments (B operand of S^T = K Q^T): block qb, k-step ds: query q_off + 32 qb + l31, d = 16 ds + 8 hi .. + 7 ----
   bf16x8 qf[2][8];
@@ -136,20 +143,24 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const bf16_t* __restrict
   }
   // buffer descriptors: SGPR base + per-tile SGPR offset + the lane's 32-bit offset -> no address arithmetic in the loop
   const int kv_bytes = (int)((int64_t)S * k_rs * 2);
-  const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(K + (int64_t)kvh * D), 0, kv_bytes, 0x00020000);
-  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(V + (int64_t)kvh * D), 0, kv_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t k_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(K + kv_head_off), 0, kv_bytes, 0x00020000);
+  const __amdgpu_buffer_rsrc_t v_rsrc = __builtin_amdgcn_make_buffer_rsrc((void*)(V + kv_head_off), 0, kv_bytes, 0x00020000);
   const int tile_bytes = (int)(KVT * k_rs * 2);
+  auto dma_k1 = [&](int t, int slot, int q) __attribute__((always_inline)) {
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lvoid*)(uintptr_t)(lds0 + LDS_K + slot * TILEB + (wave * 4 + q) * 1024), 16,
+                                             dk_off[q], t * tile_bytes, 0, 0);
+  };
+  auto dma_v1 = [&](int t, unsigned vbase, int q) __attribute__((always_inline)) {          // vbase: LDS address of the V slot
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lvoid*)(uintptr_t)(vbase + (wave * 4 + q) * 1024), 16, dv_off[q],
+                                             t * tile_bytes, 0, 0);
+  };
   auto dma_k = [&](int t, int slot) __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(k_rsrc, (lvoid*)(uintptr_t)(lds0 + LDS_K + slot * TILEB + (wave * 4 + q) * 1024), 16,
-                                               dk_off[q], t * tile_bytes, 0, 0);
+    for (int q = 0; q < 4; ++q) dma_k1(t, slot, q);
   };
-  auto dma_v = [&](int t, int slot) __attribute__((always_inline)) {
+  auto dma_v = [&](int t, unsigned vbase) __attribute__((always_inline)) {
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(v_rsrc, (lvoid*)(uintptr_t)(lds0 + LDS_V + slot * TILEB + (wave * 4 + q) * 1024), 16,
-                                               dv_off[q], t * tile_bytes, 0, 0);
+    for (int q = 0; q < 4; ++q) dma_v1(t, vbase, q);
   };
 
   // ---- state ----------------------------------------------------------------------------------------------------------
@@ -164,6 +175,22 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const bf16_t* __restrict
   for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
     for (int db = 0; db < 4; ++db) asm volatile("" : "+a"(o[qb][db]));
+  // SUMM: row sums by MFMA.  One v_mfma_f32_16x16x32_bf16 per P^T fragment: read as a [32 k][16 n] B operand, the fragment's lanes
+  // 16 g + n hold query n (g = 0, 2: its two key halves) or query 16 + n (g = 1, 3); with A[0][k] = 1 on k-groups 0, 2 and A[1][k] = 1 on
+  // k-groups 1, 3 the result row 0 is the sum for query n and row 1 the sum for query 16 + n: lanes n < 16, registers 0 and 1.
+  typedef __attribute__((ext_vector_type(4))) float f32x4;
+  f32x4 osum[2];
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    osum[qb] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    if (SUMM) asm volatile("" : "+a"(osum[qb]));
+  }
+  bf16x8 ones_frag;
+  {
+    const bool one = (lane == 0) || (lane == 32) || (lane == 17) || (lane == 49);
+#pragma unroll
+    for (int j = 0; j < 8; ++j) ones_frag[j] = (__bf16)(one ? 1.0f : 0.0f);
+  }
   f32x16 sb[2][2][2];                                // S^T[parity][qb][kb]: key 32 kb + (r & 3) + 8 (r >> 2) + 4 hi
   unsigned pk[2][2][4][4];                           // packed P^T[parity][qb][frag f][4 dwords]; frag f = regs 8 (f & 1) .. of kb = f >> 1
   float m_run[2] = {-1.0e30f, -1.0e30f}, l_run[2] = {0.f, 0.f}, m_neg[2], alpha[2] = {1.f, 1.f}, mxc[4];
@@ -172,15 +199,14 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const bf16_t* __restrict
 
   // exp half-units (64 per tile): h -> fragment g = h >> 3 (need order of P V: g = 2 f + qb), element pair pr = (h >> 1) & 3;
   // half 0: the two fma + exp2 of the pair, half 1: row sum, bf16 pack (so an exp2 result is never consumed by the next instruction)
-  float ea = 0.f, eb = 0.f;
+  float ea = 0.f, eb = 0.f, mx0_keep = 0.f;
   auto exp_half = [&](int par, int h) __attribute__((always_inline)) {
     const int g = h >> 3, pr = (h >> 1) & 3, qb = g & 1, f = g >> 1, kb = f >> 1, r = 8 * (f & 1) + 2 * pr;
     if ((h & 1) == 0) {
       ea = __builtin_amdgcn_exp2f(fmaf(sb[par][qb][kb][r], scale_log2e, m_neg[qb]));
       eb = __builtin_amdgcn_exp2f(fmaf(sb[par][qb][kb][r + 1], scale_log2e, m_neg[qb]));
     } else {
-      l_run[qb] += ea;
-      l_run[qb] += eb;
+      if (!SUMM) { l_run[qb] += ea; l_run[qb] += eb; }
       pk[par][qb][f][pr] = pack2(ea, eb);
       asm volatile("" :: "v"(pk[par][qb][f][pr]), "v"(l_run[qb]));              // computed HERE (no sinking past the phase)
     }
@@ -198,7 +224,8 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const bf16_t* __restrict
 
   // ---- the two phases -------------------------------------------------------------------------------------------------
   // phase 1: S(par ^ 1) = K(kslot) Q^T  ||  exp units NF2*8 .. 63 of tile `par`
-  auto phase1 = [&](int par, unsigned kslot, bool has_next) __attribute__((always_inline)) {
+  // dk_t / dv_t: tile whose K / V pieces are issued here (SPREAD), < 0: none; dk_slot: K ring slot, dv_base: LDS address of the V slot
+  auto phase1 = [&](int par, unsigned kslot, bool has_next, int dk_t, int dk_slot, int dv_t, unsigned dv_base) __attribute__((always_inline)) {
     bf16x8 kr[4];
     if (has_next) { kr[0] = k_frag(kslot, 0); kr[1] = k_frag(kslot, 1); if (ABL & 8) { kr[2] = kr[0]; kr[3] = kr[1]; } }
 #pragma unroll
@@ -215,6 +242,11 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const bf16_t* __restrict
           sb[par ^ 1][qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[i & 3], qf[qb][ds], sb[par ^ 1][qb][kb], 0, 0, 0);
         }
       }
+      if (SPREAD && !(ABL & 1) && (s & 3) == 1) {   // slots 1, 5, .. 29: K pieces first, then V pieces
+        const int q = s >> 2;
+        if (q < 4) { if (dk_t >= 0) dma_k1(dk_t, dk_slot, q); }
+        else { if (dv_t >= 0) dma_v1(dv_t, dv_base, q - 4); }
+      }
 #pragma unroll
       for (int u = MAP1.first[s]; u < MAP1.first[s + 1]; ++u) if (!(ABL & 4)) exp_half(par, 8 * NF2 + u);
       if (PIN) __builtin_amdgcn_sched_barrier(0);
@@ -225,32 +257,50 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const bf16_t* __restrict
     bf16x8 vr[4];
     vr[0] = v_frag(vslot, 0); vr[1] = v_frag(vslot, 1);
     if (ABL & 8) { vr[2] = vr[0]; vr[3] = vr[1]; }
+    constexpr int PER_T = SUMM ? 10 : 8, NS = 4 * PER_T;        // MFMA slots per 16-key step: 8 P V (+ 2 row-sum)
 #pragma unroll
-    for (int s = 0; s < 32; ++s) {
-      const int i = s >> 1, qb = s & 1, t = i >> 2, db = i & 3;
-      if (qb == 0 && i + 2 < 16 && !(ABL & 8)) vr[(i + 2) & 3] = v_frag(vslot, i + 2);
-      {
-        const u32x4 w = {pk[par][qb][t][0], pk[par][qb][t][1], pk[par][qb][t][2], pk[par][qb][t][3]};
-        const bf16x8 pf = __builtin_bit_cast(bf16x8, w);
+    for (int s = 0; s < NS; ++s) {
+      const int t = s / PER_T, w = s % PER_T;
+      if (w < 8) {
+        const int i = 4 * t + (w >> 1), qb = w & 1, db = i & 3;
+        if (qb == 0 && i + 2 < 16 && !(ABL & 8)) vr[(i + 2) & 3] = v_frag(vslot, i + 2);
+        const u32x4 pw = {pk[par][qb][t][0], pk[par][qb][t][1], pk[par][qb][t][2], pk[par][qb][t][3]};
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
         if (NOPS) asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o[qb][db]) : "v"(vr[i & 3]), "v"(pf));
         else asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o[qb][db]) : "v"(vr[i & 3]), "v"(pf));
+      } else {
+        const int qb = w - 8;
+        const u32x4 pw = {pk[par][qb][t][0], pk[par][qb][t][1], pk[par][qb][t][2], pk[par][qb][t][3]};
+        const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+        asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(osum[qb]) : "v"(ones_frag), "v"(pf));
       }
       if (has_next && !(ABL & 4)) {
         const int np = par ^ 1;
+        const int u0 = (MAP2.first[32] * s) / NS, u1 = (MAP2.first[32] * (s + 1)) / NS;   // units dealt evenly over the slots
+        const int a0 = SUMM ? u0 : MAP2.first[s], a1 = SUMM ? u1 : MAP2.first[s + 1];
 #pragma unroll
-        for (int u = MAP2.first[s]; u < MAP2.first[s + 1]; ++u) {
+        for (int u = a0; u < a1; ++u) {
           if (u < 32) {                              // max3 steps: four chains (qb, half): chain c = u & 3, step u >> 2
             const int c = u & 3, st = u >> 2, qb2 = c >> 1, kb2 = c & 1, r = 2 * st;
             const float a = sb[np][qb2][kb2][r], b = sb[np][qb2][kb2][r + 1];
             mxc[c] = st == 0 ? fmaxf(a, b) : fmaxf(fmaxf(a, b), mxc[c]);
           } else if (u < 34) {                       // finish: block qb2
             const int qb2 = u - 32;
-            const float mx = swap32_max(fmaxf(mxc[2 * qb2], mxc[2 * qb2 + 1]));
-            const float m_new = fmaxf(m_run[qb2], mx * scale_log2e);
-            alpha[qb2] = __builtin_amdgcn_exp2f(m_run[qb2] - m_new);
-            m_run[qb2] = m_new;
-            m_neg[qb2] = -m_new;
-            l_run[qb2] *= alpha[qb2];
+            const float mx = swap32_max(fmaxf(mxc[2 * qb2], mxc[2 * qb2 + 1])) * scale_log2e;
+            if (THR == 0 || qb2 == 1) {              // (THR > 0: both blocks decided together, one wave-uniform flag)
+              const bool grow = THR == 0 ? true : __any((mx > m_run[1] + (float)THR) || (mx0_keep > m_run[0] + (float)THR));
+#pragma unroll
+              for (int b = (THR == 0 ? qb2 : 0); b <= qb2; ++b) {
+                const float mb = b == qb2 ? mx : mx0_keep;
+                const float m_new = grow ? fmaxf(m_run[b], mb) : m_run[b];
+                alpha[b] = __builtin_amdgcn_exp2f(m_run[b] - m_new);
+                m_run[b] = m_new;
+                m_neg[b] = -m_new;
+                if (!SUMM) l_run[b] *= alpha[b];
+              }
+            } else {
+              mx0_keep = mx;
+            }
           } else {
             exp_half(np, u - 34);
           }
@@ -307,16 +357,27 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const bf16_t* __restrict
           for (int r = 0; r < 16; ++r) o[qb][db][r] *= alpha[qb];
           asm volatile("" : "+a"(o[qb][db]));
         }
+      if (SUMM) {                                   // lane n < 16 holds the sums of queries n (its own alpha) and 16 + n
+#pragma unroll
+        for (int qb = 0; qb < 2; ++qb) {
+          const float a_hi = __shfl(alpha[qb], (lane & 15) + 16, 64);
+          osum[qb][0] *= alpha[qb];
+          osum[qb][1] *= a_hi;
+          asm volatile("" : "+a"(osum[qb]));
+        }
+      }
       asm volatile("s_nop 7" ::: "memory");                                   // accumulator write -> asm MFMA read
     }
   };
 
   // ---- prologue ---------------------------------------------------------------------------------------------------------
-  dma_k(0, 0); dma_v(0, 0);
+  const unsigned vb0 = lds0 + LDS_V;
+  dma_k(0, 0); dma_v(0, vb0);
   if (n_tiles > 1) dma_k(1, 1);
+  if (V3 && n_tiles > 1) dma_v(1, vb0 + TILEB);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
-  {                                                  // S(0) into buffer 0 (phase 1 without fillers: par = 1 -> writes par ^ 1 = 0)
+  {                                                  // S(0) into buffer 0
     bf16x8 kr[4];
     kr[0] = k_frag(lds0 + LDS_K, 0); kr[1] = k_frag(lds0 + LDS_K, 1);
 #pragma unroll
@@ -339,43 +400,53 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const bf16_t* __restrict
   // (O is zero: no rescale needed for tile 0)
 
   // ---- main loop: two tiles per trip so that the buffer parity is a compile-time constant; n_tiles is even --------------------
-  // full(par, t): tile t sits in buffer `par`; K(t+2) -> K ring slot par, V(t+1) -> V ring slot par ^ 1
-  auto full = [&](int par, int t, bool more_k, bool masked) __attribute__((always_inline)) {
-    if (!(ABL & 1)) {
-      if (more_k) dma_k(t + 2, par);                 // K(t) in that slot was last read before the previous barrier
-      dma_v(t + 1, par ^ 1);
+  // full(par, t): tile t sits in S / P buffer `par`; K(t+2) -> K ring slot par.  V ring: two slots (V(t+1) -> slot par ^ 1) or,
+  // V3, three slots walked by vcur / vnext2 (V(t+2) -> the slot V(t-1) left) with a counted wait: only the four V(t+2) pieces
+  // issued last may still be in flight at the barrier, K(t+2) and V(t+1) have landed.
+  unsigned v_cur = vb0, v_nxt = vb0 + TILEB, v_nx2 = vb0 + 2 * TILEB;      // V3: slots of V(t), V(t+1), V(t+2)
+  auto full = [&](int par, int t, bool more_k, bool masked, bool more_v2) __attribute__((always_inline)) {
+    const int dk_t = more_k ? t + 2 : -1;
+    const int dv_t = V3 ? (more_v2 ? t + 2 : -1) : t + 1;
+    const unsigned dv_base = V3 ? v_nx2 : vb0 + (par ^ 1) * TILEB;
+    const unsigned vslot = V3 ? v_cur : vb0 + par * TILEB;
+    if (!SPREAD && !(ABL & 1)) {
+      if (dk_t >= 0) dma_k(dk_t, par);               // K(t) in that slot was last read before the previous barrier
+      if (dv_t >= 0) dma_v(dv_t, dv_base);
     }
-    phase1(par, lds0 + LDS_K + (par ^ 1) * TILEB, true);
+    phase1(par, lds0 + LDS_K + (par ^ 1) * TILEB, true, dk_t, par, dv_t, dv_base);
     if (ABL & 4) {
 #pragma unroll
       for (int a = 0; a < 4; ++a) asm volatile("" :: "v"(sb[par ^ 1][a >> 1][a & 1]));
     }
     if (masked) mask_tile(par ^ 1, t + 1);
-    phase2(par, lds0 + LDS_V + par * TILEB, true);
+    phase2(par, vslot, true);
     rescale_o();
     if (!(ABL & 2)) {
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      __syncthreads();
+      if (V3 && more_v2) asm volatile("s_waitcnt vmcnt(4)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
     }
+    if (V3) { const unsigned tmp = v_cur; v_cur = v_nxt; v_nxt = v_nx2; v_nx2 = tmp; }
   };
   int t = 0;
   for (; t < n_tiles - 6; t += 2) {                  // tiles t + 1 <= n - 5 lie wholly below the workgroup's first row
-    full(0, t, true, false);
-    full(1, t + 1, true, false);
+    full(0, t, true, false, true);
+    full(1, t + 1, true, false, true);
   }
   for (; t + 2 < n_tiles; t += 2) {                  // the last four tiles cross the diagonal of some wave
-    full(0, t, true, true);
-    full(1, t + 1, true, true);
+    full(0, t, true, true, true);
+    full(1, t + 1, true, true, t + 3 < n_tiles);
   }
-  full(0, t, false, true);
-  phase1(1, 0, false);                               // last tile: the rest of its softmax, then P V
-  phase2(1, lds0 + LDS_V + TILEB, false);
+  full(0, t, false, true, false);
+  phase1(1, 0, false, -1, 0, -1, 0);                 // last tile: the rest of its softmax, then P V
+  phase2(1, V3 ? v_cur : vb0 + TILEB, false);
 
   // ---- epilogue: O[query][head][d] = O^T / l -------------------------------------------------------------------------------
   asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
-    const float l_tot = swap32_sum(l_run[qb]);
+    const float l_tot = SUMM ? __shfl(l31 < 16 ? osum[qb][0] : osum[qb][1], lane & 15, 64) : swap32_sum(l_run[qb]);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     bf16_t* op = O + ((int64_t)(q_off + 32 * qb + l31) * Hq + head) * D;
 #pragma unroll
@@ -391,7 +462,7 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const bf16_t* __restrict
 }
 
 __global__ void naive_attn(const bf16_t* Q, const bf16_t* K, const bf16_t* V, float* out, const int* rows, int nrows, int S, int Hq,
-                           int Hkv, float scale) {
+                           int Hkv, float scale, int hm) {
   const int ri = blockIdx.x, head = blockIdx.y, d = threadIdx.x;           // one block per (sampled row, head), 128 threads = d
   const int q = rows[ri], kvh = head / (Hq / Hkv);
   __shared__ float red[128];
@@ -399,14 +470,15 @@ __global__ void naive_attn(const bf16_t* Q, const bf16_t* K, const bf16_t* V, fl
   const bf16_t* qp = Q + ((int64_t)q * Hq + head) * D;
   float m = -1e30f, l = 0.f, acc = 0.f;
   for (int k = 0; k <= q; ++k) {
-    red[d] = bf(qp[d]) * bf(K[((int64_t)k * Hkv + kvh) * D + d]);
+    const int64_t kvi = hm ? ((int64_t)kvh * S + k) * D + d : ((int64_t)k * Hkv + kvh) * D + d;
+    red[d] = bf(qp[d]) * bf(K[kvi]);
     __syncthreads();
     for (int st = 64; st > 0; st >>= 1) { if (d < st) red[d] += red[d + st]; __syncthreads(); }
     const float sc = red[0] * scale;
     __syncthreads();
     const float mn = fmaxf(m, sc), a = expf(m - mn), p = expf(sc - mn);
     l = l * a + p;
-    acc = acc * a + p * bf(V[((int64_t)k * Hkv + kvh) * D + d]);
+    acc = acc * a + p * bf(V[kvi]);
     m = mn;
   }
   out[((int64_t)ri * Hq + head) * D + d] = acc / l;
@@ -415,8 +487,8 @@ __global__ void naive_attn(const bf16_t* Q, const bf16_t* K, const bf16_t* V, fl
 static bf16_t f2bf(float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (bf16_t)(u >> 16); }
 static float bf2f(bf16_t h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
-template <int NF2, bool NOPS, bool PIN = true, int ABL = 0>
-static int run(int S, int Hq, int Hkv, int nrows_check, float qscale) {
+template <int NF2, bool NOPS, bool PIN = true, int ABL = 0, bool SPREAD = false, bool SUMM = false, bool V3 = false, int THR = 0>
+static int run(int S, int Hq, int Hkv, int nrows_check, float qscale, int hm = 0) {
   const size_t nq = (size_t)S * Hq * D, nkv = (size_t)S * Hkv * D;
   std::vector<bf16_t> hQ(nq), hK(nkv), hV(nkv);
   unsigned s = 777u + S;
@@ -431,14 +503,14 @@ static int run(int S, int Hq, int Hkv, int nrows_check, float qscale) {
   (void)hipMemcpy(dV, hV.data(), nkv * 2, hipMemcpyHostToDevice);
   (void)hipMemset(dO, 0xff, nq * 2);
   const float scale = 1.0f / sqrtf((float)D);
-  auto kern = attn64_kernel<NF2, NOPS, PIN, ABL>;
+  auto kern = attn64_kernel<NF2, NOPS, PIN, ABL, SPREAD, SUMM, V3, THR>;
   (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   const int grid = (S / 256) * Hq;
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   float best = 1e30f, ms = 0;
   for (int rep = 0; rep < 3; ++rep) {
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS_BYTES, 0, dQ, dK, dV, dO, S, Hq, Hkv, scale * 1.4426950408889634f);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS_BYTES, 0, dQ, dK, dV, dO, S, Hq, Hkv, scale * 1.4426950408889634f, hm);
     (void)hipEventRecord(e1);
     if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
     (void)hipEventElapsedTime(&ms, e0, e1);
@@ -452,7 +524,7 @@ static int run(int S, int Hq, int Hkv, int nrows_check, float qscale) {
   const int nr = (int)rows.size();
   (void)hipMalloc(&dRef, (size_t)nr * Hq * D * 4); (void)hipMalloc(&dRows, nr * 4);
   (void)hipMemcpy(dRows, rows.data(), nr * 4, hipMemcpyHostToDevice);
-  hipLaunchKernelGGL(naive_attn, dim3(nr, Hq), dim3(128), 0, 0, dQ, dK, dV, dRef, dRows, nr, S, Hq, Hkv, scale);
+  hipLaunchKernelGGL(naive_attn, dim3(nr, Hq), dim3(128), 0, 0, dQ, dK, dV, dRef, dRows, nr, S, Hq, Hkv, scale, hm);
   std::vector<float> ref((size_t)nr * Hq * D); std::vector<bf16_t> hO(nq);
   (void)hipMemcpy(ref.data(), dRef, ref.size() * 4, hipMemcpyDeviceToHost);
   (void)hipMemcpy(hO.data(), dO, nq * 2, hipMemcpyDeviceToHost);
@@ -466,8 +538,8 @@ static int run(int S, int Hq, int Hkv, int nrows_check, float qscale) {
         if (!(err < 2e-2)) ++bad;                                          // |V| <= 1, P rounded to bf16: abs error ~ 4e-3
       }
   const double pairs = (double)S * (S + 1) / 2;
-  printf("NF2=%d nops=%d pin=%d abl=%2d qs=%4.1f S=%6d Hq=%d Hkv=%d  %9.3f ms  %7.1f TFLOP/s   checked %d rows x %d heads: max abs err %.2e, %ld bad\n", NF2,
-         (int)NOPS, (int)PIN, ABL, qscale, S, Hq, Hkv, best, 4.0 * D * Hq * pairs / (best * 1e-3) / 1e12, nr, Hq, max_err, bad);
+  printf("NF2=%d abl=%2d spread=%d summ=%d v3=%d thr=%d hm=%d qs=%4.1f S=%6d Hq=%d Hkv=%d  %9.3f ms  %7.1f TFLOP/s   checked %d rows x %d heads: max abs err %.2e, %ld bad\n", NF2,
+         ABL, (int)SPREAD, (int)SUMM, (int)V3, THR, hm, qscale, S, Hq, Hkv, best, 4.0 * D * Hq * pairs / (best * 1e-3) / 1e12, nr, Hq, max_err, bad);
   (void)hipFree(dQ); (void)hipFree(dK); (void)hipFree(dV); (void)hipFree(dO); (void)hipFree(dRef); (void)hipFree(dRows);
   return ABL ? 0 : bad != 0;
 }
@@ -475,19 +547,21 @@ static int run(int S, int Hq, int Hkv, int nrows_check, float qscale) {
 int main(int argc, char** argv) {
   int rc = 0;
   // correctness first: one query tile, a few tiles, peaked scores (qscale 12: row maxima move, O is rescaled), then speed
-  rc |= run<3, false>(256, 5, 1, 64, 2.f);
-  rc |= run<3, false>(2048, 10, 2, 96, 12.f);
-  rc |= run<3, false>(131072, 40, 8, 16, 2.f);
-  // ablation ladder at 128K (timing only)
-  run<3, false, true, 1>(131072, 40, 8, 16, 2.f);
-  run<3, false, true, 2>(131072, 40, 8, 16, 2.f);
-  run<3, false, true, 3>(131072, 40, 8, 16, 2.f);
-  run<3, false, true, 4>(131072, 40, 8, 16, 2.f);
-  run<3, false, true, 8>(131072, 40, 8, 16, 2.f);
-  run<3, false, true, 12>(131072, 40, 8, 16, 2.f);
-  run<3, false, true, 7>(131072, 40, 8, 16, 2.f);
-  run<3, false, true, 11>(131072, 40, 8, 16, 2.f);
-  run<3, false, true, 15>(131072, 40, 8, 16, 2.f);
+#define CASES(...)                                          \
+  rc |= run<__VA_ARGS__>(256, 5, 1, 64, 2.f);               \
+  rc |= run<__VA_ARGS__>(1024, 10, 2, 96, 2.f);             \
+  rc |= run<__VA_ARGS__>(2048, 10, 2, 96, 12.f);            \
+  rc |= run<__VA_ARGS__>(2048, 10, 2, 96, 40.f);            \
+  rc |= run<__VA_ARGS__>(16384, 40, 8, 48, 2.f);            \
+  rc |= run<__VA_ARGS__>(131072, 40, 8, 16, 2.f);
+  CASES(3, false, true, 0, false, false, false, 0)
+  CASES(3, false, true, 0, false, false, false, 8)
+  CASES(3, false, true, 0, false, false, false, 4)
+  CASES(3, false, true, 0, true, false, false, 8)
+  CASES(3, false, true, 0, true, false, true, 8)
+  CASES(2, false, true, 0, true, false, true, 8)
+  CASES(4, false, true, 0, true, false, true, 8)
+  run<3, false, true, 0, false, false, false, 8>(131072, 40, 8, 16, 0.f);
   printf(rc ? "FAILED\n" : "all checks passed\n");
   return rc;
 }
