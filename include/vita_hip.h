@@ -60,6 +60,12 @@ int vita_layernorm_fwd(const void* x, const void* w, const void* b, void* y,
 int vita_rope_table(const int64_t* pos, const float* inv_freq, void* cos_out, void* sin_out,
                     int64_t n, int half_dim, void* stream);
 
+/* cos/sin tables, bf16 [n, half_dim], from the fp32 angles Megatron's RotaryEmbedding.forward returns
+ * (`freqs` [s, 1, 1, dim] = cat(freqs, freqs), rotary_pos_embedding.py:106-108; row_stride = dim): the argument
+ * apply_rotary_pos_emb(t, freqs, config, cu_seqlens) receives at :232-259.  cos_ = cos(freqs).to(bf16) as :200-201. */
+int vita_rope_cos_sin(const float* freqs, int64_t row_stride, void* cos_out, void* sin_out,
+                      int64_t n, int half_dim, void* stream);
+
 /* In-place RoPE on a strided [rows, heads, head_dim] bf16 view (non-interleaved halves):
  *   t = bf16(bf16(t*cos) + bf16(rotate_half(t)*sin))   — the rounding chain of :203.
  * row_stride / head_stride in elements.  sign = +1 forward, -1 backward (transpose rotation). */

@@ -23,37 +23,16 @@
 // Reference behaviour restated: M/core/transformer/dot_product_attention.py:186-289 (unfused
 // math: softmax(QK^T / sqrt(d)) V with GQA repeat :171-175), :312-329 (ViT, non-causal),
 // :374-390 (LLM causal).  Zig-zag chunk ownership: M/training/utils.py:329-341.
-#include "vita_common.h"
+#include "attn_args.h"
 #include <stdlib.h>
 #include <type_traits>
 
 namespace {
 
-constexpr int kMaxChunks = 32;
-
 // developer aid (VITA_ATTN_VARIANT bit 2): per-phase shader-clock totals, [group A|B][top, qk, sm_pv, barrier, n]
 __device__ unsigned long long g_attn_timing[16];
 constexpr int QTILE = 256;   // query rows per workgroup (8 waves x 32)
 constexpr int KVT = 64;      // keys per tile
-
-struct AttnArgs {
-  const bf16_t* q; int64_t q_bs, q_rs, q_hs, q_gs;   // q_gs: stride between kv groups' first query head
-  const bf16_t* k; int64_t k_bs, k_rs, k_hs;
-  const bf16_t* v; int64_t v_bs, v_rs, v_hs;
-  bf16_t* o; int64_t o_bs, o_rs, o_hs, o_gs;
-  float* lse;
-  int batch, n_q_heads, n_kv_heads;
-  int chunk_len, q_valid, kv_valid;      // rows; *_valid apply to the last chunk
-  int n_q_chunks, n_kv_chunks;
-  int tiles_per_q_chunk;                 // ceil(chunk_len / 256)
-  int n_q_rows;                          // total local q rows (for lse indexing)
-  float scale_log2e;                     // softmax_scale * log2(e)
-  const int* seg_start;                  // packed sequences: first key row of each query row's segment (or null)
-  int q_order[kMaxChunks];               // q chunks sorted by gid descending
-  int q_gid[kMaxChunks];
-  int kv_gid[kMaxChunks];
-  int64_t kv_row[kMaxChunks];
-};
 
 __device__ __forceinline__ float swap32_max(float x) {
   const unsigned xi = __float_as_uint(x);
@@ -565,6 +544,8 @@ extern "C" int vita_flash_attn_fwd(const vita_attn_params* p, void* stream) {
   const int64_t nblocks = (int64_t)p->batch * p->n_q_heads * p->n_q_chunks * a.tiles_per_q_chunk;
   if (nblocks > 0x7fffffff) return VITA_ERR_UNSUPPORTED;
   hipStream_t st = (hipStream_t)stream;
+  // d = 128 causal with whole 256-row / 64-key tiles: the 4 x 64-row in-wave-pipelined kernel (attn64.hip)
+  if (vita_attn64_eligible(a, p->head_dim, p->causal != 0)) return vita_attn64_launch(a, nblocks, st);
   if (p->head_dim == 128) return p->causal ? launch_attn<128, true>(a, nblocks, st) : launch_attn<128, false>(a, nblocks, st);
   return p->causal ? launch_attn<64, true>(a, nblocks, st) : launch_attn<64, false>(a, nblocks, st);
 }

@@ -1,0 +1,439 @@
+// Flash attention forward, d = 128, causal, whole tiles: 4 waves x 64 query rows, one wave per SIMD (gfx950 / MI355X).
+// The fast path of vita_flash_attn_fwd for the LLM prefill (plain causal and the zig-zag context-parallel chunk tables);
+// attn.hip keeps every other geometry (d = 64 ViT, non-causal, ragged tails, packed samples).
+//
+// Why a second structure (tools/hwprobe/attn_ladder.hip, attn64.hip; profiles/r02_hwprobe_*): with 32 query rows per wave every
+// K / V^T fragment read from LDS feeds ONE MFMA and two waves share a SIMD, where they hide only half of each other's VALU time;
+// with 64 rows per wave a fragment feeds two MFMAs and the only way to overlap the softmax with the matrix pipe is inside one
+// instruction stream — so this kernel is an in-wave software pipeline:
+//   * one workgroup = 4 waves = 256 query rows of ONE query head; a wave owns 64 rows = two 32-row blocks qb; 64-key tiles
+//   * register classes: O^T (2 x 4 x 16 = 128 registers) lives in AGPRs and is touched by MFMAs only (inline asm, "+a"); the
+//     Q fragments (64) are pinned in AGPRs and read from there as MFMA B operands; S^T (two tiles in flight, 2 x 64) comes
+//     from builtin MFMAs in VGPR form (this file is compiled with -mllvm -amdgpu-mfma-vgpr-form=1) so the softmax reads it
+//     without accumulator moves; -fno-slp-vectorize keeps the fp32 softmax math out of v_pk_* (it shares the matrix datapath)
+//   * phase 1: 32 MFMAs  S(t+1) = K(t+1) Q^T  ||  exp2 / row sum / bf16 pack of the last 8 - NF2 P fragments of tile t
+//     phase 2: 32 MFMAs  O += V(t)^T P(t)^T   ||  row maxima of tile t+1, the running-maximum decision, its first NF2 fragments
+//     the VALU work is dealt to the MFMA slots by weight; sched_barrier(0) after every slot keeps the order
+//   * LAZY running maximum: the maximum (and with it O and l) only moves when some row of the wave exceeds it by more than
+//     2^THR (THR = 8), so P <= 2^8 instead of <= 1 — bf16 / fp32 have the range, the relative rounding of P is unchanged — and
+//     the 400-instruction accumulator rescale (AGPR -> VGPR -> AGPR) leaves the steady state.  With exact maxima a 64-row
+//     wave hits it on ~20 % of the tiles of a 128K row (measured: 0.74 -> 0.90 PFLOP/s at 16K, 1.11 -> 1.19 at 128K)
+//   * K / V tiles HBM/L2 -> LDS by LDS-DMA (buffer_load ... lds: SGPR descriptor re-based per tile + the lane's 32-bit offset,
+//     no address VALU), separate K and V rings of two 16 KiB slots, one barrier per tile; attn.hip's swizzled layouts
+//     (conflict-free ds_read_b128 / ds_read_b64_tr_b16), the swizzle applied to the DMA's per-lane SOURCE address
+//   * masks: a tile of the diagonal chunk that reaches past the workgroup's first row is masked element-wise for every wave
+//     (tiles wholly past a wave's rows come out as exp2(-inf) = 0: no per-wave control flow in the pipeline)
+// Reference behaviour restated: M/core/transformer/dot_product_attention.py:186-289,374-390; zig-zag chunk ownership
+// M/training/utils.py:329-341.
+#include "attn_args.h"
+#include <stdlib.h>
+
+namespace {
+
+constexpr int D = 128, KVT = 64, QTILE = 256, ROWB = D * 2, TILEB = KVT * ROWB;     // 16 KiB per K (or V) tile
+constexpr int LDS_K = 0, LDS_V = 2 * TILEB, LDS_BYTES = 4 * TILEB;                   // K ring [2] | V ring [2]
+constexpr int NF2 = 3;                                                               // P fragments of tile t+1 done in phase 2
+constexpr int THR = 8;                                                               // lazy running maximum, log2 units
+
+typedef __attribute__((address_space(3))) const bf16x8 lds_bf16x8;
+typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
+typedef __attribute__((address_space(3))) char lds_char;
+typedef __attribute__((address_space(3))) void lvoid;
+
+__device__ __forceinline__ float swap32_max(float x) {
+  const unsigned xi = __float_as_uint(x);
+  auto r = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+  return fmaxf(__uint_as_float(r[0]), __uint_as_float(r[1]));
+}
+__device__ __forceinline__ float swap32_sum(float x) {
+  const unsigned xi = __float_as_uint(x);
+  auto r = __builtin_amdgcn_permlane32_swap(xi, xi, false, false);
+  return __uint_as_float(r[0]) + __uint_as_float(r[1]);
+}
+
+// ---- filler schedule: units dealt to the 32 MFMA slots of a phase by cumulative weight ---------------------------------
+// phase 2 units: 0..31 max3 steps (weight 1), 32..33 running-maximum decision (weight 6), then 8 * NF2 exp half-units
+// (half 0: two fma + two exp2, half 1: two row-sum adds + one bf16 pack); phase 1 units: 8 * (8 - NF2) exp half-units
+struct SlotMap { int first[33]; };
+constexpr int unit_w2(int u) { return u < 32 ? 2 : (u < 34 ? 12 : ((u & 1) ? 6 : 8)); }
+constexpr SlotMap make_map2() {
+  SlotMap m{};
+  const int n = 34 + 8 * NF2;
+  int tot = 0;
+  for (int u = 0; u < n; ++u) tot += unit_w2(u);
+  int acc = 0, u = 0;
+  for (int s = 0; s < 32; ++s) {
+    m.first[s] = u;
+    const int lim = (tot * (s + 1) + 31) / 32;
+    while (u < n && acc + unit_w2(u) <= lim) { acc += unit_w2(u); ++u; }
+  }
+  m.first[32] = n;
+  return m;
+}
+constexpr SlotMap make_map1() {
+  SlotMap m{};
+  const int n = 8 * (8 - NF2);
+  for (int s = 0; s <= 32; ++s) m.first[s] = (n * s) / 32;
+  return m;
+}
+
+// One kv tile position of the iteration space (all fields wave-uniform -> SGPRs); c == n_kv_chunks: end.
+struct TileIt {
+  int c, j, n;        // chunk, tile inside chunk, tiles to visit in this chunk
+  int diag;           // chunk c is the query tile's own chunk
+  const char* kp;     // first K / V row of the tile (running pointers: one 64-bit add per tile, no multiplies in the loop)
+  const char* vp;
+};
+
+__global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+
+  // ---- work decomposition (attn.hip's: kv head = block id % n_kv_heads = the XCD for 8 kv heads; heaviest query tiles first) ----
+  const int G = p.n_q_heads / p.n_kv_heads;
+  int bid = blockIdx.x;
+  const int kvh = bid % p.n_kv_heads; bid /= p.n_kv_heads;
+  const int hq = bid % G; bid /= G;
+  const int n_q_tiles = p.n_q_chunks * p.tiles_per_q_chunk;
+  const int qt_order = bid % n_q_tiles;
+  const int b = bid / n_q_tiles;
+  const int head = kvh * G + hq;
+  const int qc = p.q_order[qt_order / p.tiles_per_q_chunk];
+  const int qti = p.tiles_per_q_chunk - 1 - qt_order % p.tiles_per_q_chunk;
+  const int gq = p.q_gid[qc];
+  const int q_off_wg = qti * QTILE;                 // offset of this workgroup inside its chunk
+  const int q_off = q_off_wg + wave * 64;           // this wave's first row inside the chunk
+  const float scale_log2e = p.scale_log2e;
+
+  // ---- Q fragments (B operand of S^T = K Q^T): block qb, k-step ds: row q_off + 32 qb + l31, d = 16 ds + 8 hi .. + 7 ----------
+  bf16x8 qf[2][8];
+  {
+    const bf16_t* qp = p.q + (int64_t)b * p.q_bs + ((int64_t)qc * p.chunk_len + q_off + l31) * p.q_rs + (int64_t)kvh * p.q_gs +
+                       (int64_t)hq * p.q_hs + hi * 8;
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+      for (int ds = 0; ds < 8; ++ds) qf[qb][ds] = *reinterpret_cast<const bf16x8*>(qp + (int64_t)32 * qb * p.q_rs + ds * 16);
+  }
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int ds = 0; ds < 8; ++ds) asm volatile("" : "+a"(qf[qb][ds]));      // live in AGPRs from here on
+
+  // ---- LDS fragment offsets (attn.hip's layouts) ----------------------------------------------------------------------------
+  unsigned koff[8], voff[4];
+#pragma unroll
+  for (int ds = 0; ds < 8; ++ds) koff[ds] = l31 * ROWB + (((2 * ds + hi) ^ (l31 & 15)) << 4);       // + 32 kb rows: immediate
+  {
+    const int g16 = lane >> 4, i16 = lane & 15, key_l = 4 * (g16 >> 1) + (i16 >> 2);
+#pragma unroll
+    for (int db = 0; db < 4; ++db) {
+      const int col = 32 * db + 16 * (g16 & 1) + 4 * (i16 & 3);
+      voff[db] = key_l * ROWB + (((col >> 4) ^ ((key_l & 3) << 1)) << 5) + (col & 15) * 2;
+    }
+  }
+  // ---- LDS-DMA: wave w moves pieces 4w .. 4w+3 (1 KiB = 4 rows) of K and of V; swizzle on the SOURCE address ---------------
+  unsigned dk_off[4], dv_off[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int row = (wave * 4 + q) * 4 + (lane >> 4), ps = lane & 15;
+    const int ks = ps ^ (row & 15);
+    const int vs = (((ps >> 1) ^ ((row & 3) << 1)) << 1) | (ps & 1);
+    dk_off[q] = (unsigned)((row * p.k_rs + ks * 8) * 2);     // bytes inside the tile (64 rows x row stride < 2^32)
+    dv_off[q] = (unsigned)((row * p.v_rs + vs * 8) * 2);
+  }
+  const char* kbase = (const char*)(p.k + (int64_t)b * p.k_bs + (int64_t)kvh * p.k_hs);
+  const char* vbase = (const char*)(p.v + (int64_t)b * p.v_bs + (int64_t)kvh * p.v_hs);
+  const int k_tile_bytes = (int)(p.k_rs * 2 * KVT), v_tile_bytes = (int)(p.v_rs * 2 * KVT);
+  // LDS address of this wave's first piece in K / V ring slot 0.  The descriptor is re-based on the tile's first row: no
+  // 4 GiB limit on the K / V buffers, no address VALU.  `opaque` keeps the 16 piece addresses from being hoisted into 16 SGPRs.
+  const unsigned lds_kw = lds0 + LDS_K + wave * 4096, lds_vw = lds0 + LDS_V + wave * 4096;
+  auto dma_k = [&](const TileIt& t, int slot) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)t.kp, 0, 0x7fffffff, 0x00020000);
+    unsigned base = lds_kw;
+    asm volatile("" : "+s"(base));
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lvoid*)(uintptr_t)(base + slot * TILEB + q * 1024), 16, dk_off[q], 0, 0, 0);
+  };
+  auto dma_v = [&](const TileIt& t, int slot) __attribute__((always_inline)) {
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)t.vp, 0, 0x7fffffff, 0x00020000);
+    unsigned base = lds_vw;
+    asm volatile("" : "+s"(base));
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lvoid*)(uintptr_t)(base + slot * TILEB + q * 1024), 16, dv_off[q], 0, 0, 0);
+  };
+
+  // ---- tile iterator -----------------------------------------------------------------------------------------------------------
+  const int tiles_per_chunk = p.chunk_len / KVT;
+  auto enter_chunk = [&](TileIt& t) __attribute__((always_inline)) {   // skip chunks with nothing to visit
+    while (t.c < p.n_kv_chunks) {
+      const int gk = p.kv_gid[t.c];
+      t.diag = gk == gq;
+      t.n = gk < gq ? tiles_per_chunk : (gk > gq ? 0 : q_off_wg / KVT + 4);
+      if (t.n > 0) {
+        const int64_t crow = p.kv_row[t.c];
+        t.kp = kbase + crow * p.k_rs * 2;
+        t.vp = vbase + crow * p.v_rs * 2;
+        t.j = 0;
+        return;
+      }
+      ++t.c;
+    }
+  };
+  auto advance = [&](TileIt& t) __attribute__((always_inline)) {
+    t.kp += k_tile_bytes;
+    t.vp += v_tile_bytes;
+    if (++t.j == t.n) { ++t.c; enter_chunk(t); }
+  };
+  int n_tiles = 0;                                   // a multiple of 4 (chunk_len % 256 == 0)
+  for (int c = 0; c < p.n_kv_chunks; ++c) {
+    const int gk = p.kv_gid[c];
+    n_tiles += gk < gq ? tiles_per_chunk : (gk > gq ? 0 : q_off_wg / KVT + 4);
+  }
+
+  // ---- state ----------------------------------------------------------------------------------------------------------
+  f32x16 o[2][4];                                    // O^T[qb][db]: d = 32 db + (r & 3) + 8 (r >> 2) + 4 hi, row 32 qb + l31 (AGPRs)
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int r = 0; r < 16; ++r) o[qb][db][r] = 0.f;
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+    for (int db = 0; db < 4; ++db) asm volatile("" : "+a"(o[qb][db]));
+  f32x16 sb[2][2][2];                                // S^T[parity][qb][kb]: key 32 kb + (r & 3) + 8 (r >> 2) + 4 hi
+  unsigned pk[2][2][4][4];                           // packed P^T[parity][qb][frag f][4 dwords]; frag f = regs 8 (f & 1) .. of kb = f >> 1
+  float m_run[2] = {-1.0e30f, -1.0e30f}, l_run[2] = {0.f, 0.f}, m_neg[2], alpha[2] = {1.f, 1.f}, mxc[4];
+  float ea = 0.f, eb = 0.f, mx0_keep = 0.f;
+
+  constexpr SlotMap MAP1 = make_map1(), MAP2 = make_map2();
+
+  // exp half-units (64 per tile): h -> fragment g = h >> 3 (need order of P V: g = 2 f + qb), element pair pr = (h >> 1) & 3;
+  // half 0: the two fma + exp2 of the pair, half 1: row sum, bf16 pack (an exp2 result is never consumed by the next instruction)
+  auto exp_half = [&](int par, int h) __attribute__((always_inline)) {
+    const int g = h >> 3, pr = (h >> 1) & 3, qb = g & 1, f = g >> 1, kb = f >> 1, r = 8 * (f & 1) + 2 * pr;
+    if ((h & 1) == 0) {
+      ea = __builtin_amdgcn_exp2f(fmaf(sb[par][qb][kb][r], scale_log2e, m_neg[qb]));
+      eb = __builtin_amdgcn_exp2f(fmaf(sb[par][qb][kb][r + 1], scale_log2e, m_neg[qb]));
+    } else {
+      l_run[qb] += ea;
+      l_run[qb] += eb;
+      pk[par][qb][f][pr] = pack_bf16x2(ea, eb);
+      asm volatile("" :: "v"(pk[par][qb][f][pr]), "v"(l_run[qb]));              // computed HERE (no sinking past the phase)
+    }
+  };
+  // the running-maximum decision of a tile: unit 32 keeps block 0's maximum, unit 33 decides for both blocks with ONE
+  // wave-uniform flag (grow = some row exceeds its running maximum by more than 2^THR; the first tile always grows)
+  auto max_unit = [&](int par, int u) __attribute__((always_inline)) {
+    if (u < 32) {                                    // max3 steps: four chains (qb, kb): chain c = u & 3, step u >> 2
+      const int c = u & 3, st = u >> 2, qb2 = c >> 1, kb2 = c & 1, r = 2 * st;
+      const float a = sb[par][qb2][kb2][r], bb = sb[par][qb2][kb2][r + 1];
+      mxc[c] = st == 0 ? fmaxf(a, bb) : fmaxf(fmaxf(a, bb), mxc[c]);
+    } else if (u == 32) {
+      mx0_keep = swap32_max(fmaxf(mxc[0], mxc[1])) * scale_log2e;
+    } else {
+      const float mx1 = swap32_max(fmaxf(mxc[2], mxc[3])) * scale_log2e;
+      const bool grow = __any((mx1 > m_run[1] + (float)THR) || (mx0_keep > m_run[0] + (float)THR));
+#pragma unroll
+      for (int qb2 = 0; qb2 < 2; ++qb2) {
+        const float mb = qb2 ? mx1 : mx0_keep;
+        const float m_new = grow ? fmaxf(m_run[qb2], mb) : m_run[qb2];
+        alpha[qb2] = __builtin_amdgcn_exp2f(m_run[qb2] - m_new);
+        m_run[qb2] = m_new;
+        m_neg[qb2] = -m_new;
+        l_run[qb2] *= alpha[qb2];
+      }
+    }
+  };
+  auto k_frag = [&](unsigned kslot, int i) __attribute__((always_inline)) {        // i = 2 ds + kb
+    return *(lds_bf16x8*)(uintptr_t)(kslot + koff[i >> 1] + (i & 1) * 32 * ROWB);
+  };
+  auto v_frag = [&](unsigned vslot, int i) __attribute__((always_inline)) {        // i = 4 t + db
+    const unsigned va = vslot + voff[i & 3] + 16 * (i >> 2) * ROWB;
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(va));
+    const s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(va + 8 * ROWB));
+    typedef __attribute__((ext_vector_type(8))) short s16x8;
+    const s16x8 ac = __builtin_shufflevector(a, c, 0, 1, 2, 3, 4, 5, 6, 7);
+    return __builtin_bit_cast(bf16x8, ac);
+  };
+  // S(buffer `dst`) = K(kslot) Q^T: slot = 4 ds + 2 kb + qb; K fragment (kb, ds) read two fragments ahead (ring of four);
+  // FILL: the exp half-units 8 NF2 .. 63 of tile `par` go behind the MFMAs
+  auto qk_phase = [&](int dst, unsigned kslot, bool fill, int par) __attribute__((always_inline)) {
+    bf16x8 kr[4];
+    kr[0] = k_frag(kslot, 0); kr[1] = k_frag(kslot, 1);
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      const int i = s >> 1, qb = s & 1, ds = i >> 1, kb = i & 1;
+      if (qb == 0 && i + 2 < 16) kr[(i + 2) & 3] = k_frag(kslot, i + 2);
+      if (ds == 0) {
+        f32x16 z;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) z[r] = 0.f;
+        sb[dst][qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[i & 3], qf[qb][ds], z, 0, 0, 0);
+      } else {
+        sb[dst][qb][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(kr[i & 3], qf[qb][ds], sb[dst][qb][kb], 0, 0, 0);
+      }
+      if (fill) {
+#pragma unroll
+        for (int u = MAP1.first[s]; u < MAP1.first[s + 1]; ++u) exp_half(par, 8 * NF2 + u);
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+  };
+  // the rest of tile `par`'s softmax without a next tile to multiply (last tile)
+  auto finish_sm = [&](int par) __attribute__((always_inline)) {
+#pragma unroll
+    for (int u = 8 * NF2; u < 64; ++u) exp_half(par, u);
+  };
+  // O += V(vslot)^T P(par)^T  ||  (has_next) maxima / running-maximum decision of tile par ^ 1 and its first NF2 fragments
+  auto pv_phase = [&](int par, unsigned vslot, bool has_next) __attribute__((always_inline)) {
+    bf16x8 vr[4];
+    vr[0] = v_frag(vslot, 0); vr[1] = v_frag(vslot, 1);
+#pragma unroll
+    for (int s = 0; s < 32; ++s) {
+      const int i = s >> 1, qb = s & 1, t = i >> 2, db = i & 3;
+      if (qb == 0 && i + 2 < 16) vr[(i + 2) & 3] = v_frag(vslot, i + 2);
+      const u32x4 pw = {pk[par][qb][t][0], pk[par][qb][t][1], pk[par][qb][t][2], pk[par][qb][t][3]};
+      const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o[qb][db]) : "v"(vr[i & 3]), "v"(pf));
+      if (has_next) {
+#pragma unroll
+        for (int u = MAP2.first[s]; u < MAP2.first[s + 1]; ++u) {
+          if (u < 34) max_unit(par ^ 1, u);
+          else exp_half(par ^ 1, u - 34);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+  // causal mask of a diagonal-chunk tile (kv_off = its offset inside the chunk) in buffer `par`.  Pure VALU arithmetic
+  // (s += min(lim - key, 0) * 3e38: exp2 of it is 0, a running maximum never sees it) — compare-and-select would park 64
+  // lane masks in SGPR pairs and the per-register key constants in VGPRs, and that pressure spills into the steady state.
+  auto mask_tile = [&](int par, int kv_off) __attribute__((always_inline)) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int base = q_off + 32 * qb + l31 - kv_off - 4 * hi;                 // key <= lim visible; key = const(kb, r) + 4 hi
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kc = 32 * kb + (r & 3) + 8 * (r >> 2);
+          const float pen = fminf((float)(base - kc), 0.0f);
+          sb[par][qb][kb][r] = fmaf(pen, 3.0e38f, sb[par][qb][kb][r]);
+        }
+    }
+  };
+  // O *= alpha (rare: only when a running maximum moved); every P V MFMA that precedes it has been issued
+  auto rescale_o = [&]() __attribute__((always_inline)) {
+    if (!__all(alpha[0] == 1.0f && alpha[1] == 1.0f)) {
+      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                       // asm MFMA -> accumulator read
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb)
+#pragma unroll
+        for (int db = 0; db < 4; ++db) {
+#pragma unroll
+          for (int r = 0; r < 16; ++r) o[qb][db][r] *= alpha[qb];
+          asm volatile("" : "+a"(o[qb][db]));
+        }
+      asm volatile("s_nop 7" ::: "memory");                                     // accumulator write -> asm MFMA read
+    }
+  };
+  auto needs_mask = [&](const TileIt& t) __attribute__((always_inline)) { return t.diag && t.j * KVT + KVT - 1 > q_off_wg; };
+
+  // ---- prologue: K(0), V(0), K(1) -> LDS; S(0); the start of its softmax -----------------------------------------------------
+  TileIt cur;
+  cur.c = 0; cur.j = 0; cur.n = 0; cur.diag = 0; cur.kp = kbase; cur.vp = vbase;
+  enter_chunk(cur);
+  TileIt nx1 = cur;
+  advance(nx1);
+  dma_k(cur, 0); dma_v(cur, 0);
+  dma_k(nx1, 1);                                     // n_tiles >= 4
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  qk_phase(0, lds0 + LDS_K, false, 0);
+  __syncthreads();                                  // every wave has read K(0): its ring slot may be refilled
+  if (needs_mask(cur)) mask_tile(0, cur.j * KVT);
+#pragma unroll
+  for (int u = 0; u < 34 + 8 * NF2; ++u) {
+    if (u < 34) max_unit(0, u);
+    else exp_half(0, u - 34);
+  }
+  // (O is zero: no rescale for tile 0)
+
+  // ---- main loop: two tiles per trip (the S / P buffer parity is a compile-time constant); n_tiles is a multiple of 4 ----------
+  // full(par): `cur` sits in buffer par; K(t+2) -> K ring slot par, V(t+1) -> V ring slot par ^ 1; S(t+1) -> buffer par ^ 1
+  auto full = [&](int par, bool more_k) __attribute__((always_inline)) {
+    TileIt nx2 = nx1;
+    if (more_k) { advance(nx2); dma_k(nx2, par); }  // K(t) in that slot was last read before the previous barrier
+    dma_v(nx1, par ^ 1);
+    qk_phase(par ^ 1, lds0 + LDS_K + (par ^ 1) * TILEB, true, par);
+    if (needs_mask(nx1)) mask_tile(par ^ 1, nx1.j * KVT);
+    pv_phase(par, lds0 + LDS_V + par * TILEB, true);
+    rescale_o();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    nx1 = nx2;
+  };
+  for (int t = 0; t + 2 < n_tiles; t += 2) {
+    full(0, true);
+    full(1, true);
+  }
+  full(0, false);
+  finish_sm(1);                                      // last tile: the rest of its softmax, then P V
+  pv_phase(1, lds0 + LDS_V + TILEB, false);
+
+  // ---- epilogue: O[row][head][d] = O^T / l, lse ------------------------------------------------------------------------------
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+#pragma unroll
+  for (int qb = 0; qb < 2; ++qb) {
+    const float l_tot = swap32_sum(l_run[qb]);
+    const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
+    const int64_t orow = (int64_t)qc * p.chunk_len + q_off + 32 * qb + l31;
+    bf16_t* op = p.o + (int64_t)b * p.o_bs + orow * p.o_rs + (int64_t)kvh * p.o_gs + (int64_t)hq * p.o_hs;
+#pragma unroll
+    for (int db = 0; db < 4; ++db)
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const int d = 32 * db + 8 * rg + 4 * hi;
+        const u32x2 w = {pack_bf16x2(o[qb][db][rg * 4 + 0] * inv, o[qb][db][rg * 4 + 1] * inv),
+                         pack_bf16x2(o[qb][db][rg * 4 + 2] * inv, o[qb][db][rg * 4 + 3] * inv)};
+        *reinterpret_cast<u32x2*>(op + d) = w;
+      }
+    if (p.lse && hi == 0) {
+      const float lse = l_tot > 0.f ? (m_run[qb] + log2f(l_tot)) * 0.69314718055994530942f : -INFINITY;
+      p.lse[((int64_t)b * p.n_q_heads + head) * p.n_q_rows + orow] = lse;
+    }
+  }
+}
+
+}  // namespace
+
+bool vita_attn64_eligible(const AttnArgs& a, int head_dim, bool causal) {
+  if (head_dim != 128 || !causal || a.seg_start) return false;
+  if (a.chunk_len % QTILE || a.q_valid != a.chunk_len || a.kv_valid != a.chunk_len) return false;
+  // a tile's 64 rows x row stride must fit the 32-bit lane offset of the DMA
+  if (a.k_rs * 2 * KVT >= (1ll << 31) || a.v_rs * 2 * KVT >= (1ll << 31)) return false;
+  for (int i = 0; i < a.n_q_chunks; ++i) {           // the pipeline is primed with >= 4 tiles: every query chunk needs its diagonal
+    bool found = false;
+    for (int j = 0; j < a.n_kv_chunks; ++j) found = found || a.kv_gid[j] == a.q_gid[i];
+    if (!found) return false;
+  }
+  const char* e = getenv("VITA_ATTN64");
+  return !(e && e[0] == '0');
+}
+
+int vita_attn64_launch(const AttnArgs& a, int64_t nblocks, hipStream_t st) {
+  static bool attr_set = false;
+  if (!attr_set) {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    attr_set = true;
+  }
+  hipLaunchKernelGGL(flash_fwd64_kernel, dim3((unsigned)nblocks), dim3(256), LDS_BYTES, st, a);
+  return vita_check_launch();
+}

@@ -25,6 +25,17 @@ __global__ void rope_table_kernel(const int64_t* __restrict__ pos, const float* 
   sin_out[i] = f32_to_bf16(sinf(f));
 }
 
+// Megatron hands apply_rotary_pos_emb the fp32 angles `freqs` [s, 1, 1, dim] (emb = cat(freqs, freqs)): cos/sin of the first half
+__global__ void rope_cos_sin_kernel(const float* __restrict__ freqs, int64_t row_stride, bf16_t* __restrict__ cos_out,
+                                    bf16_t* __restrict__ sin_out, int64_t n, int half_dim) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * half_dim) return;
+  const int64_t r = i / half_dim;
+  const float f = freqs[r * row_stride + (i - r * half_dim)];
+  cos_out[i] = f32_to_bf16(cosf(f));
+  sin_out[i] = f32_to_bf16(sinf(f));
+}
+
 __global__ __launch_bounds__(256) void rope_apply_kernel(bf16_t* __restrict__ t, int64_t rows,
                                                          int heads, int head_dim,
                                                          int64_t row_stride, int64_t head_stride,
@@ -105,6 +116,16 @@ extern "C" int vita_rope_table(const int64_t* pos, const float* inv_freq, void* 
   hipLaunchKernelGGL(rope_table_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0,
                      (hipStream_t)stream, pos, inv_freq, (bf16_t*)cos_out, (bf16_t*)sin_out, n,
                      half_dim);
+  return vita_check_launch();
+}
+
+extern "C" int vita_rope_cos_sin(const float* freqs, int64_t row_stride, void* cos_out, void* sin_out, int64_t n,
+                                 int half_dim, void* stream) {
+  if (!freqs || !cos_out || !sin_out || n < 0 || half_dim <= 0 || row_stride < half_dim) return VITA_ERR_INVALID_ARG;
+  if (n == 0) return VITA_OK;
+  const int64_t total = n * half_dim;
+  hipLaunchKernelGGL(rope_cos_sin_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, freqs,
+                     row_stride, (bf16_t*)cos_out, (bf16_t*)sin_out, n, half_dim);
   return vita_check_launch();
 }
 

@@ -19,6 +19,44 @@ import torch.distributed as dist
 from . import ops, parallel_state as mpu
 
 
+class HipDotProductAttention(torch.nn.Module):
+    """`core_attention` submodule for the layer specs (gpt_layer_specs.py): Megatron's constructor
+    `(config, layer_number, attn_mask_type, attention_type, attention_dropout=None)`, forward
+    `(query, key, value, attention_mask, attn_mask_type=None, packed_seq_params=None)` -> [sq, b, hp]
+    (M/core/transformer/dot_product_attention.py:153,165,285-289).  No parameters; autograd through FlashAttnFn."""
+
+    def __init__(self, config, layer_number: int, attn_mask_type, attention_type: str = "self", attention_dropout: float = None):
+        super().__init__()
+        self.config, self.layer_number = config, max(1, layer_number)
+        self.attn_mask_type, self.attention_type = attn_mask_type, attention_type
+        tp = mpu.get_tensor_model_parallel_world_size()
+        kv = getattr(config, "num_query_groups", None) or config.num_attention_heads
+        self.num_attention_heads_per_partition = config.num_attention_heads // tp
+        self.num_query_groups_per_partition = kv // tp
+        self.hidden_size_per_attention_head = config.kv_channels
+        p = config.attention_dropout if attention_dropout is None else attention_dropout
+        if p and p > 0.0:
+            raise NotImplementedError("attention dropout > 0 is not on the Long-VITA path (--attention-dropout 0.0)")
+        causal = "causal" in str(attn_mask_type).lower()
+        self._impl = DotProductAttention(self.num_attention_heads_per_partition, self.num_query_groups_per_partition,
+                                         self.hidden_size_per_attention_head, causal=causal)
+
+    def forward(self, query, key, value, attention_mask=None, attn_mask_type=None, packed_seq_params=None):
+        needs_grad = torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad)
+        if not needs_grad:
+            return self._impl.forward(query, key, value, attention_mask, attn_mask_type, packed_seq_params)
+        assert packed_seq_params is None, (
+            "Packed sequence is not supported by DotProductAttention."
+            "Please use TEDotProductAttention instead.")
+        if mpu.get_context_parallel_world_size() > 1 or not self._impl.causal:
+            raise NotImplementedError("autograd through the module is built for causal CP = 1; the context-parallel training "
+                                      "step is long_vita_amd.training.TrainStep")
+        from .autograd_fns import FlashAttnFn
+        sq, b, np_, hn = query.shape
+        out = FlashAttnFn.apply(query.transpose(0, 1), key.transpose(0, 1), value.transpose(0, 1), self._impl.softmax_scale)
+        return out.transpose(0, 1).reshape(sq, b, np_ * hn)
+
+
 class DotProductAttention:
     def __init__(self, num_attention_heads: int, num_query_groups: int, kv_channels: int, causal: bool = True,
                  softmax_scale: Optional[float] = None):

@@ -51,10 +51,10 @@ class GPTVLModel:
     def __init__(self, cfg: GPTConfig, params: dict, external_feature_model=None):
         self.cfg, self.p = cfg, params
         self.external_feature_model = external_feature_model
-        self.embedding = LanguageModelEmbedding(params["embed"])
+        self.embedding = LanguageModelEmbedding.from_weight(params["embed"])
         self.rotary_pos_emb = RotaryEmbedding(cfg.head_dim, rotary_base=cfg.rope_theta, device=params["embed"].device)
         self.core_attention = DotProductAttention(cfg.heads, cfg.kv_groups, cfg.head_dim, causal=True)
-        self.output_layer = ColumnParallelLinear(params["lm_head"], bias=None)
+        self.output_layer = ColumnParallelLinear.from_weight(params["lm_head"], bias=None)
         self._ws = {}
         # K/V all-gather messages per layer (split by kv head; gather j+1 overlaps attention j)
         self.kv_split = 4 if cfg.kv_groups % 4 == 0 else (2 if cfg.kv_groups % 2 == 0 else 1)

@@ -247,19 +247,20 @@ class Norm:
         raise Exception("Only LayerNorm and RMSNorm are curently supported")
 
 
-class LayerNormColumnParallelLinear(_TEStateMixin, torch.nn.Module):
+class LayerNormColumnParallelLinear(ColumnParallelLinear):
     """norm(x) -> column-parallel linear in one module (TELayerNormColumnParallelLinear): vita_rmsnorm_fwd -> vita_gemm_bf16.
-    Under sequence parallelism the norm runs on the rank's sequence shard and the normed rows are all-gathered (TE order)."""
+    TE's flat parameter names: `layer_norm_weight` (`layer_norm_bias`) beside `weight`, `bias`.  Under sequence parallelism
+    the norm runs on the rank's sequence shard and the normed rows are all-gathered inside the linear (TE's order)."""
 
     def __init__(self, input_size: int, output_size: int, *, config, init_method: Optional[Callable], gather_output: bool,
                  bias: bool, skip_bias_add: bool, is_expert: bool, skip_weight_param_allocation: bool = False,
                  tp_comm_buffer_name: str = None):
-        super().__init__()
         if gather_output:
             raise ValueError("Transformer Engine linear layers do not support gather_output = True")
         if is_expert:
             raise ValueError("Transformer Engine linear layers do not yet support MoE")
-        self.config = config
+        super().__init__(input_size, output_size, config=config, init_method=init_method, bias=bias, gather_output=False,
+                         skip_bias_add=skip_bias_add, skip_weight_param_allocation=skip_weight_param_allocation)
         self.eps = config.layernorm_epsilon
         self.normalization = getattr(config, "normalization", "RMSNorm")
         self.layer_norm_weight = Parameter(torch.ones_like(_alloc(config, input_size)))
@@ -269,14 +270,6 @@ class LayerNormColumnParallelLinear(_TEStateMixin, torch.nn.Module):
             setattr(self.layer_norm_bias, "sequence_parallel", getattr(config, "sequence_parallel", False))
         else:
             self.register_parameter("layer_norm_bias", None)
-        inner = ColumnParallelLinear(input_size, output_size, config=config, init_method=init_method, bias=bias,
-                                     gather_output=False, skip_bias_add=skip_bias_add,
-                                     skip_weight_param_allocation=skip_weight_param_allocation)
-        # TE's flat parameter names (`weight`, `bias` beside `layer_norm_weight`)
-        self.weight, self.bias = inner.weight, inner.bias
-        if inner.bias is None:
-            self.register_parameter("bias", None)
-        self._linear = [inner]                      # not a submodule: its parameters are registered here
 
     def forward(self, x: torch.Tensor):
         if self.normalization == "RMSNorm":
@@ -285,9 +278,7 @@ class LayerNormColumnParallelLinear(_TEStateMixin, torch.nn.Module):
             if torch.is_grad_enabled() and x.requires_grad:
                 raise NotImplementedError("LayerNorm backward is not built (decoder layers use RMSNorm)")
             xn = ops.layernorm(x, self.layer_norm_weight, self.layer_norm_bias, self.eps)
-        lin = self._linear[0]
-        lin.weight, lin.bias = self.weight, self.bias      # (re-bound after load_state_dict / .to())
-        return lin(xn)
+        return super().forward(xn)
 
 
 def get_bias_dropout_add(training: bool, fused: bool):

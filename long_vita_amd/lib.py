@@ -21,7 +21,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libvita_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "vita_hip.h")
 
-ABI_VERSION = 10
+ABI_VERSION = 11
 VITA_OK = 0
 VITA_ERR_INVALID_ARG = -1
 VITA_ERR_UNSUPPORTED = -2
@@ -112,6 +112,7 @@ PROTOTYPES = {
     "vita_rmsnorm_fwd": (_i, [_p, _p, _p, _p, _l, _i, _f, _p]),
     "vita_layernorm_fwd": (_i, [_p, _p, _p, _p, _l, _i, _f, _p]),
     "vita_rope_table": (_i, [_p, _p, _p, _p, _l, _i, _p]),
+    "vita_rope_cos_sin": (_i, [_p, _l, _p, _p, _l, _i, _p]),
     "vita_rope_apply": (_i, [_p, _l, _i, _i, _l, _l, _p, _p, _i, _p]),
     "vita_rope_qkv_fwd": (_i, [_p, _l, _i, _i, _i, _p, _p, _p, _i, _p]),
     "vita_row_gather": (_i, [_p, _l, _p, _p, _l, _i, _i, _p, _p]),

@@ -13,10 +13,15 @@ reference patches on the prefill path:
   megatron.inference.text_generation.forward_step.ForwardStep.__init__                          (:145, wrapper carrying
         `external_inputs` into the InferenceParams)
 
-Targets of the reference that stay Megatron-resident (not arithmetic of this path): the two layer-spec builders and
-TransformerConfig (:81-97 — they need Megatron's ModuleSpec classes; INTEGRATION.md §2 shows the spec a maintainer returns),
-ensure_directory_exists, tokenisation, beam search, the pipelining forward steps (identical to upstream), parse_args,
-build_tokenizer.  `tests/test_cpu_host.py` checks every name registered here against the reference's own call sites
+  megatron.core.models.gpt.gpt_layer_specs.get_gpt_layer_local_spec / get_gpt_layer_with_transformer_engine_spec   (:81-88;
+        gpt_layer_specs.py of this package: the same ModuleSpec trees with HIP-backed leaves — norm + column-parallel linear,
+        row-parallel linear, core attention — so a Megatron-built decoder layer runs every kernel through libvita_hip.so)
+
+LanguageModelEmbedding, ColumnParallelLinear and the spec leaves are `torch.nn.Module`s with Megatron's constructor
+signatures, Parameters under Megatron's names and autograd (layers.py, language_model_embedding.py, autograd_fns.py).
+Targets of the reference that stay Megatron-resident (not arithmetic of this path): TransformerConfig (:96-97, extra
+dataclass fields), ensure_directory_exists, tokenisation, beam search, the pipelining forward steps (identical to
+upstream), parse_args, build_tokenizer.  `tests/test_cpu_host.py` checks every name registered here against the reference's own call sites
 (fixture adaptor_targets.pt).
 
 Megatron-LM is not installable in the build container, so the registration is
@@ -85,12 +90,16 @@ def generate_tokens_probs_and_return_on_first_stage(model, tokens, lengths, retu
 
 
 def _targets():
+    from .gpt_layer_specs import get_gpt_layer_local_spec, get_gpt_layer_with_transformer_engine_spec
     from .language_model_embedding import LanguageModelEmbedding
     from .layers import ColumnParallelLinear
     from .rotary_pos_embedding import apply_rotary_pos_emb
     return [
         ("megatron.core.transformer.dot_product_attention.DotProductAttention.forward",
          dot_product_attention_forward_wrapper),
+        ("megatron.core.models.gpt.gpt_layer_specs.get_gpt_layer_local_spec", get_gpt_layer_local_spec),
+        ("megatron.core.models.gpt.gpt_layer_specs.get_gpt_layer_with_transformer_engine_spec",
+         get_gpt_layer_with_transformer_engine_spec),
         ("megatron.core.models.common.embeddings.language_model_embedding.LanguageModelEmbedding",
          LanguageModelEmbedding),
         ("megatron.core.tensor_parallel.layers.ColumnParallelLinear", ColumnParallelLinear),
@@ -118,6 +127,14 @@ def exe_adaptation(create_dummy: bool = False) -> bool:
     for name, obj in _targets():
         aspm.register_patch(name, obj, create_dummy=create_dummy)
     aspm.apply_patches()
+    # the modules read tensor / context parallel sizes through long_vita_amd.parallel_state: under a real Megatron that
+    # state IS megatron.core.parallel_state (groups created by Megatron's initialize_model_parallel)
+    try:
+        from importlib import import_module
+        from . import parallel_state
+        parallel_state.bind_megatron(import_module("megatron.core.parallel_state"))
+    except Exception:          # noqa: BLE001  (dummy / partial Megatron trees in tests)
+        pass
     return True
 
 

@@ -86,6 +86,19 @@ def rope_table(positions: torch.Tensor, inv_freq: torch.Tensor):
     return cos, sin
 
 
+def rope_cos_sin(freqs: torch.Tensor):
+    """Megatron's fp32 angles `freqs` [s, 1, 1, dim] (RotaryEmbedding.forward: cat(freqs, freqs)) -> cos / sin bf16 [s, dim/2]."""
+    if freqs.dtype != torch.float32 or freqs.dim() != 4 or freqs.shape[1] != 1 or freqs.shape[2] != 1:
+        raise ValueError("freqs must be fp32 [s, 1, 1, dim]")
+    f = freqs if freqs.is_contiguous() else freqs.contiguous()
+    n, dim = f.shape[0], f.shape[3]
+    cos = torch.empty((n, dim // 2), dtype=BF16, device=f.device)
+    sin = torch.empty_like(cos)
+    _L.check(_L.load().vita_rope_cos_sin(_dev(f, "freqs", torch.float32), dim, _dev(cos, "cos"), _dev(sin, "sin"), n, dim // 2,
+                                         _stream()), "vita_rope_cos_sin")
+    return cos, sin
+
+
 def rope_apply_(t: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, sign: int = 1) -> torch.Tensor:
     """In-place apply_rotary_pos_emb_bshd on t [rows, heads, d] (any row/head stride, d contiguous)."""
     if t.dim() != 3 or t.stride(2) != 1:

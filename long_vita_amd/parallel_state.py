@@ -59,19 +59,45 @@ def initialize_model_parallel(context_parallel_size: Optional[int] = None, group
             _S.group, _S.size, _S.rank = g, cp, ranks.index(me)
 
 
+_MEGATRON = None
+
+
+def bind_megatron(mcore_parallel_state) -> None:
+    """Under a real Megatron (megatron_adaptor.exe_adaptation) the accessors below answer from
+    megatron.core.parallel_state whenever its model-parallel groups are initialised."""
+    global _MEGATRON
+    _MEGATRON = mcore_parallel_state
+
+
+def _mg():
+    m = _MEGATRON
+    if m is not None and getattr(m, "model_parallel_is_initialized", lambda: False)():
+        return m
+    return None
+
+
 def set_tensor_parallel_state(size: int, rank: int, group=None) -> None:
     _S.tp_group, _S.tp_size, _S.tp_rank = group, size, rank
 
 
 def get_tensor_model_parallel_world_size() -> int:
+    m = _mg()
+    if m is not None:
+        return m.get_tensor_model_parallel_world_size()
     return _S.tp_size
 
 
 def get_tensor_model_parallel_rank() -> int:
+    m = _mg()
+    if m is not None:
+        return m.get_tensor_model_parallel_rank()
     return _S.tp_rank
 
 
 def get_tensor_model_parallel_group():
+    m = _mg()
+    if m is not None:
+        return m.get_tensor_model_parallel_group()
     return _S.tp_group
 
 
@@ -86,14 +112,23 @@ def destroy_model_parallel() -> None:
 
 
 def get_context_parallel_world_size() -> int:
+    m = _mg()
+    if m is not None:
+        return m.get_context_parallel_world_size()
     return _S.size
 
 
 def get_context_parallel_rank() -> int:
+    m = _mg()
+    if m is not None:
+        return m.get_context_parallel_rank()
     return _S.rank
 
 
 def get_context_parallel_group():
+    m = _mg()
+    if m is not None:
+        return m.get_context_parallel_group()
     return _S.group
 
 

@@ -48,13 +48,35 @@ class RotaryEmbedding:
         return local_rows * mpu.get_context_parallel_world_size()
 
 
-def apply_rotary_pos_emb(t: torch.Tensor, cos_sin, config=None, cu_seqlens=None) -> torch.Tensor:
-    """apply_rotary_pos_emb (:232-259) for t [s, b(=1), heads, d]; rotates in place and returns t."""
+_COS_SIN_CACHE = {"key": None, "val": None}
+
+
+def _cos_sin(freqs):
+    """`freqs` is either this module's (cos, sin) pair or Megatron's fp32 angle tensor [s, 1, 1, dim]
+    (rotary_pos_embedding.py:106-108), which every one of the 48 layers passes again: the bf16 tables are built once per
+    tensor (keyed by storage, shape and version counter)."""
+    if isinstance(freqs, (tuple, list)):
+        return freqs
+    key = (freqs.data_ptr(), tuple(freqs.shape), freqs._version, freqs.device)
+    if _COS_SIN_CACHE["key"] != key:
+        _COS_SIN_CACHE["key"], _COS_SIN_CACHE["val"] = key, ops.rope_cos_sin(freqs)
+    return _COS_SIN_CACHE["val"]
+
+
+def apply_rotary_pos_emb(t: torch.Tensor, freqs, config=None, cu_seqlens=None) -> torch.Tensor:
+    """apply_rotary_pos_emb(t, freqs, config, cu_seqlens) (:232-259) for t [s, b, heads, d]; `freqs` as Megatron passes it
+    (fp32 [s, 1, 1, d]) or a (cos, sin) pair of this module's RotaryEmbedding.  Without autograd the rotation is in place
+    (Megatron only uses the returned tensor); with it, autograd_fns.RopeFn rotates a copy and its backward rotates by -theta."""
     if cu_seqlens is not None:
         raise AssertionError("thd (packed) RoPE is not on this path")
+    if config is not None and getattr(config, "rotary_interleaved", False):
+        raise NotImplementedError("only non-interleaved RoPE is on the Long-VITA path")
     s, b, h, d = t.shape
-    if b != 1:
+    cos, sin = _cos_sin(freqs)
+    if cos.shape[0] != s * b and b != 1:
         raise ValueError("batch must be 1 on the Long-VITA path")
-    cos, sin = cos_sin
+    if torch.is_grad_enabled() and t.requires_grad:
+        from .autograd_fns import RopeFn
+        return RopeFn.apply(t, cos, sin)
     ops.rope_apply_(t.view(s, h, d) if t.is_contiguous() else t[:, 0], cos, sin)
     return t

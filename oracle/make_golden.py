@@ -293,6 +293,19 @@ def golden_masked_linear():
     sel = torch.masked_select(inp, m.transpose(0, 1).unsqueeze(2)).reshape(-1, b, c)   # layers.py:344-348 verbatim shape logic
     out["y_frozen"] = torch.matmul(sel, wf.t())
     torch.save(out, os.path.join(OUT, "masked_linear.pt"))
+    # the same function at a size the MFMA GEMM accepts (K % 64 == 0) and in the dtype the path runs in (bf16): what the HIP
+    # ColumnParallelLinear module (forward + autograd backward) is compared with directly
+    g = torch.Generator().manual_seed(8)
+    s, b, c, o = 192, 1, 256, 320
+    x = (torch.randn(s, b, c, generator=g) * 0.5).bfloat16().requires_grad_(True)
+    w = (torch.randn(o, c, generator=g) * 0.05).bfloat16().requires_grad_(True)
+    mask = torch.zeros(b, s, dtype=torch.bool)
+    mask[0, torch.randperm(s, generator=g)[:70]] = True
+    y = fn.apply(x, w, None, False, False, False, None, mask)
+    go = torch.randn(y.shape, generator=g).bfloat16()
+    y.backward(go)
+    torch.save(dict(x=x.detach().clone(), w=w.detach().clone(), mask=mask, y=y.detach().clone(), go=go, dx=x.grad.clone(),
+                    dw=w.grad.clone()), os.path.join(OUT, "masked_linear_bf16.pt"))
 
 
 def golden_hf_vit():

@@ -173,6 +173,61 @@ def test_adaptor_registers_reference_targets_with_dummy_megatron():
         aspm.patches_info = {}
 
 
+def test_megatron_constructs_the_hip_modules_through_the_patched_layer_specs():
+    """under a (stand-in) Megatron the adaptor's spec builders land on the reference's dotted names
+    (M/megatron_adaptor.py:81-88) and `build_module(spec, config=, layer_number=)` — Megatron's own construction calls, with
+    Megatron's constructor arguments — yields a decoder layer whose leaves are this package's nn.Modules, with Parameters under
+    Megatron's checkpoint names.  CPU construction (`use_cpu_initialization`); the forward needs the GPU (tests/test_boundary_gpu.py)."""
+    import dummy_megatron as dm
+    import long_vita_amd.megatron_adaptor as ad
+    from long_vita_amd import layers
+    from long_vita_amd.dot_product_attention import HipDotProductAttention
+    from long_vita_amd.language_model_embedding import LanguageModelEmbedding
+    from long_vita_amd.patch_utils import MindSpeedPatchesManager as aspm
+    aspm.patches_info = {}
+    names = dm.install()
+    try:
+        assert ad.exe_adaptation(create_dummy=True)
+        specs = sys.modules["megatron.core.models.gpt.gpt_layer_specs"]
+        cfg = dm.TransformerConfig(use_cpu_initialization=True)
+        te = dm.build_module(specs.get_gpt_layer_with_transformer_engine_spec(), config=cfg, layer_number=1)
+        assert isinstance(te.self_attention.linear_qkv, layers.LayerNormColumnParallelLinear)
+        assert isinstance(te.self_attention.core_attention, HipDotProductAttention)
+        assert isinstance(te.self_attention.linear_proj, layers.RowParallelLinear)
+        assert isinstance(te.mlp.linear_fc1, layers.LayerNormColumnParallelLinear) and isinstance(te.mlp.linear_fc2, layers.RowParallelLinear)
+        sd = te.state_dict()
+        h, q, kv, f = cfg.hidden_size, cfg.kv_channels * cfg.num_attention_heads, cfg.kv_channels * cfg.num_query_groups, cfg.ffn_hidden_size
+        want = {"self_attention.linear_qkv.layer_norm_weight": (h,), "self_attention.linear_qkv.weight": (q + 2 * kv, h),
+                "self_attention.linear_qkv.bias": (q + 2 * kv,), "self_attention.linear_proj.weight": (h, q),
+                "mlp.linear_fc1.layer_norm_weight": (h,), "mlp.linear_fc1.weight": (2 * f, h), "mlp.linear_fc2.weight": (h, f)}
+        got = {k: tuple(v.shape) for k, v in sd.items() if v is not None and not k.endswith("_extra_state")}
+        assert got == want, got                                        # the names R/tools/hf2mcore_long_vita.py:590-617 writes
+        assert all(isinstance(p_, torch.nn.Parameter) and p_.dtype == torch.bfloat16 for p_ in te.parameters())
+        assert float(te.self_attention.linear_qkv.bias.abs().max()) == 0.0 and float(te.mlp.linear_fc1.weight.float().std()) > 0.01
+        te.load_state_dict({k: torch.zeros(v) for k, v in want.items()})   # a checkpoint without TE's _extra_state entries loads
+        local = dm.build_module(specs.get_gpt_layer_local_spec(), config=cfg, layer_number=1)
+        assert isinstance(local.input_layernorm, layers.RMSNorm) and isinstance(local.self_attention.linear_qkv, layers.ColumnParallelLinear)
+        assert {"input_layernorm.weight", "pre_mlp_layernorm.weight", "self_attention.linear_qkv.weight", "mlp.linear_fc1.weight"} <= set(local.state_dict())
+        # the two classes the reference replaces outright (:93-94,105-106) keep Megatron's constructor signatures
+        emb_cls = sys.modules["megatron.core.models.common.embeddings.language_model_embedding"].LanguageModelEmbedding
+        assert emb_cls is LanguageModelEmbedding
+        emb = emb_cls(config=cfg, vocab_size=256, max_sequence_length=64, position_embedding_type="rope")
+        assert list(emb.state_dict()) == ["word_embeddings.weight"] and tuple(emb.word_embeddings.weight.shape) == (256, h)
+        cpl_cls = sys.modules["megatron.core.tensor_parallel.layers"].ColumnParallelLinear
+        out_layer = cpl_cls(h, 256, config=cfg, init_method=cfg.init_method, bias=False, skip_bias_add=False, gather_output=False,
+                            skip_weight_param_allocation=True)       # the shared-embedding output layer of GPTModel
+        assert out_layer.weight is None
+        with pytest.raises(RuntimeError, match="skip_weight_param_allocation"):
+            out_layer(torch.zeros(4, 1, h, dtype=torch.bfloat16))
+        with pytest.raises(RuntimeError, match="supplied weight's shape"):
+            out_layer(torch.zeros(4, 1, h, dtype=torch.bfloat16), weight=torch.zeros(8, h, dtype=torch.bfloat16))
+        with pytest.raises(RuntimeError, match="no CPU fallback"):    # the product path never computes on the host
+            te.self_attention.linear_proj(torch.zeros(4, 1, q, dtype=torch.bfloat16))
+    finally:
+        dm.uninstall(names)
+        aspm.patches_info = {}
+
+
 def test_adaptor_target_names_are_the_references_call_sites():
     """Every dotted name the adaptor registers is one the reference registers (M/megatron_adaptor.py call sites read with
     ast, fixture adaptor_targets.pt) with the same kind of replacement (wrapper vs outright), except the documented extra;
@@ -192,8 +247,6 @@ def test_adaptor_target_names_are_the_references_call_sites():
         assert obj.__name__ == live[name], (name, obj.__name__, live[name])               # same replacement names too
     left = sorted(set(live) - set(mine))
     assert left == sorted([
-        "megatron.core.models.gpt.gpt_layer_specs.get_gpt_layer_local_spec",
-        "megatron.core.models.gpt.gpt_layer_specs.get_gpt_layer_with_transformer_engine_spec",
         "megatron.core.transformer.transformer_config.TransformerConfig",
         "megatron.training.checkpointing.ensure_directory_exists",
         "megatron.inference.text_generation.tokenization.tokenize_prompts",
