@@ -332,7 +332,8 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
   // O *= alpha (rare: only when a running maximum moved); every P V MFMA that precedes it has been issued
   auto rescale_o = [&]() __attribute__((always_inline)) {
     if (!__all(alpha[0] == 1.0f && alpha[1] == 1.0f)) {
-      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                       // asm MFMA -> accumulator read
+      // (the accumulators are operands of the wait: the compiler may not read them above it)
+      asm volatile("s_nop 15\n\ts_nop 15" : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[0][2]), "+a"(o[0][3]), "+a"(o[1][0]), "+a"(o[1][1]), "+a"(o[1][2]), "+a"(o[1][3]));                       // asm MFMA -> accumulator read
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
@@ -389,7 +390,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
   pv_phase(1, lds0 + LDS_V + TILEB, false);
 
   // ---- epilogue: O[row][head][d] = O^T / l, lse ------------------------------------------------------------------------------
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  asm volatile("s_nop 15\n\ts_nop 15" : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[0][2]), "+a"(o[0][3]), "+a"(o[1][0]), "+a"(o[1][1]), "+a"(o[1][2]), "+a"(o[1][3]));
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     const float l_tot = swap32_sum(l_run[qb]);

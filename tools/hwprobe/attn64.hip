@@ -348,7 +348,7 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const bf16_t* __restrict
   // O *= alpha (rare: only when a row maximum moved); all PV MFMAs that precede it have been issued
   auto rescale_o = [&]() __attribute__((always_inline)) {
     if (!__all(alpha[0] == 1.0f && alpha[1] == 1.0f)) {
-      asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");                     // asm MFMA -> accumulator read
+      asm volatile("s_nop 15\n\ts_nop 15" : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[0][2]), "+a"(o[0][3]), "+a"(o[1][0]), "+a"(o[1][1]), "+a"(o[1][2]), "+a"(o[1][3]));                     // asm MFMA -> accumulator read
 #pragma unroll
       for (int qb = 0; qb < 2; ++qb)
 #pragma unroll
@@ -443,7 +443,7 @@ __global__ __launch_bounds__(256, 1) void attn64_kernel(const bf16_t* __restrict
   phase2(1, V3 ? v_cur : vb0 + TILEB, false);
 
   // ---- epilogue: O[query][head][d] = O^T / l -------------------------------------------------------------------------------
-  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  asm volatile("s_nop 15\n\ts_nop 15" : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[0][2]), "+a"(o[0][3]), "+a"(o[1][0]), "+a"(o[1][1]), "+a"(o[1][2]), "+a"(o[1][3]));
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
     const float l_tot = SUMM ? __shfl(l31 < 16 ? osum[qb][0] : osum[qb][1], lane & 15, 64) : swap32_sum(l_run[qb]);
