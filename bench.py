@@ -49,43 +49,86 @@ def flops_per_token(seq, frames, cfg, vcfg):
     return (lin + attn + frames * vit_frame + head) / seq
 
 
-def cpu_baseline(fpt_workload: float):
-    """Oracle decoder on the host cores: 4 full-width layers (hidden 5120, 40/8 heads, ffn 13824) at S = 2048,
-    bf16-rounded weights, fp32 matmuls (a bounded sample, about 10 s).  The benchmark workload is attention-dominated
-    (O(S^2)), so the sample's achieved FLOP rate — not its tokens/s — is what carries over: value = CPU FLOP/s divided
-    by the algorithmic FLOPs per token of the benchmark workload."""
-    from oracle import glue, llm as ollm
+def cpu_baseline(seq: int, frames: int, fpt_workload: float):
+    """The CPU oracle ("port") on the host cores, bounded samples of the same workload (tens of seconds):
+      * 2 full-width decoder layers (hidden 5120, 40:8 heads, ffn 13824) at S = 2048: oracle.llm.decoder_layer;
+      * single-layer causal attention (oracle.attention.core_attention, one kv group at a time) at S = 2K / 4K / 8K:
+        BASELINE.md §3 B3 — its time follows b * S^2, and on a CPU the attention runs at a much lower FLOP rate than the
+        GEMMs, so a FLOP-rate carry-over would flatter the host on this attention-dominated workload;
+      * oracle.vit (24-layer InternViT + projector) on 2 frames;
+      * BASELINE.md §3 B1, bounded: transformers' Qwen2ForCausalLM (what the reference's HF path wraps,
+        H/models/long_vita_qwen2_intern/modeling_long_vita.py:227) at the 14B width, 2 layers, S = 2048.
+    value = seq / (48 * (a * seq + b * seq^2) + frames * vit seconds per frame), a from the layer sample minus its own
+    attention share, b from the attention samples — the host's time model evaluated at the benchmark sequence."""
+    from oracle import glue, llm as ollm, vit as ovit
     from oracle.attention import core_attention
-    S, L = 2048, 4
+    S, L = 2048, 2
     cfg = ollm.LLMConfig(num_layers=L, vocab=64)
     p = ollm.init_llm_params(cfg, seed=1)
     h = (torch.randn(S, 1, cfg.hidden, generator=torch.Generator().manual_seed(0)) * 0.5).bfloat16()
     freqs = glue.rope_emb(S, glue.rope_inv_freq(cfg.head_dim, cfg.rope_theta))
+
+    def attn_by_group(q, k, v):
+        outs = [core_attention(q[:, :, g * cfg.qpg:(g + 1) * cfg.qpg], k[:, :, g:g + 1], v[:, :, g:g + 1], True).view(q.shape[0], 1, cfg.qpg, -1)
+                for g in range(cfg.kv_groups)]
+        return torch.cat(outs, 2).reshape(q.shape[0], 1, -1)
+
     t0 = time.perf_counter()
     with torch.no_grad():
         for lp in p["layers"]:
-            h, _ = ollm.decoder_layer(h, lp, cfg, freqs, lambda q, k, v: core_attention(q, k, v, causal=True))
-    dt = time.perf_counter() - t0
+            h, _ = ollm.decoder_layer(h, lp, cfg, freqs, attn_by_group)
+    t_layer = (time.perf_counter() - t0) / L
     qkv_out = (cfg.heads + 2 * cfg.kv_groups) * cfg.head_dim
-    flops = L * (2 * S * (cfg.hidden * qkv_out + cfg.hidden * cfg.heads * cfg.head_dim + 3 * cfg.hidden * cfg.ffn)
-                 + 4 * cfg.head_dim * cfg.heads * (S * (S + 1) // 2))
-    rate = flops / dt
-    # the ViT + projector leg of the same path (SURVEY.md §8d item 2): oracle.vit on 4 frames, seconds per frame
-    from oracle import vit as ovit
+    lin_flops_per_token = 2 * (cfg.hidden * qkv_out + cfg.hidden * cfg.heads * cfg.head_dim + 3 * cfg.hidden * cfg.ffn)
+    flops_layer = S * lin_flops_per_token + 4 * cfg.head_dim * cfg.heads * (S * (S + 1) // 2)
+    rate = flops_layer / t_layer
+    attn = {}
+    for s_a in (2048, 4096, 8192):
+        g = torch.Generator().manual_seed(s_a)
+        q = torch.randn(s_a, 1, cfg.heads, cfg.head_dim, generator=g).bfloat16()
+        k = torch.randn(s_a, 1, cfg.kv_groups, cfg.head_dim, generator=g).bfloat16()
+        v = torch.randn(s_a, 1, cfg.kv_groups, cfg.head_dim, generator=g).bfloat16()
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            attn_by_group(q, k, v)
+        attn[s_a] = time.perf_counter() - t0
+    b_coef = sum(attn[s_a] * s_a ** 2 for s_a in attn) / sum(float(s_a) ** 4 for s_a in attn)        # least squares through 0
+    a_coef = max(t_layer - attn[S], 0.0) / S
     vcfg = ovit.ViTConfig()
     vp = ovit.init_vit_params(vcfg, seed=2)
-    imgs = torch.randn(4, 3, 448, 448, generator=torch.Generator().manual_seed(3)).bfloat16()
+    imgs = torch.randn(2, 3, 448, 448, generator=torch.Generator().manual_seed(3)).bfloat16()
     t0 = time.perf_counter()
     with torch.no_grad():
         ovit.vision_model(imgs, vp, vcfg)
     vit_s_per_frame = (time.perf_counter() - t0) / imgs.size(0)
-    return {"value": rate / fpt_workload, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
-            "sample": f"{L} of 48 full-width decoder layers at S={S} (oracle.llm.decoder_layer, text-only) took {dt:.1f} s = "
-                      f"{rate / 1e12:.2f} TFLOP/s on the host; value = that rate / the workload's algorithmic FLOPs per token "
-                      f"({fpt_workload / 1e9:.1f} GFLOP); the linear per-layer extrapolation of the sample itself would be "
-                      f"{S / (dt / L * 48):.1f} tokens/s at S={S}; oracle.vit (24-layer ViT + projector) on 4 frames: "
-                      f"{vit_s_per_frame:.2f} s/frame",
-            "vit_s_per_frame": vit_s_per_frame}
+    t_prefill = 48 * (a_coef * seq + b_coef * float(seq) ** 2) + frames * vit_s_per_frame
+    try:
+        import transformers
+        hcfg = transformers.Qwen2Config(hidden_size=cfg.hidden, intermediate_size=cfg.ffn, num_hidden_layers=2,
+                                        num_attention_heads=cfg.heads, num_key_value_heads=cfg.kv_groups, vocab_size=1024,
+                                        max_position_embeddings=4096, rope_theta=cfg.rope_theta)
+        hm = transformers.Qwen2ForCausalLM(hcfg).to(torch.bfloat16).eval()
+        ids = torch.randint(0, 1024, (1, S), generator=torch.Generator().manual_seed(5))
+        t0 = time.perf_counter()
+        with torch.no_grad():
+            hm(ids, use_cache=False)
+        dt_hf = time.perf_counter() - t0
+        hf = {"layers": 2, "seq": S, "seconds": dt_hf, "tokens_per_s_extrapolated_to_48_layers_at_2048": S / (dt_hf / 2 * 48),
+              "transformers": transformers.__version__}
+        del hm
+    except Exception as e:  # noqa: BLE001
+        hf = {"error": f"{type(e).__name__}: {e}"}
+    return {"value": seq / t_prefill, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"{L} of 48 full-width decoder layers at S={S} (oracle.llm.decoder_layer): {t_layer:.2f} s per layer = "
+                      f"{rate / 1e12:.2f} TFLOP/s; single-layer causal attention (oracle.attention.core_attention) "
+                      + ", ".join(f"{attn[s_a]:.2f} s @ {s_a}" for s_a in attn)
+                      + f" -> b = {b_coef:.3e} s/token^2, a = {a_coef:.3e} s/token per layer; oracle.vit on 2 frames: "
+                      f"{vit_s_per_frame:.2f} s/frame; value = {seq} / (48 (a S + b S^2) + {frames} frames) = {seq} tokens / "
+                      f"{t_prefill:.0f} s (model evaluated at the benchmark sequence, not run)",
+            "decoder_layer_s_at_2048": t_layer, "decoder_layer_tflops_at_2048": rate / 1e12,
+            "attention_seconds_by_seq": attn, "attention_s_per_token2": b_coef, "linear_s_per_token_per_layer": a_coef,
+            "vit_s_per_frame": vit_s_per_frame, "flop_rate_carry_over_tokens_per_s": rate / fpt_workload,
+            "hf_transformers_qwen2": hf}
 
 
 def main():
@@ -98,6 +141,7 @@ def main():
     ap.add_argument("--vit-layers", type=int, default=24, help="debug only")
     ap.add_argument("--frames", type=int, default=-1, help="debug only; default fills the sequence (506 @128K)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-parity-check", action="store_true")
     args = ap.parse_args()
 
     rank = int(os.environ.get("RANK", "0"))
@@ -146,6 +190,21 @@ def main():
         dt = float(t.item())
     assert torch.isfinite(out.float()).all()
 
+    # once, outside the timed region (N = 1): the same prefill through the context-parallel code path (K/V pack, all-gather
+    # messages, zig-zag chunk tables, logits gather) must give the plain path's logits
+    parity = None
+    if world == 1 and not args.no_parity_check:
+        model.attn_events = None
+        model.force_cp_path = True
+        out_cp = step()
+        model.force_cp_path = False
+        torch.cuda.synchronize()
+        a, b_ = out_cp.float(), out.float()
+        parity = {"what": "logits of the forced context-parallel path vs the plain path, same inputs, outside the timed region",
+                  "rel_l2": float((a - b_).norm() / b_.norm()), "max_abs": float((a - b_).abs().max()),
+                  "argmax_equal": bool((a.argmax(-1) == b_.argmax(-1)).all())}
+        assert parity["rel_l2"] < 2e-2, parity
+
     # dominant kernel: flash attention forward, one launch per layer per step on this rank
     ev_ms = [a.elapsed_time(b) for a, b in model.attn_events]
     attn_ms = sum(ev_ms) / max(len(ev_ms), 1)
@@ -157,36 +216,39 @@ def main():
     # rocprofv3 --pmc measurement of the same launch shape is committed under profiles/, report it
     traffic, traffic_src = None, None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r01_attn128k_pmc.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_attn128k_pmc.json")))
         if pmc["seq"] == seq and pmc["n_gpus"] == world:
-            traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/r01_attn128k_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, offline)"
+            traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/r02_attn128k_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, offline)"
     except (OSError, KeyError, ValueError):
         pass
 
     ms_per_step = dt / args.steps * 1e3
     value = seq / (dt / args.steps)
     fpt = flops_per_token(seq, frames, cfg, vcfg)
+    name = {16384: "Long-VITA-16K", 131072: "Long-VITA-128K", 1048576: "Long-VITA-1M"}.get(seq, f"Long-VITA (seq {seq})")
     line = {
-        "metric": "prefill tokens/sec/node (ViT+LLM) at seq=128K",
+        "metric": "prefill tokens/sec/node (ViT+LLM) at seq=128K" if seq == 131072 else f"prefill tokens/sec/node (ViT+LLM) at seq={seq}",
         "value": value, "unit": "tokens/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": ms_per_step, "higher_is_better": True, "scaling": "strong", "vs_baseline": None,
         "dtype": "bf16", "data": "synthetic",
-        "config": {"workload": f"Long-VITA-128K prefill: {frames}-frame synthetic video (InternViT-300M + projector) + "
+        "config": {"workload": f"{name} prefill: {frames}-frame synthetic video (InternViT-300M + projector) + "
                                f"Qwen2.5-14B decoder ({cfg.num_layers} layers), seq {seq}, logits-masked LM head",
                    "seq_len": seq, "frames": frames, "global_batch": 1, "parallelism": f"cp{world}",
                    "weights": "seeded random bf16 (N(0,0.02))",
                    "algorithmic_gflop_per_token": fpt / 1e9,
                    "end_to_end_tflops_per_gpu": fpt * value / world / 1e12,
                    "end_to_end_frac_of_mfma_peak": fpt * value / world / 1e12 / MFMA_BF16_PEAK_TFLOPS},
-        "roofline": {"bound": "mfma", "kernel": "flash_fwd_kernel<128, causal>", "achieved": achieved,
+        "roofline": {"bound": "mfma", "kernel": "flash_fwd64_kernel (d = 128, causal; 4 waves x 64 rows)" if os.environ.get("VITA_ATTN64", "1") != "0" else "flash_fwd_kernel<128, causal>", "achieved": achieved,
                      "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
                      "traffic": traffic, "traffic_source": traffic_src, "launches_timed": len(ev_ms), "ms_per_launch": attn_ms,
                      "flop_per_launch": attn_flops},
     }
+    if parity is not None:
+        line["parity_check"] = parity
     if rank == 0:
         if world == 1 and not args.no_cpu_baseline:
             try:
-                line["cpu_baseline"] = cpu_baseline(fpt)
+                line["cpu_baseline"] = cpu_baseline(seq, frames, fpt)
             except Exception as e:  # noqa: BLE001 — a reported baseline must not cost the measured line
                 line["cpu_baseline"] = {"value": None, "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
                                         "sample": f"failed: {type(e).__name__}: {e}"}

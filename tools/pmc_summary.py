@@ -5,7 +5,8 @@ def main(root):
     for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"]
-            if "flash_fwd" in k: k = "flash_fwd<" + ("128" if "128" in k else "64") + ">"
+            if "flash_fwd64" in k: k = "flash_fwd64"
+            elif "flash_fwd" in k: k = "flash_fwd<" + ("128" if "128" in k else "64") + ">"
             elif "gemm_bf16" in k: k = "gemm_bf16<" + k.split("<")[1].split(">")[0] + ">"
             else: continue
             agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
