@@ -193,8 +193,9 @@ def main():
     # once, outside the timed region (N = 1): the same prefill through the context-parallel code path (K/V pack, all-gather
     # messages, zig-zag chunk tables, logits gather) must give the plain path's logits
     parity = None
+    attn_events = model.attn_events
+    model.attn_events = None
     if world == 1 and not args.no_parity_check:
-        model.attn_events = None
         model.force_cp_path = True
         out_cp = step()
         model.force_cp_path = False
@@ -206,7 +207,7 @@ def main():
         assert parity["rel_l2"] < 2e-2, parity
 
     # dominant kernel: flash attention forward, one launch per layer per step on this rank
-    ev_ms = [a.elapsed_time(b) for a, b in model.attn_events]
+    ev_ms = [a.elapsed_time(b) for a, b in attn_events]
     attn_ms = sum(ev_ms) / max(len(ev_ms), 1)
     pairs = seq * (seq + 1) // 2 / world
     attn_flops = 4 * cfg.head_dim * cfg.heads * pairs
