@@ -48,6 +48,16 @@ int vita_rmsnorm_fwd(const void* x, const void* w, void* y, float* rstd_out,
 int vita_layernorm_fwd(const void* x, const void* w, const void* b, void* y,
                        int64_t rows, int cols, float eps, void* stream);
 
+/* Logit post-processing, in place on the bf16 logits [rows, cols] of the selected rows (row stride ld elements):
+ *   logits *= multiplier_scale (skipped when 0);  logits = tanh(logits / softcapping) * softcapping (skipped when 0)
+ * with the reference's bf16 rounding after every step.  Replaces M/core/models/multimodal/gpt_vl_model.py:349-355
+ * (args.output_multiplier_scale, args.output_logit_softcapping).  _bwd: grad *= scale * (1 - (y / cap)^2) from the
+ * stored output y (autograd of the same expressions). */
+int vita_logit_postprocess(void* logits, int64_t ld, int64_t rows, int64_t cols, float multiplier_scale,
+                           float softcapping, void* stream);
+int vita_logit_postprocess_bwd(const void* y, int64_t ldy, void* grad, int64_t ldg, int64_t rows, int64_t cols,
+                               float multiplier_scale, float softcapping, void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * RoPE.  Replaces M/core/models/common/embeddings/rotary_pos_embedding.py:84-122 (table),
  * :181-204 (apply_rotary_pos_emb_bshd) and apex fused_apply_rotary_pos_emb (:248-252).

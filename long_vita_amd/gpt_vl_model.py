@@ -37,6 +37,8 @@ class GPTConfig:
     vocab: int = 152064
     eps: float = 1e-6
     rope_theta: float = 1e6
+    output_multiplier_scale: float = 0.0        # args.output_multiplier_scale (gpt_vl_model.py:349-350); 0 = off
+    output_logit_softcapping: float = 0.0       # args.output_logit_softcapping (:352-355); 0 = off
 
     @property
     def qpg(self):
@@ -215,6 +217,7 @@ class GPTVLModel:
         rows = ops.rmsnorm(rows, self.p["final_ln"], self.cfg.eps)
         logits, _ = self.output_layer(rows.view(rows.shape[0], 1, hdim), weight=None, logit_mask=sel_mask)   # :339
         logits = self._gather_vocab_parallel(logits)
+        ops.logit_postprocess_(logits, self.cfg.output_multiplier_scale, self.cfg.output_logit_softcapping)   # :349-355
         if bool(torch.isnan(logits.float().sum())):                                       # :393-396
             raise ValueError("found NaN in local forward logits calculation")
         return logits.transpose(0, 1).contiguous()                                        # [s b v] -> [b s v] :370

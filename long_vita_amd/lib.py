@@ -111,6 +111,8 @@ PROTOTYPES = {
     "vita_error_string": (C.c_char_p, [_i]),
     "vita_rmsnorm_fwd": (_i, [_p, _p, _p, _p, _l, _i, _f, _p]),
     "vita_layernorm_fwd": (_i, [_p, _p, _p, _p, _l, _i, _f, _p]),
+    "vita_logit_postprocess": (_i, [_p, _l, _l, _l, _f, _f, _p]),
+    "vita_logit_postprocess_bwd": (_i, [_p, _l, _p, _l, _l, _l, _f, _f, _p]),
     "vita_rope_table": (_i, [_p, _p, _p, _p, _l, _i, _p]),
     "vita_rope_cos_sin": (_i, [_p, _l, _p, _p, _l, _i, _p]),
     "vita_rope_apply": (_i, [_p, _l, _i, _i, _l, _l, _p, _p, _i, _p]),

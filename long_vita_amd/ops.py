@@ -612,6 +612,28 @@ def segments_from_cu_seqlens(cu_seqlens: torch.Tensor, total: int):
     return start.contiguous(), end.contiguous()
 
 
+def logit_postprocess_(logits: torch.Tensor, multiplier_scale: float = 0.0, softcapping: float = 0.0) -> torch.Tensor:
+    """In place on bf16 logits [..., V]: x * scale, then tanh(x / cap) * cap (gpt_vl_model.py:349-355); 0 / None = skip."""
+    s, c = float(multiplier_scale or 0.0), float(softcapping or 0.0)
+    if s == 0.0 and c == 0.0:
+        return logits
+    x = logits.view(-1, logits.shape[-1])
+    _L.check(_L.load().vita_logit_postprocess(_dev(x, "logits", BF16), x.stride(0), x.shape[0], x.shape[1], s, c, _stream()),
+             "vita_logit_postprocess")
+    return logits
+
+
+def logit_postprocess_bwd_(y: torch.Tensor, grad: torch.Tensor, multiplier_scale: float = 0.0, softcapping: float = 0.0) -> torch.Tensor:
+    """grad (bf16, in place) *= d(post-processed logits) / d(raw logits), from the post-processed logits y."""
+    s, c = float(multiplier_scale or 0.0), float(softcapping or 0.0)
+    if s == 0.0 and c == 0.0:
+        return grad
+    y2, g2 = y.view(-1, y.shape[-1]), grad.view(-1, grad.shape[-1])
+    _L.check(_L.load().vita_logit_postprocess_bwd(_dev(y2, "y", BF16), y2.stride(0), _dev(g2, "grad", BF16), g2.stride(0), g2.shape[0],
+                                                  g2.shape[1], s, c, _stream()), "vita_logit_postprocess_bwd")
+    return grad
+
+
 def add_(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """a = bf16(a + b) in place (residual add behind a tensor-parallel all-reduce)."""
     if a.shape != b.shape or not a.is_contiguous() or not b.is_contiguous():

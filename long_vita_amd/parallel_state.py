@@ -94,6 +94,17 @@ def get_tensor_model_parallel_rank() -> int:
     return _S.tp_rank
 
 
+def get_tensor_model_parallel_src_rank() -> int:
+    """Global rank of tensor-parallel rank 0 of this rank's group (Megatron: adjacent ranks form a TP group)."""
+    m = _mg()
+    if m is not None:
+        return m.get_tensor_model_parallel_src_rank()
+    import torch.distributed as dist
+    if not dist.is_available() or not dist.is_initialized():
+        return 0
+    return (dist.get_rank() // _S.tp_size) * _S.tp_size
+
+
 def get_tensor_model_parallel_group():
     m = _mg()
     if m is not None:

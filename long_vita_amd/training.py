@@ -235,6 +235,7 @@ class TrainStep:
         tp, tp_rank = mpu.get_tensor_model_parallel_world_size(), mpu.get_tensor_model_parallel_rank()
         logits_local = ops.gemm(hn_p, m.p["lm_head"])                # [n_sel (padded), V / TP]
         logits = m._gather_vocab_parallel(logits_local).contiguous() # [n_sel (padded), V]
+        ops.logit_postprocess_(logits, c.output_multiplier_scale, c.output_logit_softcapping)     # gpt_vl_model.py:349-355
         # labels of the selected rows (masked_select, gpt_vl_model.py:380-382); 16-byte rows for the gather
         lab_sel = ops.row_gather(lab.reshape(-1, 1).repeat(1, 2).contiguous(), idx)[:, 0]
         # instruction shift (gpt_vl_model.py:389-391): logits[:-1] vs labels[1:]
@@ -258,6 +259,7 @@ class TrainStep:
 
         # ---- backward ------------------------------------------------------------------------------
         grads = {"layers": [dict() for _ in m.p["layers"]]}
+        ops.logit_postprocess_bwd_(logits, dlogits, c.output_multiplier_scale, c.output_logit_softcapping)
         if tp > 1:      # this rank's vocabulary slice of dlogits
             v_l = logits_local.shape[1]
             dlogits = dlogits[:, tp_rank * v_l: (tp_rank + 1) * v_l].contiguous()

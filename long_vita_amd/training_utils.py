@@ -94,6 +94,97 @@ def get_batch_on_this_cp_rank(batch: dict, seq_length: Optional[int] = None, cp_
     return batch
 
 
+def get_batch_on_this_tp_rank(data_iterator, *, micro_batch_size: int, seq_length: int, image_size: int = 448,
+                              reset_attention_mask: bool = False, create_attention_mask_in_dataloader: bool = False,
+                              device=None) -> dict:
+    """Mirror of M/training/utils.py:410-626 at pipeline size 1 (the Long-VITA path runs PP = 1): tensor-parallel rank 0
+    draws the batch (skipping items without "tokens", :434-438), casts the frames to bf16 (:450; a batch without images gets the
+    reference's all-ones placeholder frame per sample, :451-452) and broadcasts, in the reference's ORDER, tokens / labels /
+    loss_mask / attention_mask / position_ids, the two size vectors, the frames and — only when present — the context-token
+    indices over the tensor-parallel group; the other ranks allocate by `micro_batch_size` / `seq_length` and the received
+    sizes (:525-545).  `--reset-attention-mask`: `actual_seq_len` goes through the length-prefixed dynamic broadcast
+    (:419-431,513-516) into set_actual_seq_len.  Pure data movement: torch.distributed over RCCL on device tensors
+    (gloo + host tensors in the CPU tests); no arithmetic."""
+    import torch.distributed as dist
+    tp, rank, group = mpu.get_tensor_model_parallel_world_size(), mpu.get_tensor_model_parallel_rank(), mpu.get_tensor_model_parallel_group()
+    if device is None:
+        device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else torch.device("cpu")
+    src = mpu.get_tensor_model_parallel_src_rank()
+
+    def _broadcast(item):
+        if item is not None and tp > 1:
+            dist.broadcast(item, src, group=group)
+
+    def broadcast_dynamic(item):
+        if item is not None:
+            item = item.to(device)
+            item_len = torch.tensor(item.numel(), device=device)
+            _broadcast(item_len)
+            _broadcast(item)
+        else:
+            item_len = torch.empty((), dtype=torch.int64, device=device)
+            _broadcast(item_len)
+            item = torch.empty([int(item_len.item())], dtype=torch.int64, device=device)
+            _broadcast(item)
+        return item
+
+    if rank == 0:
+        data = None
+        if data_iterator is not None:
+            while True:
+                data = next(data_iterator)
+                if "tokens" in data:
+                    break
+        to = lambda t: t.to(device, non_blocking=True)                                             # noqa: E731
+        batch = {"tokens": to(data["tokens"]), "labels": to(data["labels"]), "loss_mask": to(data["loss_mask"]),
+                 "attention_mask": None if "attention_mask" not in data else to(data["attention_mask"]),
+                 "position_ids": to(data["position_ids"])}
+        if "images" in data:
+            batch["external_images"] = to(data["images"]).bfloat16()
+        else:
+            batch["external_images"] = torch.ones([len(data["tokens"]), 3, image_size, image_size]).to(device).bfloat16()
+        external_images_sizes = torch.tensor(batch["external_images"].size()).to(device)
+        if "image_indices" in data:
+            batch["external_indices"] = to(data["image_indices"]).to(torch.int64)
+            external_indices_sizes = torch.tensor(batch["external_indices"].size()).to(device)
+        else:
+            external_indices_sizes = torch.tensor([0, 0, 0]).to(device)
+        for k in ("tokens", "labels", "loss_mask", "attention_mask", "position_ids"):
+            _broadcast(batch[k])
+        _broadcast(external_images_sizes)
+        _broadcast(external_indices_sizes)
+        _broadcast(batch["external_images"])
+        if external_indices_sizes.sum() > 0:
+            _broadcast(batch["external_indices"])
+        if reset_attention_mask:
+            set_actual_seq_len(broadcast_dynamic(data["actual_seq_len"]).tolist())
+        return batch
+
+    tokens = torch.empty((micro_batch_size, seq_length), dtype=torch.int64, device=device)
+    labels = torch.empty((micro_batch_size, seq_length), dtype=torch.int64, device=device)
+    loss_mask = torch.empty((micro_batch_size, seq_length), dtype=torch.float32, device=device)
+    attention_mask = (torch.empty((micro_batch_size, 1, seq_length, seq_length), dtype=torch.bool, device=device)
+                      if create_attention_mask_in_dataloader else None)
+    position_ids = torch.empty((micro_batch_size, seq_length), dtype=torch.int64, device=device)
+    external_images_sizes = torch.empty((4), dtype=torch.int64, device=device)
+    external_indices_sizes = torch.empty((3), dtype=torch.int64, device=device)
+    for t in (tokens, labels, loss_mask, attention_mask, position_ids, external_images_sizes, external_indices_sizes):
+        _broadcast(t)
+    external_images = torch.empty(external_images_sizes.tolist(), dtype=torch.bfloat16, device=device)
+    _broadcast(external_images)
+    external_indices = None
+    if external_indices_sizes.sum() > 0:
+        external_indices = torch.empty(external_indices_sizes.tolist(), dtype=torch.int64, device=device)
+        _broadcast(external_indices)
+    if reset_attention_mask:
+        set_actual_seq_len(broadcast_dynamic(None).tolist())
+    batch = {"tokens": tokens, "labels": labels, "loss_mask": loss_mask, "attention_mask": attention_mask,
+             "position_ids": position_ids, "external_images": external_images}
+    if external_indices is not None:
+        batch["external_indices"] = external_indices
+    return batch
+
+
 def get_packed_segments():
     """Packed samples as the reference's GPU path detects them: transformers' _flash_attention_forward
     (called at M/core/transformer/dot_product_attention.py:374-390 with position_ids=get_position_ids()) switches to

@@ -161,6 +161,17 @@ def masked_linear_fwd(inp: torch.Tensor, weight: torch.Tensor, bias, logit_mask:
     return out
 
 
+def logit_postprocess(logits: torch.Tensor, output_multiplier_scale=None, output_logit_softcapping=None) -> torch.Tensor:
+    """M/core/models/multimodal/gpt_vl_model.py:349-355, verbatim op order (every op rounds in logits.dtype)."""
+    if output_multiplier_scale:
+        logits = logits * output_multiplier_scale
+    if output_logit_softcapping:
+        logits = logits / output_logit_softcapping
+        logits = torch.tanh(logits)
+        logits = logits * output_logit_softcapping
+    return logits
+
+
 def masked_linear_bwd(grad_output: torch.Tensor, inp: torch.Tensor, weight: torch.Tensor, logit_mask: torch.Tensor):
     """layers.py:444-455,522-523: returns (grad_input [s,b,c], grad_weight [out,c])."""
     total_input = inp

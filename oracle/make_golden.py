@@ -1088,6 +1088,59 @@ def _run_ranks(worker, case):
         return [torch.load(os.path.join(d, f"rank{r}.pt")) for r in range(case["cp"])]
 
 
+TP_BATCH_CASES = [dict(name="video", cp=2, images=True, reset=False), dict(name="text_only", cp=2, images=False, reset=False),
+                  dict(name="packed", cp=2, images=True, reset=True)]
+
+
+def tp_batch_data(case):
+    """What the dataloader hands tensor-parallel rank 0 (H/data/dataset_qwen2.py item keys), preceded by an item without tokens."""
+    g = torch.Generator().manual_seed(len(case["name"]))
+    b, s = 2, 64
+    d = {"tokens": torch.randint(0, 1000, (b, s), generator=g), "labels": torch.randint(0, 1000, (b, s), generator=g),
+         "loss_mask": (torch.rand(b, s, generator=g) > 0.5).float(), "position_ids": torch.arange(s).repeat(b, 1)}
+    if case["images"]:
+        d["images"] = torch.randn(3, 3, 28, 28, generator=g)
+        d["image_indices"] = torch.stack([torch.tensor([[0] * 4, [1] * 4, [1] * 4]), torch.randint(0, s, (3, 4), generator=g)]).to(torch.int32)
+    if case["reset"]:
+        d["actual_seq_len"] = torch.tensor([10, 40, 64, 74, 128])
+    return [{"not_a_batch": torch.zeros(1)}, d]
+
+
+def _tp_batch_worker(rank: int, case: dict, port: int, out_dir: str):
+    """One tensor-parallel rank of the reference's get_batch_on_this_tp_rank (M/training/utils.py:410-626) on CPU + gloo:
+    `.cuda()` / current_device re-pointed at the host, Megatron's mpu stubbed with TP = 2."""
+    import torch.distributed as dist
+    _install_stubs()
+    a = STATE["args"]
+    a.bf16, a.image_size, a.pipeline_model_parallel_size, a.reset_attention_mask = True, 28, 1, case["reset"]
+    a.micro_batch_size, a.seq_length, a.create_attention_mask_in_dataloader = 2, 64, False
+    dist.init_process_group("gloo", init_method=f"tcp://127.0.0.1:{port}", rank=rank, world_size=2)
+    for mod in ("megatron.core.mpu", "megatron.core.parallel_state"):
+        m = sys.modules[mod]
+        m.get_tensor_model_parallel_rank = lambda: rank
+        m.get_tensor_model_parallel_src_rank = lambda: 0
+        m.get_tensor_model_parallel_group = lambda: None
+        m.is_pipeline_first_stage = lambda: True
+        m.is_pipeline_last_stage = lambda: True
+    torch.Tensor.cuda = lambda self, *a_, **k_: self
+    torch.cuda.current_device = lambda: "cpu"
+    utils = importlib.import_module("long_vita_megatron.training.utils")
+    batch = utils.get_batch_on_this_tp_rank(iter(tp_batch_data(case)) if rank == 0 else None)
+    out = {k: v for k, v in batch.items()}
+    out["actual_seq_len"] = utils.get_actual_seq_len() if case["reset"] else None
+    torch.save(out, os.path.join(out_dir, f"rank{rank}.pt"))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def golden_tp_batch():
+    out = {"cases": []}
+    for case in TP_BATCH_CASES:
+        ranks = _run_ranks(_tp_batch_worker, case)
+        out["cases"].append(dict(case, ranks=ranks))
+    torch.save(out, os.path.join(OUT, "tp_batch.pt"))
+
+
 def golden_loss_func():
     out = {"cases": []}
     for case in LOSS_CASES:
@@ -1117,7 +1170,7 @@ def main():
                      ("external_inputs", golden_external_inputs), ("decode_loop", golden_decode_loop), ("loss_func", golden_loss_func), ("unfused_attention", golden_unfused_attention),
                      ("converters", golden_converters), ("sampling", golden_sampling), ("patch_manager", golden_patch_manager),
                      ("adaptor_targets", golden_adaptor_targets), ("packed_positions", golden_packed_positions),
-                     ("ckpt_scripts", golden_ckpt_scripts)]:
+                     ("ckpt_scripts", golden_ckpt_scripts), ("tp_batch", golden_tp_batch)]:
         if only and name not in only:
             continue
         fn()

@@ -28,7 +28,8 @@ def _grads(p):
 
 
 def loss_and_grads(tokens, labels, loss_mask, params, cfg: ollm.LLMConfig, cp_size: int = 1,
-                   is_instruction: bool = True, feature_fn=None, indices=None, position_ids=None):
+                   is_instruction: bool = True, feature_fn=None, indices=None, position_ids=None,
+                   output_multiplier_scale=None, output_logit_softcapping=None):
     """Mean cross-entropy over the logit-masked rows, with the reference's per-rank selection and
     instruction shift: rank r keeps the masked positions among ITS zig-zag positions (local order),
     pairs logits[k] with labels[k+1] of that selection (gpt_vl_model.py:380-391), all ranks' pairs are
@@ -63,6 +64,7 @@ def loss_and_grads(tokens, labels, loss_mask, params, cfg: ollm.LLMConfig, cp_si
         if sel.numel() == 0:
             continue
         logits = ollm.linear(h[sel, 0], p["lm_head"])                         # bf16 logits like the GPU GEMM
+        logits = glue.logit_postprocess(logits, output_multiplier_scale, output_logit_softcapping)     # gpt_vl_model.py:349-355
         lab = labels[0, sel]
         if is_instruction:
             logits, lab = logits[:-1], lab[1:]

@@ -405,3 +405,20 @@ def test_gemm_siglip_epilogues(ops):
         assert float((d / (ref.float().abs() + 1.0)).max()) < 2e-2
     with pytest.raises(ValueError):
         ops.gemm(ad, wd, ops.EPI_BIAS2_RES, bd)                              # residual required
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("scale,cap", [(0.5, 0.0), (0.0, 30.0), (1.7, 20.0)])
+def test_logit_scale_and_softcap(ops, scale, cap):
+    """args.output_multiplier_scale / output_logit_softcapping (M/core/models/multimodal/gpt_vl_model.py:349-355): the
+    reference's bf16 op chain; the backward factor against torch autograd of the same expression in fp32."""
+    x = (torch.randn(5, 152064, generator=g(71)) * 12).bfloat16()
+    ref = glue.logit_postprocess(x, scale or None, cap or None)
+    out = ops.logit_postprocess_(x.to(DEV).clone(), scale, cap).cpu()
+    d = (out.view(torch.int16).int() - ref.view(torch.int16).int()).abs()          # device tanhf vs host tanh: <= 1 bf16 ulp
+    assert int(d.max()) <= 1 and float((d > 0).float().mean()) < 2e-2
+    xf = x.float().requires_grad_(True)
+    glue.logit_postprocess(xf, scale or None, cap or None).backward(torch.ones_like(xf))
+    gr = torch.ones(5, 152064).bfloat16().to(DEV)
+    ops.logit_postprocess_bwd_(out.to(DEV), gr, scale, cap)
+    assert rel_l2(gr, xf.grad) < 1e-2

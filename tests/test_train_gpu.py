@@ -64,6 +64,22 @@ def test_train_step_cp1_vs_autograd(amd, S, n_ans):
     _check_grads(g, g_ref, 4e-2)
 
 
+def test_train_step_with_logit_scale_and_softcap(amd):
+    """output_multiplier_scale / output_logit_softcapping (gpt_vl_model.py:349-355) in the loss and its gradient."""
+    S = 512
+    ocfg = ollm.LLMConfig(**SMALL)
+    p = ollm.init_llm_params(ocfg, seed=21)
+    tokens, labels, loss_mask = _data(S, SMALL["vocab"], 60, 22)
+    loss_ref, g_ref = otrain.loss_and_grads(tokens, labels, loss_mask, p, ocfg, output_multiplier_scale=3.0, output_logit_softcapping=5.0)
+    G = amd["gpt"]
+    model = G.GPTVLModel.from_oracle_layout(G.GPTConfig(**SMALL, output_multiplier_scale=3.0, output_logit_softcapping=5.0), p, None, DEV)
+    loss, g_ = amd["train"].TrainStep(model).forward_backward(tokens.to(DEV), labels.to(DEV), loss_mask.to(DEV))
+    assert abs(float(loss) - float(loss_ref)) < 2e-2 * abs(float(loss_ref))
+    _check_grads(g_, g_ref, 5e-2)
+    plain_ref, _ = otrain.loss_and_grads(tokens, labels, loss_mask, p, ocfg)
+    assert abs(float(plain_ref) - float(loss_ref)) > 1e-3          # the options really change the loss
+
+
 class _FakeGroup:
     def __init__(self, cp):
         self.cp, self.slots, self.barrier = cp, {}, threading.Barrier(cp)
