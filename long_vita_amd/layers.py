@@ -281,14 +281,26 @@ class LayerNormColumnParallelLinear(ColumnParallelLinear):
         return super().forward(xn)
 
 
+class ResidualAddFn(torch.autograd.Function):
+    """residual + x as one library kernel (vita_add_bf16); the gradient passes to both unchanged."""
+
+    @staticmethod
+    def forward(ctx, x, residual):
+        return ops.add_(x.contiguous().clone(), residual.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        return g, g
+
+
 def get_bias_dropout_add(training: bool, fused: bool):
     """megatron.core.fusions.fused_bias_dropout.get_bias_dropout_add for this path: no linear bias, dropout 0 (stage-3
-    `--attention-dropout 0.0 --hidden-dropout 0.0`): residual + x as one library kernel when nothing needs a gradient;
-    anything else (a bias, dropout > 0, autograd) takes Megatron's unfused torch expression."""
+    `--attention-dropout 0.0 --hidden-dropout 0.0`): residual + x through the library (ResidualAddFn); a bias or dropout > 0
+    in training mode takes Megatron's unfused torch expression (not on the Long-VITA path)."""
     def _bda(x_with_bias, residual, prob):
         x, bias = x_with_bias
-        if bias is None and (prob == 0.0 or not training) and not (torch.is_grad_enabled() and (x.requires_grad or residual.requires_grad)):
-            return ops.add_(x.contiguous().clone(), residual.contiguous())
+        if bias is None and (prob == 0.0 or not training):
+            return ResidualAddFn.apply(x, residual)
         if bias is not None:
             x = x + bias
         out = torch.nn.functional.dropout(x, p=prob, training=training)

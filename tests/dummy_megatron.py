@@ -139,8 +139,10 @@ class SelfAttention(torch.nn.Module):
         self.query_projection_size = config.kv_channels * config.num_attention_heads
         self.kv_projection_size = config.kv_channels * config.num_query_groups
         self.hidden_size_per_attention_head = config.kv_channels
-        self.num_attention_heads_per_partition = config.num_attention_heads
-        self.num_query_groups_per_partition = config.num_query_groups
+        from megatron.core import parallel_state
+        world = parallel_state.get_tensor_model_parallel_world_size()
+        self.num_attention_heads_per_partition = config.num_attention_heads // world
+        self.num_query_groups_per_partition = config.num_query_groups // world
         self.core_attention = build_module(submodules.core_attention, config=config, layer_number=layer_number,
                                            attn_mask_type=attn_mask_type, attention_type="self")
         self.linear_proj = build_module(submodules.linear_proj, self.query_projection_size, config.hidden_size, config=config,
@@ -270,7 +272,10 @@ def install():
             raise AssertionError("Megatron's unfused attention must not run")
     sys.modules["megatron.core.transformer.dot_product_attention"].DotProductAttention = _UpstreamDPA
     ps = sys.modules["megatron.core.parallel_state"]
-    ps.model_parallel_is_initialized = lambda: False     # TP = CP = 1: long_vita_amd.parallel_state's own defaults answer
+    ps.model_parallel_is_initialized = lambda: False     # long_vita_amd.parallel_state's own (thread-local, test-set) state answers
+    from long_vita_amd import parallel_state as own
+    ps.get_tensor_model_parallel_world_size = own.get_tensor_model_parallel_world_size
+    ps.get_tensor_model_parallel_rank = own.get_tensor_model_parallel_rank
     return sorted(names)
 
 

@@ -148,3 +148,62 @@ def test_embedding_and_masked_output_layer_modules_against_the_reference_fixture
     assert max(e_y, e_dx, e_dw) < 4e-3, (e_y, e_dx, e_dw)
     keep = m["mask"][0].to(DEV)
     assert float(x.grad[~keep].abs().max()) == 0.0           # zeros.masked_scatter (M/core/tensor_parallel/layers.py:455-460)
+
+
+def test_sequence_parallel_tensor_parallel_layer_matches_the_unsharded_oracle(megatron, monkeypatch):
+    """`--sequence-parallel` with TP = 2 (every reference script passes it, stage3 .sh:151; BASELINE config 5): the Megatron-built
+    layer on two simulated tensor-parallel ranks — column-parallel linears all-gather their sequence shard over the TP group
+    (M/core/tensor_parallel/layers.py:392-399) and reduce-scatter the input gradient (:483-494), row-parallel linears
+    reduce-scatter their output (:1095) — reassembled == the unsharded oracle layer, forward and backward."""
+    from long_vita_amd import parallel_state as mpu, tensor_parallel as tpar
+    from long_vita_amd.gpt_vl_model import GPTConfig
+    from test_train_gpu import _run_grid
+    tp, S = 2, 512
+    ocfg = ollm.LLMConfig(**CFG)
+    p = ollm.init_llm_params(ocfg, seed=41)
+    lp = p["layers"][0]
+    g = torch.Generator().manual_seed(42)
+    x = (torch.randn(S, 1, CFG["hidden"], generator=g) * 0.5).bfloat16()
+    w_out = torch.randn(S, 1, CFG["hidden"], generator=g).bfloat16()
+    freqs = glue.rope_emb(S, glue.rope_inv_freq(ocfg.head_dim, ocfg.rope_theta))
+    xo = x.clone().requires_grad_(True)
+    lpo = {k: v.clone().requires_grad_(True) for k, v in lp.items()}
+    ref, _ = ollm.decoder_layer(xo, lpo, ocfg, freqs, lambda q, k, v: oattn.core_attention(q, k, v, causal=True))
+    (ref.float() * w_out.float()).sum().backward()
+
+    def rank_fn(ci, ti):
+        shard, _ = tpar.shard_llm_params(p, GPTConfig(**CFG), tp, ti)
+        sl = shard["layers"][0]
+        mcfg = dm.TransformerConfig(hidden_size=CFG["hidden"], num_attention_heads=CFG["heads"], num_query_groups=CFG["kv_groups"],
+                                    kv_channels=CFG["head_dim"], ffn_hidden_size=CFG["ffn"], sequence_parallel=True,
+                                    tensor_model_parallel_size=tp)
+        layer = dm.build_module(megatron.get_gpt_layer_with_transformer_engine_spec(), config=mcfg, layer_number=1)
+        assert layer.self_attention.linear_qkv.sequence_parallel and layer.mlp.linear_fc2.sequence_parallel
+        assert tuple(layer.self_attention.linear_qkv.weight.shape) == tuple(sl["qkv_w"].shape)
+        _load(layer, sl, True)
+        n = S // tp
+        xs = x[ti * n:(ti + 1) * n].to(DEV).requires_grad_(True)                     # this rank's sequence shard
+        out, _ = layer(xs, attention_mask=None, rotary_pos_emb=freqs.to(DEV))
+        assert out.shape == (n, 1, CFG["hidden"])
+        (out.float() * w_out[ti * n:(ti + 1) * n].to(DEV).float()).sum().backward()
+        grads = {k: v.grad.detach().clone() for k, v in layer.named_parameters()}
+        return out.detach(), xs.grad.detach(), grads
+
+    outs = _run_grid(tp, 1, rank_fn, {"mpu": mpu}, monkeypatch)
+    out = torch.cat([outs[(0, t)][0] for t in range(tp)], 0)
+    dx = torch.cat([outs[(0, t)][1] for t in range(tp)], 0)
+    assert rel_l2(out, ref) < 1e-2, rel_l2(out, ref)
+    assert rel_l2(dx, xo.grad) < 5e-2, rel_l2(dx, xo.grad)
+    gs = [outs[(0, t)][2] for t in range(tp)]
+    d, qpg, ng = CFG["head_dim"], CFG["heads"] // CFG["kv_groups"], CFG["kv_groups"]
+    cat0 = lambda k: torch.cat([g_[k] for g_ in gs], 0)                               # noqa: E731
+    errs = {"qkv_w": rel_l2(cat0("self_attention.linear_qkv.weight"), lpo["qkv_w"].grad),
+            "qkv_b": rel_l2(cat0("self_attention.linear_qkv.bias"), lpo["qkv_b"].grad),
+            "o_w": rel_l2(torch.cat([g_["self_attention.linear_proj.weight"] for g_ in gs], 1), lpo["o_w"].grad),
+            "fc2_w": rel_l2(torch.cat([g_["mlp.linear_fc2.weight"] for g_ in gs], 1), lpo["fc2_w"].grad),
+            # sequence-parallel parameters (norm weights): each rank saw its sequence shard, Megatron all-reduces their grads
+            "ln1": rel_l2(sum(g_["self_attention.linear_qkv.layer_norm_weight"].float() for g_ in gs), lpo["ln1"].grad),
+            "ln2": rel_l2(sum(g_["mlp.linear_fc1.layer_norm_weight"].float() for g_ in gs), lpo["ln2"].grad)}
+    halves = [g_["mlp.linear_fc1.weight"].chunk(2, 0) for g_ in gs]
+    errs["fc1_w"] = rel_l2(torch.cat([h_[0] for h_ in halves] + [h_[1] for h_ in halves], 0), lpo["fc1_w"].grad)
+    assert max(errs.values()) < 5e-2, errs
