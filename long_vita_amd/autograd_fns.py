@@ -64,7 +64,8 @@ class LinearFn(torch.autograd.Function):
         ctx.save_for_backward(input, weight, logit_mask)
         ctx.use_bias = bias is not None
         ctx.allreduce_dgrad, ctx.sequence_parallel = allreduce_dgrad, sequence_parallel
-        total_input = _gather_sequence(input) if sequence_parallel else input                     # :392-400
+        ctx.tp, ctx.group = _tp()       # captured here: the backward runs on autograd's own thread
+        total_input = _gather_sequence(input, ctx.tp, ctx.group) if sequence_parallel else input  # :392-400
         s, b, c = total_input.shape
         x = total_input.reshape(s * b, c)
         if logit_mask is not None:                                                                 # :402-407
@@ -81,8 +82,8 @@ class LinearFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, grad_output):
         input, weight, logit_mask = ctx.saved_tensors
-        tp, group = _tp()
-        total_input = _gather_sequence(input) if ctx.sequence_parallel else input                 # :435-452
+        tp, group = ctx.tp, ctx.group
+        total_input = _gather_sequence(input, tp, group) if ctx.sequence_parallel else input      # :435-452
         s, b, c = total_input.shape
         go = grad_output.reshape(-1, grad_output.shape[-1]).contiguous()
         grad_input = dgrad(go, weight)                                                             # :453
@@ -109,9 +110,10 @@ class LinearFn(torch.autograd.Function):
         return grad_input, grad_weight, grad_bias, None, None, None
 
 
-def _gather_sequence(x: torch.Tensor) -> torch.Tensor:
+def _gather_sequence(x: torch.Tensor, tp=None, group=None) -> torch.Tensor:
     """[s / TP, b, c] -> [s, b, c] over the tensor-parallel group (layers.py:392-399: _all_gather_base along dim 0)."""
-    tp, group = _tp()
+    if tp is None:
+        tp, group = _tp()
     if tp == 1:
         return x
     out = torch.empty((x.shape[0] * tp,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
@@ -140,7 +142,7 @@ class ReduceScatterToSP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x):
-        tp, group = _tp()
+        tp, group = ctx.tp, ctx.group = _tp()
         if tp == 1:
             return x
         out = torch.empty((x.shape[0] // tp,) + tuple(x.shape[1:]), dtype=x.dtype, device=x.device)
@@ -149,7 +151,7 @@ class ReduceScatterToSP(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        return _gather_sequence(g)
+        return _gather_sequence(g, ctx.tp, ctx.group)
 
 
 class CopyToTP(torch.autograd.Function):
@@ -157,11 +159,12 @@ class CopyToTP(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x):
+        ctx.tp, ctx.group = _tp()
         return x
 
     @staticmethod
     def backward(ctx, g):
-        tp, group = _tp()
+        tp, group = ctx.tp, ctx.group
         if tp > 1:
             g = g.contiguous()
             dist.all_reduce(g, group=group)
@@ -174,6 +177,7 @@ class GatherFromTP(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x):
         tp, group = _tp()
+        ctx.tp, ctx.rank = tp, mpu.get_tensor_model_parallel_rank()
         if tp == 1:
             return x
         flat = torch.empty((tp,) + tuple(x.shape), dtype=x.dtype, device=x.device)
@@ -182,10 +186,9 @@ class GatherFromTP(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, g):
-        tp, _ = _tp()
+        tp, r = ctx.tp, ctx.rank
         if tp == 1:
             return g
-        r = mpu.get_tensor_model_parallel_rank()
         n = g.shape[-1] // tp
         return g[..., r * n:(r + 1) * n].contiguous()
 

@@ -172,6 +172,12 @@ def test_sequence_parallel_tensor_parallel_layer_matches_the_unsharded_oracle(me
     (ref.float() * w_out.float()).sum().backward()
 
     def rank_fn(ci, ti):
+        # the simulated ranks are threads: autograd must run each rank's backward (with its collectives) on that rank's
+        # own thread, not on the engine's shared device thread
+        with torch.autograd.set_multithreading_enabled(False):
+            return rank_body(ci, ti)
+
+    def rank_body(ci, ti):
         shard, _ = tpar.shard_llm_params(p, GPTConfig(**CFG), tp, ti)
         sl = shard["layers"][0]
         mcfg = dm.TransformerConfig(hidden_size=CFG["hidden"], num_attention_heads=CFG["heads"], num_query_groups=CFG["kv_groups"],
