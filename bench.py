@@ -142,8 +142,11 @@ def main():
     ap.add_argument("--frames", type=int, default=-1, help="debug only; default fills the sequence (506 @128K)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-parity-check", action="store_true")
+    ap.add_argument("--dry-run", action="store_true", help="plumbing check: tiny model (2 + 2 layers, seq 4096, 8 frames); NOT a measurement")
     args = ap.parse_args()
 
+    if args.dry_run:
+        args.seq, args.layers, args.vit_layers, args.frames, args.no_cpu_baseline = 4096, 2, 2, 8, True
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -151,7 +154,7 @@ def main():
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: launch with torch.distributed.run")
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
-    if world > 1:
+    if world > 1 or "MASTER_ADDR" in os.environ and args.dry_run:
         dist.init_process_group("nccl", device_id=torch.device(dev))
 
     from long_vita_amd import generation, gpt_vl_model, lib, parallel_state as mpu, synthetic, vision
@@ -171,7 +174,7 @@ def main():
         return generation.prefill_step(model, tokens, seq, ext, reference_compat=False)
 
     def fence():
-        if world > 1:
+        if dist.is_initialized():
             dist.barrier()
         torch.cuda.synchronize()
 
@@ -234,7 +237,7 @@ def main():
         "dtype": "bf16", "data": "synthetic",
         "config": {"workload": f"{name} prefill: {frames}-frame synthetic video (InternViT-300M + projector) + "
                                f"Qwen2.5-14B decoder ({cfg.num_layers} layers), seq {seq}, logits-masked LM head",
-                   "seq_len": seq, "frames": frames, "global_batch": 1, "parallelism": f"cp{world}",
+                   "seq_len": seq, "frames": frames, "global_batch": 1, "parallelism": f"cp{world}", "dry_run": bool(args.dry_run),
                    "weights": "seeded random bf16 (N(0,0.02))",
                    "algorithmic_gflop_per_token": fpt / 1e9,
                    "end_to_end_tflops_per_gpu": fpt * value / world / 1e12,
@@ -256,7 +259,7 @@ def main():
         else:
             line["cpu_baseline"] = None
         print(json.dumps(line), flush=True)
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
 

@@ -1,0 +1,99 @@
+"""Two REAL RCCL ranks (VERDICT r1 "next round" item 6) — runs whenever the box has >= 2 GPUs, skipped otherwise (the builder's
+GPU box has one; the simulated-rank tests in test_model_gpu.py / test_train_gpu.py / test_decode_gpu.py cover the same code with
+in-process collectives).  One process per GPU over torch.distributed "nccl" (= RCCL on ROCm), rendezvous on 127.0.0.1:
+  * CP = 2 prefill through DotProductAttention.forward_cp (packed K/V all-gather per kv-head split, zig-zag chunk tables) with
+    the logits gathered by sync_output            == the CP = 1 prefill of the same model (computed by rank 0 alone);
+  * the training step: K/V all-gather, dK/dV reduce-scatter, loss / gradient all-reduce   == CP = 1 loss and gradients;
+  * cached decode over the sequence-sharded KV cache   == CP = 1 tokens."""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+_WORKER = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["VITA_ROOT"])
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(rank)
+dev = f"cuda:{rank}"
+dist.init_process_group("nccl", device_id=torch.device(dev))
+from long_vita_amd import generation, gpt_vl_model, lib, parallel_state as mpu, training
+lib.load(allow_build=False)
+cfgd = dict(num_layers=2, hidden=1024, heads=8, kv_groups=4, head_dim=128, ffn=2816, vocab=1024)
+S = 2048
+def rel(a, b): return float((a.float() - b.float()).norm() / b.float().norm())
+g = torch.Generator().manual_seed(7)
+tokens = torch.randint(0, cfgd["vocab"], (1, S), generator=g).to(dev)
+labels = torch.randint(0, cfgd["vocab"], (1, S), generator=g).to(dev)
+loss_mask = torch.zeros(1, S, device=dev); loss_mask[0, S - 200:] = 1; loss_mask[0, 300:320] = 1
+model = gpt_vl_model.GPTVLModel.random_init(gpt_vl_model.GPTConfig(**cfgd), seed=5, device=dev)
+# ---- CP = 1 references (every rank computes them alone, no process group in the way) ----
+mpu.destroy_model_parallel()
+ref_logits = generation.prefill_step(model, tokens, S, None, reference_compat=False)
+ref_loss, ref_grads = training.TrainStep(model).forward_backward(tokens, labels, loss_mask)
+def decode(n_new=6, P=1024):
+    buf = torch.zeros(1, P + 64, dtype=torch.long, device=dev)
+    buf[:, :P] = tokens[:, :P]
+    it = generation.generate_tokens_probs_and_return_on_first_stage(model, buf, torch.tensor([P], device=dev), use_kv_cache=True)
+    for i, _ in enumerate(it):
+        if i + 1 == n_new:
+            break
+    return buf[:, :P + n_new].clone()
+ref_gen = decode()
+# ---- CP = world over RCCL ----
+mpu.initialize_model_parallel()
+assert mpu.get_context_parallel_world_size() == world
+out = generation.prefill_step(model, tokens, S, None, reference_compat=False)
+assert rel(out, ref_logits) < 1e-2, rel(out, ref_logits)
+loss, grads = training.TrainStep(model).forward_backward(tokens, labels, loss_mask)
+training.allreduce_grads(grads)
+assert abs(float(loss) - float(ref_loss)) < 1e-2 * abs(float(ref_loss)), (float(loss), float(ref_loss))
+for k in ("embed", "lm_head", "final_ln"):
+    assert rel(grads[k], ref_grads[k]) < 3e-2, (k, rel(grads[k], ref_grads[k]))
+for gl, rl in zip(grads["layers"], ref_grads["layers"]):
+    for k in rl:
+        assert rel(gl[k], rl[k]) < 3e-2, (k, rel(gl[k], rl[k]))
+gen = decode()
+assert torch.equal(gen.cpu(), ref_gen.cpu())
+dist.barrier()
+dist.destroy_process_group()
+print("OK", rank)
+"""
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (real RCCL ranks)")
+def test_two_real_rccl_ranks_match_cp1(tmp_path):
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(2):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   VITA_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for p in procs:
+        out, _ = p.communicate(timeout=540)
+        assert p.returncode == 0 and "OK" in out, out
+
+
+def test_bench_dry_run_goes_through_the_distributed_plumbing():
+    """`torchrun ... bench.py --gpus N --dry-run`: argument parsing, process-group set-up, model construction, one tiny step,
+    the JSON line — here with N = 1 through the same launcher the driver uses for N = 2, 4, 8."""
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", "1", "--master-addr", "127.0.0.1",
+           "--master-port", str(port), os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--dry-run"]
+    r = subprocess.run(cmd, capture_output=True, text=True, timeout=500, env=dict(os.environ, HSA_ENABLE_IPC_MODE_LEGACY="0"))
+    assert r.returncode == 0, r.stdout + r.stderr
+    import json
+    line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
+    assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["dry_run"] is True
