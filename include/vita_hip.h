@@ -223,6 +223,45 @@ typedef struct {
 int vita_flash_attn_fwd(const vita_attn_params* p, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
+ * Context-parallel core attention for callers without PyTorch (cp_attn.hip): the K/V exchange of one decoder layer over
+ * RCCL + the zig-zag chunk-table attention.  Replaces TransformerEngine's AttnFuncWithCP (the core_attention of
+ * M/core/models/gpt/gpt_layer_specs.py:40 under --context-parallel-size > 1: a CP-1-step P2P ring) with one all-gather per
+ * kv-head split issued up front on a communication stream — xGMI is point to point, every peer pushes over its own link —
+ * and, in the backward, one reduce-scatter of dK / dV per split.  Rank r owns zig-zag chunks {r, 2 CP - 1 - r} of the
+ * sequence (M/training/utils.py:329-341); s_local = the two chunks together.
+ *
+ * vita_cp_unique_id / vita_cp_init / vita_cp_destroy: the RCCL communicator of the context-parallel group (ncclGetUniqueId on
+ *   one rank, shipped to the others by any channel, then ncclCommInitRank), the communication stream and its events.  The only
+ *   persistent state of the library (SURVEY.md §8b "Ownership"); RCCL is resolved at run time, so nothing here is needed —
+ *   or loaded — on the single-GPU path.  cp_size = 1 is valid (the exchange degenerates to a copy through RCCL).
+ * vita_cp_attn_fwd: q = this rank's rotated queries as a grouped view (head h of kv group g at q + row * q_row_stride +
+ *   g * q_group_stride + h * q_head_stride); kv_packed = its rotated K and V packed [n_split][2 (K | V)][s_local][n_kv_heads /
+ *   n_split][head_dim] (what vita_rope_qkv_fwd writes); out [s_local][n_q_heads][head_dim] via out_row/head_stride; lse
+ *   (optional) [n_q_heads][s_local].  workspace = vita_cp_attn_workspace_bytes(...) of device memory, caller-owned: the gathered
+ *   K/V; it is the `k`/`v` of the backward.  Everything is stream-ordered behind `stream`.
+ * vita_cp_attn_bwd: d_out like out; lse from the forward; delta from vita_attn_delta; dq like q; dkv_packed like kv_packed
+ *   receives this rank's dK / dV; p->dkv_workspace (same size as workspace) takes the gathered-layout dK / dV. */
+typedef struct vita_cp_context vita_cp_context;
+typedef struct {
+  const void* q; int64_t q_row_stride, q_head_stride, q_group_stride;
+  const void* kv_packed;
+  void* out; int64_t out_row_stride, out_head_stride;
+  float* lse;
+  int64_t s_local;
+  int n_q_heads, n_kv_heads, head_dim, n_split;
+  float softmax_scale;
+  void* workspace; size_t workspace_bytes;
+  void* dkv_workspace;
+} vita_cp_attn_params;
+int vita_cp_unique_id(void* id_out128);
+int vita_cp_init(vita_cp_context** ctx, int cp_size, int cp_rank, const void* unique_id128);
+int vita_cp_destroy(vita_cp_context* ctx);
+size_t vita_cp_attn_workspace_bytes(int cp_size, int64_t s_local, int n_kv_heads, int head_dim);
+int vita_cp_attn_fwd(vita_cp_context* ctx, const vita_cp_attn_params* p, void* stream);
+int vita_cp_attn_bwd(vita_cp_context* ctx, const vita_cp_attn_params* p, const void* d_out, const float* lse,
+                     const float* delta, void* dq, void* dkv_packed, void* stream);
+
+/* ---------------------------------------------------------------------------------------------
  * ViT front / back ends.
  * vita_patchify14: im2col of the 14x14 / stride-14 patch conv (M/core/models/vision/intern_vit_model.py:139-145,203-205):
  *   images [n, 3, H, W] bf16 -> patches [n * (H/14) * (W/14), k_pad] bf16, column = c*196 + dy*14 + dx

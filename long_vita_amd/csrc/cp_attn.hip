@@ -1,0 +1,225 @@
+// Context-parallel core attention behind the C ABI: the K/V exchange of one decoder layer + the zig-zag chunk-table attention,
+// for callers that are not Python (vita_cp_attn_fwd / _bwd, vita_cp_init / vita_cp_destroy owning the RCCL
+// communicator and the communication stream).  The Python operator mirror (dot_product_attention.DotProductAttention.forward_cp)
+// does the same over torch.distributed; this is that path without torch.
+//
+// Replaces TransformerEngine's AttnFuncWithCP (the `core_attention=TEDotProductAttention` of M/core/models/gpt/gpt_layer_specs.py:40
+// under --context-parallel-size > 1): a CP-1-step P2P ring.  xGMI is point to point, so a ring is single-link bound; here every
+// rank pushes its shard to every peer at once:
+//   forward : per kv-head split j ONE ncclAllGather of the packed shard [2 (K | V)][S_l][hg][d] -> [CP][2][S_l][hg][d], all splits
+//             issued up front on the communication stream; the attention over split j (compute stream) waits only for the
+//             event behind gather j, so gathers j+1.. run under it.  Global chunk 2p+h of the gathered buffer is zig-zag chunk
+//             (h ? 2CP-1-p : p) (M/training/utils.py:329-341); the kernel addresses it through chunk tables.
+//   backward: vita_flash_attn_bwd writes dK / dV of every visible key in the gathered layout, ONE ncclReduceScatter (sum, bf16)
+//             per split returns each rank its shard.
+// RCCL is resolved at run time (dlsym): inside a PyTorch process that is the librccl torch already loaded, a plain C host gets
+// librccl.so from the ROCm installation.  No symbol of this file is needed by the single-GPU path.
+#include "vita_common.h"
+#include <dlfcn.h>
+#include <stdlib.h>
+#include <string.h>
+
+extern "C" int vita_flash_attn_fwd(const vita_attn_params* p, void* stream);
+extern "C" int vita_flash_attn_bwd(const vita_attn_bwd_params* p, void* stream);
+
+namespace {
+
+typedef struct ncclComm* ncclComm_t;
+typedef struct { char internal[128]; } ncclUniqueId;
+constexpr int kNcclBfloat16 = 9, kNcclSum = 0;        // rccl.h: ncclDataType_t / ncclRedOp_t
+constexpr int kMaxSplit = 8, kMaxCP = 16;
+
+struct Rccl {
+  int (*GetUniqueId)(ncclUniqueId*);
+  int (*CommInitRank)(ncclComm_t*, int, ncclUniqueId, int);
+  int (*CommDestroy)(ncclComm_t);
+  int (*AllGather)(const void*, void*, size_t, int, ncclComm_t, hipStream_t);
+  int (*ReduceScatter)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t);
+  bool ok;
+};
+
+Rccl& rccl() {
+  static Rccl r = [] {
+    Rccl x;
+    memset(&x, 0, sizeof(x));
+    void* h = RTLD_DEFAULT;
+    if (!dlsym(h, "ncclAllGather")) {
+      h = dlopen("librccl.so.1", RTLD_NOW | RTLD_GLOBAL);
+      if (!h) h = dlopen("librccl.so", RTLD_NOW | RTLD_GLOBAL);
+      if (!h) return x;
+    }
+    x.GetUniqueId = (int (*)(ncclUniqueId*))dlsym(h, "ncclGetUniqueId");
+    x.CommInitRank = (int (*)(ncclComm_t*, int, ncclUniqueId, int))dlsym(h, "ncclCommInitRank");
+    x.CommDestroy = (int (*)(ncclComm_t))dlsym(h, "ncclCommDestroy");
+    x.AllGather = (int (*)(const void*, void*, size_t, int, ncclComm_t, hipStream_t))dlsym(h, "ncclAllGather");
+    x.ReduceScatter = (int (*)(const void*, void*, size_t, int, int, ncclComm_t, hipStream_t))dlsym(h, "ncclReduceScatter");
+    x.ok = x.GetUniqueId && x.CommInitRank && x.CommDestroy && x.AllGather && x.ReduceScatter;
+    return x;
+  }();
+  return r;
+}
+
+}  // namespace
+
+struct vita_cp_context {
+  ncclComm_t comm;
+  int cp_size, cp_rank;
+  hipStream_t comm_stream;
+  hipEvent_t ready;                 // compute -> communication: the packed shard is written
+  hipEvent_t gathered[kMaxSplit];   // communication -> compute: gather j has landed
+  hipEvent_t reduced;               // communication -> compute: the reduce-scatters have landed
+};
+
+extern "C" int vita_cp_unique_id(void* id_out128) {
+  if (!id_out128) return VITA_ERR_INVALID_ARG;
+  if (!rccl().ok) return VITA_ERR_UNSUPPORTED;
+  ncclUniqueId id;
+  if (rccl().GetUniqueId(&id) != 0) return VITA_ERR_LAUNCH;
+  memcpy(id_out128, id.internal, 128);
+  return VITA_OK;
+}
+
+extern "C" int vita_cp_init(vita_cp_context** out, int cp_size, int cp_rank, const void* unique_id128) {
+  if (!out || !unique_id128 || cp_size < 1 || cp_size > kMaxCP || cp_rank < 0 || cp_rank >= cp_size) return VITA_ERR_INVALID_ARG;
+  if (!rccl().ok) return VITA_ERR_UNSUPPORTED;
+  vita_cp_context* c = (vita_cp_context*)calloc(1, sizeof(vita_cp_context));
+  if (!c) return VITA_ERR_LAUNCH;
+  ncclUniqueId id;
+  memcpy(id.internal, unique_id128, 128);
+  if (rccl().CommInitRank(&c->comm, cp_size, id, cp_rank) != 0) { free(c); return VITA_ERR_LAUNCH; }
+  c->cp_size = cp_size; c->cp_rank = cp_rank;
+  bool ok = hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->ready, hipEventDisableTiming) == hipSuccess;
+  ok = ok && hipEventCreateWithFlags(&c->reduced, hipEventDisableTiming) == hipSuccess;
+  for (int j = 0; j < kMaxSplit && ok; ++j) ok = hipEventCreateWithFlags(&c->gathered[j], hipEventDisableTiming) == hipSuccess;
+  if (!ok) { rccl().CommDestroy(c->comm); free(c); return VITA_ERR_LAUNCH; }
+  *out = c;
+  return VITA_OK;
+}
+
+extern "C" int vita_cp_destroy(vita_cp_context* c) {
+  if (!c) return VITA_ERR_INVALID_ARG;
+  (void)hipStreamSynchronize(c->comm_stream);
+  for (int j = 0; j < kMaxSplit; ++j) (void)hipEventDestroy(c->gathered[j]);
+  (void)hipEventDestroy(c->ready);
+  (void)hipEventDestroy(c->reduced);
+  (void)hipStreamDestroy(c->comm_stream);
+  rccl().CommDestroy(c->comm);
+  free(c);
+  return VITA_OK;
+}
+
+extern "C" size_t vita_cp_attn_workspace_bytes(int cp_size, int64_t s_local, int n_kv_heads, int head_dim) {
+  return (size_t)cp_size * 2 * (size_t)s_local * n_kv_heads * head_dim * 2;            // the gathered K/V of one layer, bf16
+}
+
+namespace {
+
+struct Geo {
+  int32_t q_gid[2], kv_gid[2 * kMaxCP];
+  int64_t kv_row[2 * kMaxCP];
+};
+
+Geo make_geo(int cp, int r, int64_t s_local) {
+  Geo g;
+  const int64_t c = s_local / 2;
+  g.q_gid[0] = r; g.q_gid[1] = 2 * cp - 1 - r;
+  for (int p = 0; p < cp; ++p) {
+    g.kv_gid[2 * p] = p; g.kv_gid[2 * p + 1] = 2 * cp - 1 - p;
+    g.kv_row[2 * p] = (int64_t)p * 2 * s_local; g.kv_row[2 * p + 1] = (int64_t)p * 2 * s_local + c;
+  }
+  return g;
+}
+
+int check(const vita_cp_attn_params* p, const vita_cp_context* c) {
+  if (!p || !c || !p->q || !p->kv_packed || !p->workspace) return VITA_ERR_INVALID_ARG;
+  if (p->n_split < 1 || p->n_split > kMaxSplit || p->n_kv_heads % p->n_split || p->n_q_heads % p->n_kv_heads) return VITA_ERR_INVALID_ARG;
+  if (p->s_local <= 0 || (p->s_local & 1) || p->head_dim != 128) return VITA_ERR_UNSUPPORTED;
+  if (p->workspace_bytes < vita_cp_attn_workspace_bytes(c->cp_size, p->s_local, p->n_kv_heads, p->head_dim)) return VITA_ERR_INVALID_ARG;
+  return VITA_OK;
+}
+
+}  // namespace
+
+extern "C" int vita_cp_attn_fwd(vita_cp_context* c, const vita_cp_attn_params* p, void* stream) {
+  int rc = check(p, c);
+  if (rc != VITA_OK) return rc;
+  if (!p->out) return VITA_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int cp = c->cp_size, hg = p->n_kv_heads / p->n_split, G = p->n_q_heads / p->n_kv_heads, d = p->head_dim;
+  const int64_t s_l = p->s_local;
+  const size_t shard = (size_t)2 * s_l * hg * d;                                          // elements per rank and split
+  const bf16_t* kv = (const bf16_t*)p->kv_packed;
+  bf16_t* ws = (bf16_t*)p->workspace;
+  if (hipEventRecord(c->ready, st) != hipSuccess || hipStreamWaitEvent(c->comm_stream, c->ready, 0) != hipSuccess) return VITA_ERR_LAUNCH;
+  for (int j = 0; j < p->n_split; ++j) {
+    if (rccl().AllGather(kv + j * shard, ws + (size_t)j * cp * shard, shard, kNcclBfloat16, c->comm, c->comm_stream) != 0) return VITA_ERR_LAUNCH;
+    if (hipEventRecord(c->gathered[j], c->comm_stream) != hipSuccess) return VITA_ERR_LAUNCH;
+  }
+  const Geo g = make_geo(cp, c->cp_rank, s_l);
+  for (int j = 0; j < p->n_split; ++j) {
+    if (hipStreamWaitEvent(st, c->gathered[j], 0) != hipSuccess) return VITA_ERR_LAUNCH;
+    const bf16_t* rows = ws + (size_t)j * cp * shard;                                    // [cp][2][s_l][hg][d]: K of rank r at r*2*s_l rows, V at + s_l
+    vita_attn_params a;
+    memset(&a, 0, sizeof(a));
+    a.q = (const bf16_t*)p->q + (int64_t)j * hg * p->q_group_stride;
+    a.q_row_stride = p->q_row_stride; a.q_head_stride = p->q_head_stride; a.q_group_stride = p->q_group_stride;
+    a.k = rows; a.k_row_stride = (int64_t)hg * d; a.k_head_stride = d;
+    a.v = rows + (size_t)s_l * hg * d; a.v_row_stride = (int64_t)hg * d; a.v_head_stride = d;
+    a.o = (bf16_t*)p->out + (int64_t)j * hg * G * p->out_head_stride;
+    a.o_row_stride = p->out_row_stride; a.o_head_stride = p->out_head_stride;
+    a.lse = p->lse ? p->lse + (int64_t)j * hg * G * s_l : nullptr;
+    a.batch = 1; a.n_q_heads = hg * G; a.n_kv_heads = hg; a.head_dim = d;
+    a.chunk_len = s_l / 2; a.q_valid = a.kv_valid = s_l / 2;
+    a.n_q_chunks = 2; a.n_kv_chunks = 2 * cp;
+    a.q_chunk_gid = g.q_gid; a.kv_chunk_gid = g.kv_gid; a.kv_chunk_row = g.kv_row;
+    a.causal = 1; a.softmax_scale = p->softmax_scale;
+    rc = vita_flash_attn_fwd(&a, stream);
+    if (rc != VITA_OK) return rc;
+  }
+  return VITA_OK;
+}
+
+extern "C" int vita_cp_attn_bwd(vita_cp_context* c, const vita_cp_attn_params* p, const void* d_out, const float* lse,
+                                const float* delta, void* dq, void* dkv_packed, void* stream) {
+  int rc = check(p, c);
+  if (rc != VITA_OK) return rc;
+  if (!d_out || !lse || !delta || !dq || !dkv_packed || !p->dkv_workspace) return VITA_ERR_INVALID_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int cp = c->cp_size, hg = p->n_kv_heads / p->n_split, G = p->n_q_heads / p->n_kv_heads, d = p->head_dim;
+  const int64_t s_l = p->s_local;
+  const size_t shard = (size_t)2 * s_l * hg * d;
+  const bf16_t* ws = (const bf16_t*)p->workspace;                                        // gathered K/V of the forward (or its recompute)
+  bf16_t* dws = (bf16_t*)p->dkv_workspace;                                               // dK/dV in the gathered layout, same size
+  const Geo g = make_geo(cp, c->cp_rank, s_l);
+  for (int j = 0; j < p->n_split; ++j) {
+    const bf16_t* rows = ws + (size_t)j * cp * shard;
+    bf16_t* drows = dws + (size_t)j * cp * shard;
+    vita_attn_bwd_params b;
+    memset(&b, 0, sizeof(b));
+    b.q = (const bf16_t*)p->q + (int64_t)j * hg * p->q_group_stride;
+    b.q_row_stride = p->q_row_stride; b.q_head_stride = p->q_head_stride; b.q_group_stride = p->q_group_stride;
+    b.k = rows; b.k_row_stride = (int64_t)hg * d; b.k_head_stride = d;
+    b.v = rows + (size_t)s_l * hg * d; b.v_row_stride = (int64_t)hg * d; b.v_head_stride = d;
+    b.d_o = (const bf16_t*)d_out + (int64_t)j * hg * G * p->out_head_stride;
+    b.do_row_stride = p->out_row_stride; b.do_head_stride = p->out_head_stride;
+    b.lse = lse + (int64_t)j * hg * G * s_l; b.delta = delta + (int64_t)j * hg * G * s_l;
+    b.dq = (bf16_t*)dq + (int64_t)j * hg * p->q_group_stride;
+    b.dq_row_stride = p->q_row_stride; b.dq_head_stride = p->q_head_stride; b.dq_group_stride = p->q_group_stride;
+    b.dk = drows; b.dk_row_stride = (int64_t)hg * d; b.dk_head_stride = d;
+    b.dv = drows + (size_t)s_l * hg * d; b.dv_row_stride = (int64_t)hg * d; b.dv_head_stride = d;
+    b.n_q_heads = hg * G; b.n_kv_heads = hg; b.head_dim = d;
+    b.chunk_len = s_l / 2; b.n_q_chunks = 2; b.n_kv_chunks = 2 * cp;
+    b.q_chunk_gid = g.q_gid; b.kv_chunk_gid = g.kv_gid; b.kv_chunk_row = g.kv_row;
+    b.softmax_scale = p->softmax_scale;
+    rc = vita_flash_attn_bwd(&b, stream);
+    if (rc != VITA_OK) return rc;
+  }
+  if (hipEventRecord(c->ready, st) != hipSuccess || hipStreamWaitEvent(c->comm_stream, c->ready, 0) != hipSuccess) return VITA_ERR_LAUNCH;
+  for (int j = 0; j < p->n_split; ++j)
+    if (rccl().ReduceScatter(dws + (size_t)j * cp * shard, (bf16_t*)dkv_packed + j * shard, shard, kNcclBfloat16, kNcclSum, c->comm,
+                             c->comm_stream) != 0)
+      return VITA_ERR_LAUNCH;
+  if (hipEventRecord(c->reduced, c->comm_stream) != hipSuccess || hipStreamWaitEvent(st, c->reduced, 0) != hipSuccess) return VITA_ERR_LAUNCH;
+  return VITA_OK;
+}

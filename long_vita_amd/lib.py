@@ -79,6 +79,22 @@ class AttnBwdParams(C.Structure):
     ]
 
 
+class CpAttnParams(C.Structure):
+    """Mirror of ``vita_cp_attn_params`` (include/vita_hip.h)."""
+
+    _fields_ = [
+        ("q", C.c_void_p), ("q_row_stride", C.c_int64), ("q_head_stride", C.c_int64), ("q_group_stride", C.c_int64),
+        ("kv_packed", C.c_void_p),
+        ("out", C.c_void_p), ("out_row_stride", C.c_int64), ("out_head_stride", C.c_int64),
+        ("lse", C.c_void_p),
+        ("s_local", C.c_int64),
+        ("n_q_heads", C.c_int), ("n_kv_heads", C.c_int), ("head_dim", C.c_int), ("n_split", C.c_int),
+        ("softmax_scale", C.c_float),
+        ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
+        ("dkv_workspace", C.c_void_p),
+    ]
+
+
 class DecodeLayerParams(C.Structure):
     """Mirror of ``vita_decode_layer_params`` (include/vita_hip.h)."""
 
@@ -149,6 +165,12 @@ PROTOTYPES = {
     "vita_decode_layer_mlp": (_i, [C.POINTER(DecodeLayerParams), _p]),
     "vita_frames_resize_norm": (_i, [_p, _l, _i, _i, _i, _i, C.POINTER(C.c_int), _i, _i, _i, _i, _i, _i, _i, _p, _p, _i, _p, _p, _i,
                                       C.POINTER(C.c_float), C.POINTER(C.c_float), _p, _p, _p, _p]),
+    "vita_cp_unique_id": (_i, [_p]),
+    "vita_cp_init": (_i, [C.POINTER(_p), _i, _i, _p]),
+    "vita_cp_destroy": (_i, [_p]),
+    "vita_cp_attn_workspace_bytes": (C.c_size_t, [_i, _l, _i, _i]),
+    "vita_cp_attn_fwd": (_i, [_p, C.POINTER(CpAttnParams), _p]),
+    "vita_cp_attn_bwd": (_i, [_p, C.POINTER(CpAttnParams), _p, _p, _p, _p, _p, _p]),
     "vita_decode_attn_merge": (_i, [_p, _p, _p, _i, _l, _l, _i, _i, _p, _p, _p, _p, _p]),
 }
 

@@ -19,7 +19,7 @@ def test_library_builds_and_exports_every_declared_symbol():
     from long_vita_amd import lib
     lib.build()
     declared = set(re.findall(r"\b(vita_[a-z0-9_]+)\s*\(", open(lib.HEADER_PATH).read()))
-    declared -= {"vita_attn_params", "vita_attn_bwd_params", "vita_decode_layer_params"}
+    declared -= {"vita_attn_params", "vita_attn_bwd_params", "vita_decode_layer_params", "vita_cp_attn_params", "vita_cp_context"}
     assert declared == set(lib.PROTOTYPES), declared ^ set(lib.PROTOTYPES)
     handle = lib.load()                                  # resolves + type-annotates every symbol
     assert handle.vita_abi_version() == lib.ABI_VERSION
@@ -40,7 +40,7 @@ def test_product_path_has_no_cpu_fallback_and_does_not_import_oracle():
             assert not re.search(r"^\s*(from|import)\s+oracle", src, re.M), fn
 
 
-@pytest.mark.parametrize("struct", ["vita_attn_params", "vita_attn_bwd_params", "vita_decode_layer_params"])
+@pytest.mark.parametrize("struct", ["vita_attn_params", "vita_attn_bwd_params", "vita_decode_layer_params", "vita_cp_attn_params"])
 def test_attn_params_struct_matches_header_field_order(struct):
     from long_vita_amd import lib
     hdr = open(lib.HEADER_PATH).read()
@@ -56,7 +56,7 @@ def test_attn_params_struct_matches_header_field_order(struct):
         names.append(re.findall(r"[A-Za-z_][A-Za-z0-9_]*", first)[-1])
         names += [re.findall(r"[A-Za-z_][A-Za-z0-9_]*", r)[-1] for r in rest]
     cls = {"vita_attn_params": lib.AttnParams, "vita_attn_bwd_params": lib.AttnBwdParams,
-           "vita_decode_layer_params": lib.DecodeLayerParams}[struct]
+           "vita_decode_layer_params": lib.DecodeLayerParams, "vita_cp_attn_params": lib.CpAttnParams}[struct]
     assert names == [f[0] for f in cls._fields_]
 
 

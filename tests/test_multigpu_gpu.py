@@ -67,21 +67,31 @@ print("OK", rank)
 """
 
 
-@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (real RCCL ranks)")
-def test_two_real_rccl_ranks_match_cp1(tmp_path):
+def _launch(tmp_path, world, extra_env=None):
     script = tmp_path / "worker.py"
     script.write_text(_WORKER)
     with socket.socket() as s:
         s.bind(("127.0.0.1", 0))
         port = s.getsockname()[1]
     procs = []
-    for r in range(2):
-        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE="2", MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
-                   VITA_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0")
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   VITA_ROOT=ROOT, HSA_ENABLE_IPC_MODE_LEGACY="0", **(extra_env or {}))
         procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
     for p in procs:
         out, _ = p.communicate(timeout=540)
         assert p.returncode == 0 and "OK" in out, out
+
+
+@pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (real RCCL ranks)")
+def test_two_real_rccl_ranks_match_cp1(tmp_path):
+    _launch(tmp_path, 2)
+
+
+def test_the_same_worker_on_one_real_rccl_rank(tmp_path):
+    """The worker script itself on a world of ONE real RCCL rank (prefill forced through the context-parallel code path:
+    K/V pack, RCCL all-gather, chunk tables, logits gather) — what a 1-GPU box can run of it."""
+    _launch(tmp_path, 1, {"VITA_FORCE_CP": "1"})
 
 
 def test_bench_dry_run_goes_through_the_distributed_plumbing():

@@ -422,3 +422,63 @@ def test_logit_scale_and_softcap(ops, scale, cap):
     gr = torch.ones(5, 152064).bfloat16().to(DEV)
     ops.logit_postprocess_bwd_(out.to(DEV), gr, scale, cap)
     assert rel_l2(gr, xf.grad) < 1e-2
+
+
+# ---------------------------------------------------------------------------------------------
+def test_cp_attention_through_the_c_abi_on_one_real_rccl_rank(ops):
+    """vita_cp_unique_id / vita_cp_init / vita_cp_attn_fwd / vita_cp_attn_bwd / vita_cp_destroy (include/vita_hip.h) driven
+    with raw pointers the way a non-Python host would: an RCCL communicator of ONE rank (what a 1-GPU box can hold), the K/V
+    all-gathers per kv-head split on the library's communication stream, chunk-table attention, dK/dV reduce-scatter —
+    equal to the single-device kernels on the same data (forward bit for bit: same kernel, same geometry)."""
+    import ctypes as C
+    from long_vita_amd import lib as L
+    h = L.load()
+    S, ng, qpg, d, n_split = 1024, 4, 2, 128, 2
+    hq = ng * qpg
+    mixed = torch.randn(1, S, ng, qpg + 2, d, generator=g(81)).bfloat16().to(DEV)
+    q5, k, v = mixed[:, :, :, :qpg], mixed[:, :, :, qpg], mixed[:, :, :, qpg + 1]
+    hg = ng // n_split
+    kv_packed = torch.stack([torch.stack([k[0, :, j * hg:(j + 1) * hg], v[0, :, j * hg:(j + 1) * hg]]) for j in range(n_split)]).contiguous()
+    uid = C.create_string_buffer(128)
+    L.check(h.vita_cp_unique_id(uid), "vita_cp_unique_id")
+    ctx = C.c_void_p()
+    L.check(h.vita_cp_init(C.byref(ctx), 1, 0, uid), "vita_cp_init")
+    try:
+        nbytes = h.vita_cp_attn_workspace_bytes(1, S, ng, d)
+        assert nbytes == 2 * S * ng * d * 2
+        ws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+        dws = torch.empty(nbytes, dtype=torch.uint8, device=DEV)
+        out = torch.empty(S, hq, d, dtype=torch.bfloat16, device=DEV)
+        lse = torch.empty(hq, S, dtype=torch.float32, device=DEV)
+        p = L.CpAttnParams()
+        p.q, p.q_row_stride, p.q_head_stride, p.q_group_stride = q5.data_ptr(), q5.stride(1), q5.stride(3), q5.stride(2)
+        p.kv_packed = kv_packed.data_ptr()
+        p.out, p.out_row_stride, p.out_head_stride, p.lse = out.data_ptr(), out.stride(0), out.stride(1), lse.data_ptr()
+        p.s_local, p.n_q_heads, p.n_kv_heads, p.head_dim, p.n_split = S, hq, ng, d, n_split
+        p.softmax_scale = 1.0 / math.sqrt(d)
+        p.workspace, p.workspace_bytes, p.dkv_workspace = ws.data_ptr(), nbytes, dws.data_ptr()
+        st = torch.cuda.current_stream().cuda_stream
+        L.check(h.vita_cp_attn_fwd(ctx, C.byref(p), st), "vita_cp_attn_fwd")
+        torch.cuda.synchronize()
+        ref, ref_lse = ops.flash_attn(q5, k, v, causal=True, return_lse=True)
+        assert torch.equal(out, ref[0]) and torch.equal(lse, ref_lse[0])
+        # backward
+        d_o = torch.randn(1, S, hq, d, generator=g(82)).bfloat16().to(DEV)
+        dq_r, dk_r, dv_r = ops.flash_attn_bwd(q5, k.contiguous().view(1, S, ng, d), v.contiguous().view(1, S, ng, d), ref, d_o, ref_lse)
+        delta = torch.empty(hq, S, dtype=torch.float32, device=DEV)
+        L.check(h.vita_attn_delta(out.data_ptr(), d_o.data_ptr(), delta.data_ptr(), S, hq, d, out.stride(0), out.stride(1), d_o.stride(1),
+                                  d_o.stride(2), st), "vita_attn_delta")
+        dmixed = torch.zeros_like(mixed)
+        dq5 = dmixed[:, :, :, :qpg]
+        dkv = torch.empty_like(kv_packed)
+        L.check(h.vita_cp_attn_bwd(ctx, C.byref(p), d_o.data_ptr(), lse.data_ptr(), delta.data_ptr(), dq5.data_ptr(), dkv.data_ptr(), st),
+                "vita_cp_attn_bwd")
+        torch.cuda.synchronize()
+        assert rel_l2(dq5, dq_r) < 1e-3
+        dk_c = torch.cat([dkv[j, 0] for j in range(n_split)], 1)
+        dv_c = torch.cat([dkv[j, 1] for j in range(n_split)], 1)
+        assert rel_l2(dk_c, dk_r[0]) < 1e-3 and rel_l2(dv_c, dv_r[0]) < 1e-3
+        bad = L.CpAttnParams()
+        assert h.vita_cp_attn_fwd(ctx, C.byref(bad), st) == L.VITA_ERR_INVALID_ARG
+    finally:
+        L.check(h.vita_cp_destroy(ctx), "vita_cp_destroy")
