@@ -446,23 +446,21 @@ __global__ __launch_bounds__(512, 2) void flash_fwd_kernel(AttnArgs p) {
 template <int D, bool CAUSAL, int VARIANT, bool TIMING = false>
 int launch_attn_v(const AttnArgs& a, int64_t nblocks, hipStream_t st) {
   constexpr int lds = 2 * 2 * KVT * D * 2;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<unsigned long long> attr_set{0};
+  vita_device_once(attr_set, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd_kernel<D, CAUSAL, VARIANT, TIMING>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
+  });
   hipLaunchKernelGGL((flash_fwd_kernel<D, CAUSAL, VARIANT, TIMING>), dim3((unsigned)nblocks), dim3(512), lds, st, a);
   return vita_check_launch();
 }
 
 // VITA_ATTN_VARIANT (developer tuning aid): bits 0-3 = kernel VARIANT (default 6 = LDS-DMA + QK_AHEAD 3), bit 4 = phase timers.
 inline int attn_variant() {
-  static int v = -1;
-  if (v < 0) {
+  static const int v = [] {
     const char* e = getenv("VITA_ATTN_VARIANT");
-    v = e ? atoi(e) : 0;
-  }
+    return e ? atoi(e) : 6;
+  }();
   return v;
 }
 

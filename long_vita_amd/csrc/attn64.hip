@@ -430,11 +430,10 @@ bool vita_attn64_eligible(const AttnArgs& a, int head_dim, bool causal) {
 }
 
 int vita_attn64_launch(const AttnArgs& a, int64_t nblocks, hipStream_t st) {
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<unsigned long long> attr_set{0};
+  vita_device_once(attr_set, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
-    attr_set = true;
-  }
+  });
   hipLaunchKernelGGL(flash_fwd64_kernel, dim3((unsigned)nblocks), dim3(256), LDS_BYTES, st, a);
   return vita_check_launch();
 }

@@ -454,15 +454,14 @@ extern "C" int vita_flash_attn_bwd(const vita_attn_bwd_params* p, void* stream) 
   for (int i = 0; i < p->n_kv_chunks; ++i) { a.kv_gid[i] = p->kv_chunk_gid[i]; a.kv_row[i] = p->kv_chunk_row[i]; }
 
   hipStream_t st = (hipStream_t)stream;
-  static bool attr_set = false;
+  static std::atomic<unsigned long long> attr_set{0};
   constexpr int lds_dq = 2 * DQ_STAGE, lds_kv = KV_FIXED + 2 * KV_STAGE;
-  if (!attr_set) {
+  vita_device_once(attr_set, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_dq);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
-    attr_set = true;
-  }
+  });
   const int64_t n_dq = (int64_t)p->n_q_heads * p->n_q_chunks * (p->chunk_len / QT_DQ);
   const int64_t n_kv = (int64_t)p->n_kv_heads * p->n_kv_chunks * (p->chunk_len / KT_KV);
   if (n_dq > 0x7fffffff || n_kv > 0x7fffffff) return VITA_ERR_UNSUPPORTED;

@@ -464,11 +464,10 @@ int launch_gemm4(GemmArgs a, hipStream_t st) {
   const int64_t tn = (a.N + bn_out - 1) / bn_out;
   if (tm * tn > 0x7fffffff) return VITA_ERR_UNSUPPORTED;
   a.tiles_m = (int)tm; a.tiles_n = (int)tn;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<unsigned long long> attr_set{0};
+  vita_device_once(attr_set, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm4_kernel<EPI, MODE>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
+  });
   hipLaunchKernelGGL((gemm4_kernel<EPI, MODE>), dim3((unsigned)(tm * tn)), dim3(256), lds, st, a);
   return vita_check_launch();
 }
@@ -523,12 +522,11 @@ int launch_gemm_cfg(GemmArgs a, hipStream_t st) {
   const int64_t tn = (a.N + bn_out - 1) / bn_out;
   if (tm * tn > 0x7fffffff) return VITA_ERR_UNSUPPORTED;
   a.tiles_m = (int)tm; a.tiles_n = (int)tn;
-  static bool attr_set = false;
-  if (!attr_set) {
+  static std::atomic<unsigned long long> attr_set{0};
+  vita_device_once(attr_set, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_bf16_kernel<EPI, BM, BN, WM, WN, PIN>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds);
-    attr_set = true;
-  }
+  });
   hipLaunchKernelGGL((gemm_bf16_kernel<EPI, BM, BN, WM, WN, PIN>), dim3((unsigned)(tm * tn)), dim3(64 * WM * WN), lds, st, a);
   return vita_check_launch();
 }

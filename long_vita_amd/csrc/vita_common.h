@@ -4,6 +4,20 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include "../../include/vita_hip.h"
+#include <atomic>
+
+// Function attributes (dynamic LDS size) are per device: run `f` once per device ordinal, not once per process.
+// Two threads racing on the same device may both run it (idempotent); nobody launches before it has run.
+template <class F>
+inline void vita_device_once(std::atomic<unsigned long long>& done, F&& f) {
+  int d = 0;
+  (void)hipGetDevice(&d);
+  const unsigned long long bit = 1ull << (d & 63);
+  if (!(done.load(std::memory_order_acquire) & bit)) {
+    f();
+    done.fetch_or(bit, std::memory_order_release);
+  }
+}
 
 typedef unsigned short bf16_t;  // raw bf16 bit pattern in memory
 
