@@ -39,6 +39,7 @@ struct GemmArgs {
   const bf16_t* bias; const bf16_t* scale;
   const bf16_t* R; int64_t ldr;
   int tiles_m, tiles_n;
+  int stagger;            // K-loop start offset policy (see gemm_bf16_kernel)
 };
 
 __device__ __forceinline__ float gelu_tanh(float x) {       // F.gelu(x, approximate="tanh")
@@ -255,13 +256,33 @@ __global__ __launch_bounds__(64 * WM * WN, (BM == 256 && WM * WN == 4) ? 1 : 2) 
   const int nk = (int)(p.K / BK);
   // measurement aid (EPI 0 only, VITA_GEMM_EXP=10): ldr = -1 makes every K tile re-read tile 0, so all loads hit L1/L2
   const int kstep = (EPI == VITA_EPI_NONE && p.ldr == -1) ? 0 : BK;
-  stage(lds0, kstep);
+  // Staggered K start: workgroups that run at the same time walk K from different offsets (wrapping around), so that
+  // they do not all ask the memory system for the same K columns — the same few channels — at the same moment.
+  //   1 = by XCD (the workgroups of one XCD stay in phase and keep sharing their operands through that XCD's L2)
+  //   2 = by M tile, 3 = by tile id (two K tiles apart, modulo 32)
+  int kt = 0;
+  if (p.stagger == 1) kt = (int)(((int64_t)(blockIdx.x & 7) * nk) >> 3);
+  else if (p.stagger == 2) kt = ((tm & 31) * 2) % nk;
+  else if (p.stagger == 3) kt = ((pid & 31) * 2) % nk;
+  kt = __builtin_amdgcn_readfirstlane(kt);
+  if (kt && kstep) {
+#pragma unroll
+    for (int q = 0; q < QA; ++q) a_src[q] += (int64_t)kt * BK;
+#pragma unroll
+    for (int q = 0; q < QW; ++q) w_src[q] += (int64_t)kt * BK;
+  }
+  auto next_adv = [&]() __attribute__((always_inline)) {     // pointer step after staging tile kt; wraps at the end of K
+    int adv = kstep;
+    if (++kt == nk) { kt = 0; adv = kstep ? kstep - (int)p.K : 0; }
+    return adv;
+  };
+  stage(lds0, next_adv());
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   for (int t = 0; t < nk; ++t) {
     const unsigned cur = lds0 + (t & 1) * STAGE;
-    if (t + 1 < nk) stage(lds0 + ((t + 1) & 1) * STAGE, kstep);
+    if (t + 1 < nk) stage(lds0 + ((t + 1) & 1) * STAGE, next_adv());
     bf16x8 af[4][MI], wf[4][NI];
 #pragma unroll
     for (int kk = 0; kk < 4; ++kk) {
@@ -579,6 +600,10 @@ extern "C" int vita_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
   a.C = (bf16_t*)C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
   a.bias = (const bf16_t*)bias; a.scale = (const bf16_t*)scale; a.R = (const bf16_t*)R; a.ldr = ldr;
   a.tiles_m = a.tiles_n = 0;
+  {
+    const char* e = getenv("VITA_GEMM_STAGGER");          // developer tuning aid, read per launch
+    a.stagger = e ? atoi(e) : 0;
+  }
   hipStream_t st = (hipStream_t)stream;
   switch (epilogue) {
     case VITA_EPI_NONE: return launch_gemm<VITA_EPI_NONE>(a, st);

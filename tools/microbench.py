@@ -134,8 +134,35 @@ def bench_gemm_variants():
         del a, w, out
 
 
+def bench_gemm_env(name, values):
+    """Sweep one developer env switch of the GEMM (VITA_GEMM_STAGGER, ...) over the four decoder GEMMs with their epilogues."""
+    for (M, N, K, epi, tag) in [(131072, 7168, 5120, 1, "S128K/qkv"), (131072, 5120, 5120, 3, "S128K/o"),
+                                (131072, 13824, 5120, 5, "S128K/fc1_swiglu"), (131072, 5120, 13824, 3, "S128K/fc2"),
+                                (16384, 7168, 5120, 1, "S16K/qkv"), (16384, 5120, 13824, 3, "S16K/fc2")]:
+        a = (torch.randn(M, K, device=DEV) * 0.5).bfloat16()
+        w = (torch.randn((2 * N if epi == 5 else N), K, device=DEV) * 0.02).bfloat16()
+        out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
+        res = torch.randn(M, N, device=DEV).bfloat16() if epi == 3 else None
+        bias = torch.randn(N, device=DEV).bfloat16() if epi == 1 else None
+        base = None
+        for v in values:
+            os.environ[name] = v
+            out.zero_()
+            med, best = timeit(lambda: ops.gemm(a, w, epi, bias, None, res, out=out))
+            if base is None:
+                base = out[:2048].float().clone()
+            err = float((out[:2048].float() - base).abs().max())
+            fl = 2.0 * M * (2 * N if epi == 5 else N) * K
+            emit(kind="gemm_env", env=name, value=v, tag=tag, ms=med, ms_best=best, tflops=fl / med / 1e9, max_abs_diff_vs_first=err)
+        os.environ.pop(name)
+        del a, w, out
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "attn", "hbm"]
+    if which and which[0] == "env":
+        bench_gemm_env(which[1], which[2].split(","))
+        sys.exit(0)
     if "variants" in which:
         bench_gemm_variants()
     if "peaks" in which:
