@@ -55,7 +55,106 @@ __device__ __forceinline__ int tile_off(int row, int slot) {
   return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
 }
 
-// ---- epilogue shared by the tile kernels: lane holds D^T: row m = ... + (lane & 31), columns 8*rg + 4*(lane>>5) + 0..3 --
+// ---- epilogue arithmetic on four consecutive output columns n..n+3 of row m (shared by all tile kernels) ------------------
+// o = the raw fp32 accumulators; the bf16 rounding chains are the reference's unfused ones (include/vita_hip.h)
+// pure arithmetic of the non-SwiGLU epilogues: o = raw accumulators -> values to round and store; b / sc / r = bias, LayerScale and
+// residual of the same four columns as floats (ignored where the epilogue has none)
+template <int EPI>
+__device__ __forceinline__ void epilogue_math(float (&o)[4], bool has_bias, const float (&b)[4], const float (&sc)[4],
+                                              const float (&r)[4]) {
+  if (EPI == VITA_EPI_BIAS2_GELU_TANH || EPI == VITA_EPI_BIAS2_RES) {      // bias added to the ROUNDED product
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = bf16_round(o[j]);
+  }
+  if (EPI != VITA_EPI_NONE && has_bias) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] += b[j];
+  }
+  if (EPI == VITA_EPI_BIAS_GELU) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = gelu_erf(bf16_round(o[j]));
+  }
+  if (EPI == VITA_EPI_BIAS2_GELU_TANH) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = gelu_tanh(bf16_round(o[j]));
+  }
+  if (EPI == VITA_EPI_BIAS_SCALE_RES) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = bf16_round(bf16_round(o[j]) * sc[j]);
+  }
+  if (EPI == VITA_EPI_RESIDUAL || EPI == VITA_EPI_BIAS2_RES) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] = bf16_round(o[j]);
+  }
+  if (EPI == VITA_EPI_RESIDUAL || EPI == VITA_EPI_BIAS_SCALE_RES || EPI == VITA_EPI_BIAS2_RES) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) o[j] += r[j];
+  }
+}
+template <int EPI> constexpr bool epi_has_residual() { return EPI == VITA_EPI_RESIDUAL || EPI == VITA_EPI_BIAS_SCALE_RES || EPI == VITA_EPI_BIAS2_RES; }
+__device__ __forceinline__ void unpack_quad(const u32x2 v, float (&f)[4]) {
+  f[0] = bf16lo_to_f32(v[0]); f[1] = bf16hi_to_f32(v[0]); f[2] = bf16lo_to_f32(v[1]); f[3] = bf16hi_to_f32(v[1]);
+}
+
+// ---- epilogue on four consecutive output columns n..n+3 of row m, with the tail handling of ragged N (shared by all tile kernels)
+template <int EPI>
+__device__ __forceinline__ void epilogue_quad(const GemmArgs& p, float (&o)[4], int64_t m, int64_t n) {
+  const bool full = n + 3 < p.N;
+  float b[4] = {0.f, 0.f, 0.f, 0.f}, sc[4] = {0.f, 0.f, 0.f, 0.f}, r[4] = {0.f, 0.f, 0.f, 0.f};
+  const bool has_bias = EPI != VITA_EPI_NONE && p.bias;
+  if (has_bias) {
+    if (full) {
+      unpack_quad(*reinterpret_cast<const u32x2*>(p.bias + n), b);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (n + j < p.N) b[j] = bf16_to_f32(p.bias[n + j]);     // static indices: no scratch
+    }
+  }
+  if (EPI == VITA_EPI_BIAS_SCALE_RES) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) sc[j] = bf16_to_f32(p.scale[(n + j < p.N) ? n + j : p.N - 1]);
+  }
+  if (epi_has_residual<EPI>()) {
+    const bf16_t* rsrc = p.R + m * p.ldr + n;
+    if (full) {
+      unpack_quad(*reinterpret_cast<const u32x2*>(rsrc), r);
+    } else {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) if (n + j < p.N) r[j] = bf16_to_f32(rsrc[j]);
+    }
+  }
+  epilogue_math<EPI>(o, has_bias, b, sc, r);
+  bf16_t* dst = p.C + m * p.ldc + n;
+  if (full) {
+    u32x2 v = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+    *reinterpret_cast<u32x2*>(dst) = v;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (n + j < p.N) dst[j] = f32_to_bf16(o[j]);
+  }
+}
+
+// SwiGLU: g / u = the raw accumulators of the gate and up rows of output columns n..n+3
+__device__ __forceinline__ void swiglu_quad(const GemmArgs& p, const float (&gt)[4], const float (&up)[4], int64_t m, int64_t n) {
+  float o[4];
+#pragma unroll
+  for (int j = 0; j < 4; ++j) {
+    const float g = bf16_round(gt[j]);
+    const float u = bf16_round(up[j]);
+    const float s = bf16_round(g / (1.0f + __expf(-g)));
+    o[j] = s * u;
+  }
+  bf16_t* dst = p.C + m * p.ldc + n;
+  if (n + 3 < p.N) {
+    u32x2 v = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+    *reinterpret_cast<u32x2*>(dst) = v;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) if (n + j < p.N) dst[j] = f32_to_bf16(o[j]);
+  }
+}
+
+// ---- epilogue of the 32x32-block kernels: lane holds D^T: row m = ... + (lane & 31), columns 8*rg + 4*(lane>>5) + 0..3 --
 template <int EPI, int MI, int NI, int TM, int TN>
 __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[NI][MI], int64_t m0, int64_t n0, int wm,
                                               int wn, int lane) {
@@ -72,21 +171,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[N
         for (int rg = 0; rg < 4; ++rg) {
           const int64_t n = n0 + (wn * (NI / 2) + pi) * 32 + rg * 8 + hi * 4;
           if (n >= p.N) continue;
-          float o[4];
+          float g[4], u[4];
 #pragma unroll
-          for (int j = 0; j < 4; ++j) {
-            const float g = bf16_round(acc[2 * pi][mi][rg * 4 + j]);
-            const float u = bf16_round(acc[2 * pi + 1][mi][rg * 4 + j]);
-            const float s = bf16_round(g / (1.0f + __expf(-g)));
-            o[j] = s * u;
-          }
-          bf16_t* dst = p.C + m * p.ldc + n;
-          if (n + 3 < p.N) {
-            u32x2 v = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-            *reinterpret_cast<u32x2*>(dst) = v;
-          } else {
-            for (int j = 0; j < 4 && n + j < p.N; ++j) dst[j] = f32_to_bf16(o[j]);
-          }
+          for (int j = 0; j < 4; ++j) { g[j] = acc[2 * pi][mi][rg * 4 + j]; u[j] = acc[2 * pi + 1][mi][rg * 4 + j]; }
+          swiglu_quad(p, g, u, m, n);
         }
       }
     } else {
@@ -96,59 +184,10 @@ __device__ __forceinline__ void gemm_epilogue(const GemmArgs& p, f32x16 (&acc)[N
         for (int rg = 0; rg < 4; ++rg) {
           const int64_t n = n0 + wn * TN + ni * 32 + rg * 8 + hi * 4;
           if (n >= p.N) continue;
-          const bool full = n + 3 < p.N;
           float o[4];
 #pragma unroll
           for (int j = 0; j < 4; ++j) o[j] = acc[ni][mi][rg * 4 + j];
-          if (EPI == VITA_EPI_BIAS2_GELU_TANH || EPI == VITA_EPI_BIAS2_RES) {      // bias added to the ROUNDED product
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = bf16_round(o[j]);
-          }
-          if (EPI != VITA_EPI_NONE && p.bias) {
-            if (full) {
-              const u32x2 b = *reinterpret_cast<const u32x2*>(p.bias + n);
-              o[0] += bf16lo_to_f32(b[0]); o[1] += bf16hi_to_f32(b[0]);
-              o[2] += bf16lo_to_f32(b[1]); o[3] += bf16hi_to_f32(b[1]);
-            } else {
-              for (int j = 0; j < 4 && n + j < p.N; ++j) o[j] += bf16_to_f32(p.bias[n + j]);
-            }
-          }
-          if (EPI == VITA_EPI_BIAS_GELU) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = gelu_erf(bf16_round(o[j]));
-          }
-          if (EPI == VITA_EPI_BIAS2_GELU_TANH) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) o[j] = gelu_tanh(bf16_round(o[j]));
-          }
-          if (EPI == VITA_EPI_BIAS_SCALE_RES) {
-#pragma unroll
-            for (int j = 0; j < 4; ++j) {
-              const int64_t nn = (n + j < p.N) ? n + j : p.N - 1;
-              o[j] = bf16_round(bf16_round(o[j]) * bf16_to_f32(p.scale[nn]));
-            }
-          }
-          if (EPI == VITA_EPI_RESIDUAL || EPI == VITA_EPI_BIAS_SCALE_RES || EPI == VITA_EPI_BIAS2_RES) {
-            const bf16_t* rsrc = p.R + m * p.ldr + n;
-            if (EPI == VITA_EPI_RESIDUAL || EPI == VITA_EPI_BIAS2_RES) {
-#pragma unroll
-              for (int j = 0; j < 4; ++j) o[j] = bf16_round(o[j]);
-            }
-            if (full) {
-              const u32x2 rv = *reinterpret_cast<const u32x2*>(rsrc);
-              o[0] += bf16lo_to_f32(rv[0]); o[1] += bf16hi_to_f32(rv[0]);
-              o[2] += bf16lo_to_f32(rv[1]); o[3] += bf16hi_to_f32(rv[1]);
-            } else {
-              for (int j = 0; j < 4 && n + j < p.N; ++j) o[j] += bf16_to_f32(rsrc[j]);
-            }
-          }
-          bf16_t* dst = p.C + m * p.ldc + n;
-          if (full) {
-            u32x2 v = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
-            *reinterpret_cast<u32x2*>(dst) = v;
-          } else {
-            for (int j = 0; j < 4 && n + j < p.N; ++j) dst[j] = f32_to_bf16(o[j]);
-          }
+          epilogue_quad<EPI>(p, o, m, n);
         }
       }
     }
@@ -493,6 +532,292 @@ int launch_gemm4(GemmArgs a, hipStream_t st) {
   return vita_check_launch();
 }
 
+// ---- 4 waves x (128 x 128), v_mfma_f32_16x16x32_bf16, accumulators pinned in AGPRs: the large-problem kernel (round 2) ------------
+// Same macro tile as <256,256,2,4>, one wave per SIMD.  What makes it ~20 % faster than the 8-wave kernel (tools/hwprobe/gemmd.hip is
+// the stand-alone version with its schedule sweep):
+//   * the 64 accumulator blocks (256 registers) stay in AGPRs for the whole K loop — the MFMAs are inline asm ("+a") — and the 32
+//     operand fragments of a K tile sit in VGPRs: nothing ever moves between the two halves of the register file;
+//   * LDS layout "interleaved rows, padded lines": line (h, r16) = the eight tile rows 128 h + 16 rb + r16 (rb = 0..7), 128 B each,
+//     + 16 B of padding.  One LDS-DMA instruction (buffer_load_dwordx4 ... lds, lane -> rb = lane / 8, 16-B chunk lane % 8) fills
+//     exactly one line from whole 128-B row segments, and the 16x16x32 fragment read (lane -> row lane % 16, k chunk lane / 16)
+//     strides 1040 B = 260 dwords between lanes: conflict-free, with row block and k half as address constants;
+//   * two stages with prefetch distance two: the DMA of tile t+2 goes into the stage tile t is being read from as soon as every wave
+//     holds its second-half fragments (barrier in the first half of the iteration), so a piece has about 1.5 iterations to land;
+//   * the loop is one fixed instruction order (asm volatile statements + sched_barrier): MFMA slots 0..127, a fragment read behind
+//     every second MFMA of slots 0..30, lgkmcnt(0) + s_barrier at 36, one DMA piece every fourth slot 40..100 (a burst costs 6 %),
+//     vmcnt + s_barrier at 103, the next tile's 16 first-half reads behind slots 104..119.
+// Ragged M / N: source rows are clamped (their products land in rows / columns the epilogue does not store).
+namespace w4 {
+constexpr int LINE = 1040, HALF = 16 * LINE, OPB = 2 * HALF, STAGE = 2 * OPB, LDS_BYTES = 2 * STAGE;   // 133120 B
+}
+
+// INTERIOR = every tile of the problem is whole (M % 256 == 0, N % tile width == 0): chosen at launch, so that each instantiation has
+// ONE straight-line epilogue (two epilogue paths behind a run-time branch made hipcc shuffle the pinned accumulators between AGPRs
+// and produced wrong blocks).
+template <int EPI, bool INTERIOR>
+__global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
+  using namespace w4;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+
+  const int nwg = p.tiles_m * p.tiles_n;
+  int pid;
+  {
+    const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
+  }
+  constexpr int GROUP_M = 4;
+  const int per_group = GROUP_M * p.tiles_n;
+  const int group = pid / per_group;
+  const int first_m = group * GROUP_M;
+  const int gsz = min(p.tiles_m - first_m, GROUP_M);
+  const int in_group = pid - group * per_group;
+  const int tm = first_m + in_group % gsz;
+  const int tn = in_group / gsz;
+  const int64_t m0 = (int64_t)tm * 256;
+  const int64_t n0 = (int64_t)tn * (EPI == VITA_EPI_SWIGLU ? 128 : 256);
+  const int nk = (int)(p.K / BK);
+
+  // ---- DMA geometry: wave w fills lines (h = w >> 1, r16 = (w & 1) * 8 + i), i = 0..7, of both operands; per-lane byte offsets of
+  // the eight pieces relative to the tile's first row (clamped rows for ragged edges; SwiGLU: 16-row blocks alternate gate / up) ------
+  const int h = wave >> 1, r0 = (wave & 1) * 8;
+  const unsigned d_line0 = (unsigned)(h * HALF + r0 * LINE);
+  unsigned voff_a[8], voff_w[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int lr = 128 * h + 16 * (lane >> 3) + r0 + i;
+    int64_t g = m0 + lr;
+    g = g < p.M ? g : p.M - 1;
+    voff_a[i] = (unsigned)((g - m0) * p.lda * 2 + (lane & 7) * 16);
+    if (EPI == VITA_EPI_SWIGLU) {
+      const int blk = lr >> 4;
+      int64_t oc = n0 + (blk >> 1) * 16 + (lr & 15);
+      oc = oc < p.N ? oc : p.N - 1;
+      g = ((blk & 1) ? p.N : 0) + oc;
+    } else {
+      g = n0 + lr;
+      g = g < p.N ? g : p.N - 1;
+    }
+    voff_w[i] = (unsigned)((g - n0) * p.ldw * 2 + (lane & 7) * 16);
+  }
+  // the descriptor base must stay in SGPRs (a VGPR descriptor costs a waterfall loop per DMA): uniform halves, a scalar K offset
+  auto uniform_ptr = [](const void* q) __attribute__((always_inline)) {
+    const uint64_t v = (uint64_t)(uintptr_t)q;
+    const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
+    return (const char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
+  };
+  const char* const ap = uniform_ptr(p.A + m0 * p.lda);
+  const char* const wp = uniform_ptr(p.W + n0 * p.ldw);
+  int koff = 0;                                                                             // byte offset of the K tile fetched next
+  auto dma_piece = [&](unsigned stage, int j) __attribute__((always_inline)) {              // j = 0..7: A lines, 8..15: W lines
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)((j < 8 ? ap : wp) + koff), 0, 0x7fffffff, 0x00020000);
+    const int i = j & 7;
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(uintptr_t)(stage + (j < 8 ? 0 : OPB) + d_line0 + i * LINE), 16,
+                                             j < 8 ? voff_a[i] : voff_w[i], 0, 0, 0);
+  };
+  auto next_tile = [&]() __attribute__((always_inline)) { koff += BK * 2; };
+
+  // ---- fragment reads: lane -> (row lane % 16) * LINE + (k chunk lane / 16) * 16, + row block * 128 + k half * 64 ------------------
+  const unsigned rd_a = (unsigned)(wm * HALF + (lane & 15) * LINE + (lane >> 4) * 16);
+  const unsigned rd_w = (unsigned)(OPB + wn * HALF + (lane & 15) * LINE + (lane >> 4) * 16);
+  bf16x8 af[2][8], wf[2][8];
+  // read q (0..15) of k half ks: W block 0 first, then the eight A blocks, then W blocks 1..7 (the order the MFMAs need them)
+  auto frag_read = [&](unsigned stage, int ks, int q) __attribute__((always_inline)) {
+    if (q == 0 || q > 8) {
+      const int nb = q == 0 ? 0 : q - 8;
+      const unsigned ad = stage + rd_w + nb * 128 + ks * 64;
+      asm volatile("ds_read_b128 %0, %1" : "=v"(wf[ks][nb]) : "v"(ad));
+    } else {
+      const int mb = q - 1;
+      const unsigned ad = stage + rd_a + mb * 128 + ks * 64;
+      asm volatile("ds_read_b128 %0, %1" : "=v"(af[ks][mb]) : "v"(ad));
+    }
+  };
+
+  f32x4 acc[8][8];                                                       // [n block][m block], AGPRs
+#pragma unroll
+  for (int i = 0; i < 8; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // ---- prologue: tiles 0 and 1 in flight, first-half fragments of tile 0 ---------------------------------------------------------
+#pragma unroll
+  for (int j = 0; j < 16; ++j) dma_piece(lds0, j);
+  next_tile();
+  if (nk > 1) {
+#pragma unroll
+    for (int j = 0; j < 16; ++j) dma_piece(lds0 + STAGE, j);
+    next_tile();
+    asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+  } else {
+    asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+  }
+#pragma unroll
+  for (int q = 0; q < 16; ++q) frag_read(lds0, 0, q);
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+
+  // one K tile: DMA = tile t+2 exists (goes into `cur`), NEXT = tile t+1 exists (its first-half fragments come from `nxt`)
+  auto tile = [&](const bool DMA, const bool NEXT, unsigned cur, unsigned nxt) __attribute__((always_inline)) {
+#pragma unroll
+    for (int s = 0; s < 128; ++s) {
+      const int ks = s >> 6, nb = (s >> 3) & 7, mb = s & 7;
+      asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[nb][mb]) : "v"(wf[ks][nb]), "v"(af[ks][mb]));
+      if (s <= 30 && (s & 1) == 0) frag_read(cur, 1, s >> 1);
+      if (s == 36) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (DMA && s >= 40 && s <= 100 && (s & 3) == 0) dma_piece(cur, (s - 40) >> 2);
+      if (NEXT && s == 103) {
+        if (DMA) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      }
+      if (NEXT && s >= 104 && s < 120) frag_read(nxt, 0, s - 104);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    if (DMA) next_tile();
+    if (NEXT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  };
+
+  int t = 0;
+  for (; t + 2 < nk; ++t) tile(true, true, lds0 + (t & 1) * STAGE, lds0 + ((t + 1) & 1) * STAGE);
+  if (t + 1 < nk) {
+    tile(false, true, lds0 + (t & 1) * STAGE, lds0 + ((t + 1) & 1) * STAGE);
+    ++t;
+  }
+  tile(false, false, lds0 + (t & 1) * STAGE, 0u);
+
+  // ---- epilogue.  The inline-asm MFMAs are invisible to the compiler's hazard tracking: one wait for the matrix pipe, then every row
+  // block's accumulators pass through an (empty) asm statement of their own right before they are read — asm volatile statements
+  // keep their order, so no accumulator read can be placed above the wait, and the AGPR -> VGPR copies stay next to their use ---------
+  asm volatile("s_nop 15\n\ts_nop 15" ::: "memory");
+  auto pin_row_block = [&](int mb) __attribute__((always_inline)) {
+    asm volatile("" : "+a"(acc[0][mb]), "+a"(acc[1][mb]), "+a"(acc[2][mb]), "+a"(acc[3][mb]), "+a"(acc[4][mb]), "+a"(acc[5][mb]),
+                 "+a"(acc[6][mb]), "+a"(acc[7][mb]));
+  };
+  // block (nb, mb): lane holds C[m][n .. n+3], m = .. + (lane & 15), n = .. + 4 * (lane >> 4)
+  const int64_t mrow = m0 + wm * 128 + (lane & 15);
+  const int64_t ncol = n0 + wn * (EPI == VITA_EPI_SWIGLU ? 64 : 128) + 4 * (lane >> 4);
+  if (INTERIOR) {
+    // whole tiles only (all decoder shapes): no masks.  With one workgroup per CU nothing else runs while a wave waits
+    // for memory, so the bias / LayerScale / residual operands of one row block are loaded ahead of the previous block's arithmetic
+    const bool has_bias = EPI != VITA_EPI_NONE && EPI != VITA_EPI_SWIGLU && p.bias;
+    float bq[8][4], sq[8][4];
+#pragma unroll
+    for (int nb = 0; nb < 8; ++nb)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) { bq[nb][j] = 0.f; sq[nb][j] = 0.f; }
+    if (has_bias) {
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) unpack_quad(*reinterpret_cast<const u32x2*>(p.bias + ncol + nb * 16), bq[nb]);
+    }
+    if (EPI == VITA_EPI_BIAS_SCALE_RES) {
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) unpack_quad(*reinterpret_cast<const u32x2*>(p.scale + ncol + nb * 16), sq[nb]);
+    }
+    u32x2 rq[2][8];
+    auto load_res = [&](int mb) __attribute__((always_inline)) {
+      if (epi_has_residual<EPI>()) {
+        const bf16_t* rrow = p.R + (mrow + mb * 16) * p.ldr + ncol;
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) rq[mb & 1][nb] = *reinterpret_cast<const u32x2*>(rrow + nb * 16);
+      }
+    };
+    load_res(0);
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+      if (mb + 1 < 8) load_res(mb + 1);
+      pin_row_block(mb);
+      bf16_t* crow = p.C + (mrow + mb * 16) * p.ldc + ncol;
+      if (EPI == VITA_EPI_SWIGLU) {
+#pragma unroll
+        for (int pi = 0; pi < 4; ++pi) {
+          float o[4];
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const float g = bf16_round(acc[2 * pi][mb][j]);
+            const float u = bf16_round(acc[2 * pi + 1][mb][j]);
+            o[j] = bf16_round(g / (1.0f + __expf(-g))) * u;
+          }
+          u32x2 v = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+          *reinterpret_cast<u32x2*>(crow + pi * 16) = v;
+        }
+      } else {
+#pragma unroll
+        for (int nb = 0; nb < 8; ++nb) {
+          float o[4], r[4] = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int j = 0; j < 4; ++j) o[j] = acc[nb][mb][j];
+          if (epi_has_residual<EPI>()) unpack_quad(rq[mb & 1][nb], r);
+          epilogue_math<EPI>(o, has_bias, bq[nb], sq[nb], r);
+          u32x2 v = {pack_bf16x2(o[0], o[1]), pack_bf16x2(o[2], o[3])};
+          *reinterpret_cast<u32x2*>(crow + nb * 16) = v;
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);      // one row block at a time: keeps the accumulator reads from being hoisted wholesale
+    }
+    return;
+  }
+#pragma unroll
+  for (int mb = 0; mb < 8; ++mb) {
+    pin_row_block(mb);
+    const int64_t m = mrow + mb * 16;
+    if (m >= p.M) continue;
+    if (EPI == VITA_EPI_SWIGLU) {
+      // the wave's W rows = 4 x [gate 16 | up 16]; pair pi -> output columns n0 + wn * 64 + pi * 16 + 0..15
+#pragma unroll
+      for (int pi = 0; pi < 4; ++pi) {
+        const int64_t n = ncol + pi * 16;
+        if (n >= p.N) continue;
+        float g[4], u[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { g[j] = acc[2 * pi][mb][j]; u[j] = acc[2 * pi + 1][mb][j]; }
+        swiglu_quad(p, g, u, m, n);
+      }
+    } else {
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) {
+        const int64_t n = ncol + nb * 16;
+        if (n >= p.N) continue;
+        float o[4];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) o[j] = acc[nb][mb][j];
+        epilogue_quad<EPI>(p, o, m, n);
+      }
+    }
+    __builtin_amdgcn_sched_barrier(0);
+  }
+}
+
+template <int EPI, bool INTERIOR>
+int launch_gemm_w4_cfg(const GemmArgs& a, hipStream_t st) {
+  static std::atomic<unsigned long long> attr_set{0};
+  vita_device_once(attr_set, [&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<EPI, INTERIOR>), hipFuncAttributeMaxDynamicSharedMemorySize,
+                              w4::LDS_BYTES);
+  });
+  hipLaunchKernelGGL((gemm_w4_kernel<EPI, INTERIOR>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), w4::LDS_BYTES, st, a);
+  return vita_check_launch();
+}
+
+template <int EPI>
+int launch_gemm_w4(GemmArgs a, hipStream_t st) {
+  const int64_t tm = (a.M + 255) / 256;
+  const int64_t bn_out = EPI == VITA_EPI_SWIGLU ? 128 : 256;
+  const int64_t tn = (a.N + bn_out - 1) / bn_out;
+  if (tm * tn > 0x7fffffff) return VITA_ERR_UNSUPPORTED;
+  a.tiles_m = (int)tm; a.tiles_n = (int)tn;
+  const bool interior = a.M % 256 == 0 && a.N % bn_out == 0 && (a.ldc & 3) == 0 &&
+                        (!a.R || (a.ldr & 3) == 0);             // 8-byte vector accesses of whole quads
+  return interior ? launch_gemm_w4_cfg<EPI, true>(a, st) : launch_gemm_w4_cfg<EPI, false>(a, st);
+}
+
+// the w4 kernel addresses a tile's rows with 32-bit byte offsets from the tile's first row
+inline bool gemm_w4_addressable(const GemmArgs& a, bool swiglu) {
+  const int64_t a_span = 256 * a.lda * 2, w_span = (swiglu ? a.N + 128 : 256) * a.ldw * 2;
+  return a_span < 0x7fff0000LL && w_span < 0x7fff0000LL;
+}
+
 // ---- skinny-M (M <= 16): one wave per output column, x rows cached in LDS ------------------
 // HBM-bound on W: algorithmic bytes = N*K*2.  Each lane streams 16-byte pieces of one W row.
 template <int MAXM>
@@ -571,8 +896,14 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
   if (gemm_tile_override() == 128) big = false;
   if (gemm_tile_override() == 256) big = true;
   static const bool nopin = getenv("VITA_GEMM_NOPIN") != nullptr;     // developer tuning aid
-  if (gemm_tile_override() == 2564) return launch_gemm_cfg<EPI, 256, 256, 2, 2>(a, st);   // 4 waves x (128 x 128)
-  if (EPI == VITA_EPI_NONE) {     // developer measurement aids, read per launch (tools/microbench.py variants; DESIGN.md §4.2)
+  if (gemm_tile_override() == 2564) return launch_gemm_cfg<EPI, 256, 256, 2, 2>(a, st);   // 4 waves x (128 x 128), compiler-scheduled
+  // VITA_GEMM_KERNEL (developer aid, read per launch): "w4" / "w8" force the large-problem kernel, "128" the small tile
+  const char* kn = getenv("VITA_GEMM_KERNEL");
+  const bool w4_ok = gemm_w4_addressable(a, EPI == VITA_EPI_SWIGLU);
+  if (kn && kn[0] == 'w' && kn[1] == '4' && w4_ok) return launch_gemm_w4<EPI>(a, st);
+  if (kn && kn[0] == 'w' && kn[1] == '8') return launch_gemm_cfg<EPI, 256, 256, 2, 4>(a, st);
+  if (kn && kn[0] == '1') return launch_gemm_cfg<EPI, 128, 128, 2, 2>(a, st);
+  if (EPI == VITA_EPI_NONE) {     // developer measurement aids, read per launch (tools/microbench.py variants; DESIGN.md 4.2)
     const char* e = getenv("VITA_GEMM_EXP");
     const int v = e ? atoi(e) : 0;
     if (v == 10) { GemmArgs b = a; b.ldr = -1; return launch_gemm_cfg<EPI, 256, 256, 2, 4>(b, st); }   // 8 waves, L2-hit loads
@@ -582,6 +913,7 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
     if (v == 43) return launch_gemm4<VITA_EPI_NONE, 3>(a, st);
   }
   if (nopin) return big ? launch_gemm_cfg<EPI, 256, 256, 2, 4, false>(a, st) : launch_gemm_cfg<EPI, 128, 128, 2, 2, false>(a, st);
+  if (big && w4_ok) return launch_gemm_w4<EPI>(a, st);
   return big ? launch_gemm_cfg<EPI, 256, 256, 2, 4>(a, st) : launch_gemm_cfg<EPI, 128, 128, 2, 2>(a, st);
 }
 

@@ -191,11 +191,17 @@ def _gemm_ref(a, w, epi, bias, scale, res, ops):
 @pytest.mark.parametrize("M,N,K", [(128, 128, 64), (256, 384, 1024), (1025, 1024, 1024), (300, 200, 640),
                                    (77, 5120, 1024), (2048, 7168, 5120)])
 @pytest.mark.parametrize("epi", [0, 1, 2, 3, 4, 5])
-def test_gemm_epilogues(ops, M, N, K, epi):
+@pytest.mark.parametrize("kernel", ["auto", "w4", "w8"])
+def test_gemm_epilogues(ops, M, N, K, epi, kernel, monkeypatch):
+    """kernel: "auto" = the library's own choice (small tile below 192 big tiles, the 4-wave AGPR kernel above), "w4" / "w8" force
+    the large-problem kernels (4 waves x 16x16x32 with pinned accumulators / 8 waves x 32x32x16) onto every shape, so that their
+    ragged-edge clamping, single-K-tile prologue and every epilogue are covered at small sizes too."""
     if epi == 5 and N % 2:
         pytest.skip("swiglu needs even rows")
-    if M * N * K > 2e10 and epi not in (0, 5):
+    if M * N * K > 2e10 and epi not in (0, 5) and kernel != "w4":
         pytest.skip("large shape only for plain / swiglu")
+    if kernel != "auto":
+        monkeypatch.setenv("VITA_GEMM_KERNEL", kernel)
     a = (torch.randn(M, K, generator=g(20)) * 0.5).bfloat16()
     wrows = 2 * N if epi == ops.EPI_SWIGLU else N
     w = (torch.randn(wrows, K, generator=g(21)) * (1.0 / math.sqrt(K))).bfloat16()

@@ -40,7 +40,7 @@ __device__ __forceinline__ unsigned pack2(float a, float b) {         // RNE fp3
   return (ua >> 16) | (ub & 0xffff0000u);
 }
 
-template <int STAG>
+template <int STAG, int RGAP = 2, int BAR1 = 36, int DMA0 = 40, int DGAP = 4, int NX0 = 104, int NGAP = 1, int GM = 4>
 __global__ __launch_bounds__(256, 1) void gemmd_kernel(const bf16_t* __restrict__ A, const bf16_t* __restrict__ W,
                                                        bf16_t* __restrict__ C, int M, int N, int K) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -55,7 +55,7 @@ __global__ __launch_bounds__(256, 1) void gemmd_kernel(const bf16_t* __restrict_
     const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
-  constexpr int GROUP_M = 4;
+  constexpr int GROUP_M = GM;
   const int per_group = GROUP_M * tiles_n, group = pid / per_group, first_m = group * GROUP_M;
   const int gsz = min(tiles_m - first_m, GROUP_M), in_group = pid - group * per_group;
   const int tm = first_m + in_group % gsz, tn = in_group / gsz;
@@ -126,14 +126,15 @@ __global__ __launch_bounds__(256, 1) void gemmd_kernel(const bf16_t* __restrict_
     for (int s = 0; s < 128; ++s) {
       const int ks = s >> 6, nb = (s >> 3) & 7, mb = s & 7;
       asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[nb][mb]) : "v"(wf[ks][nb]), "v"(af[ks][mb]));
-      if (s <= 30 && (s & 1) == 0) frag_read(cur, 1, s >> 1);
-      if (s == 36) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (DMA && s >= 40 && s <= 100 && (s & 3) == 0) dma_piece(cur, (s - 40) >> 2);
-      if (NEXT && s == 103) {
+      static_assert(15 * RGAP < BAR1 && BAR1 < DMA0 && DMA0 + 15 * DGAP < NX0 - 1 && NX0 + 15 * NGAP < 128, "slot plan");
+      if (s < 16 * RGAP && s % RGAP == 0) frag_read(cur, 1, s / RGAP);
+      if (s == BAR1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (DMA && s >= DMA0 && s < DMA0 + 16 * DGAP && (s - DMA0) % DGAP == 0) dma_piece(cur, (s - DMA0) / DGAP);
+      if (NEXT && s == NX0 - 1) {
         if (DMA) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
         else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
       }
-      if (NEXT && s >= 104 && s < 120) frag_read(nxt, 0, s - 104);
+      if (NEXT && s >= NX0 && s < NX0 + 16 * NGAP && (s - NX0) % NGAP == 0) frag_read(nxt, 0, (s - NX0) / NGAP);
       __builtin_amdgcn_sched_barrier(0);
     }
     if (DMA) next_tile();
@@ -182,8 +183,8 @@ __global__ void naive_rows(const bf16_t* A, const bf16_t* W, float* out, const i
 static bf16_t f2bf(float f) { unsigned u; memcpy(&u, &f, 4); u += 0x7fffu + ((u >> 16) & 1u); return (bf16_t)(u >> 16); }
 static float bf2f(bf16_t h) { unsigned u = (unsigned)h << 16; float f; memcpy(&f, &u, 4); return f; }
 
-template <int STAG>
-static int run(int M, int N, int K, bool check_all) {
+typedef void (*kern_t)(const bf16_t*, const bf16_t*, bf16_t*, int, int, int);
+static int run(kern_t kern, const char* name, int M, int N, int K, bool check_all) {
   std::vector<bf16_t> hA((size_t)M * K), hW((size_t)N * K);
   unsigned s = 12345u + M + N + K;
   auto rnd = [&]() { s = s * 1664525u + 1013904223u; return ((s >> 8) & 0xffff) / 65536.0f - 0.5f; };
@@ -194,13 +195,13 @@ static int run(int M, int N, int K, bool check_all) {
   (void)hipMemcpy(dA, hA.data(), hA.size() * 2, hipMemcpyHostToDevice);
   (void)hipMemcpy(dW, hW.data(), hW.size() * 2, hipMemcpyHostToDevice);
   (void)hipMemset(dC, 0xff, (size_t)M * N * 2);
-  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemmd_kernel<STAG>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+  (void)hipFuncSetAttribute(reinterpret_cast<const void*>(kern), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   const int grid = (M / BM) * (N / BN);
   hipEvent_t e0, e1; (void)hipEventCreate(&e0); (void)hipEventCreate(&e1);
   float best = 1e30f, ms = 0;
   for (int rep = 0; rep < 5; ++rep) {
     (void)hipEventRecord(e0);
-    hipLaunchKernelGGL(gemmd_kernel<STAG>, dim3(grid), dim3(256), LDS_BYTES, 0, dA, dW, dC, M, N, K);
+    hipLaunchKernelGGL(kern, dim3(grid), dim3(256), LDS_BYTES, 0, dA, dW, dC, M, N, K);
     (void)hipEventRecord(e1);
     if (hipDeviceSynchronize() != hipSuccess) { printf("launch failed: %s\n", hipGetErrorString(hipGetLastError())); return 1; }
     (void)hipEventElapsedTime(&ms, e0, e1);
@@ -225,24 +226,33 @@ static int run(int M, int N, int K, bool check_all) {
       if (err > max_rel) max_rel = err;
       if (!(err < 8e-3)) ++bad;
     }
-  printf("stag=%d M=%6d N=%6d K=%6d  %8.3f ms  %7.1f TFLOP/s   checked %d rows: max rel err %.2e, %ld bad\n", STAG, M, N, K, best,
+  printf("%-28s M=%6d N=%6d K=%6d  %8.3f ms  %7.1f TFLOP/s   checked %d rows: max rel err %.2e, %ld bad\n", name, M, N, K, best,
          2.0 * M * N * K / (best * 1e-3) / 1e12, nr, max_rel, bad);
   (void)hipFree(dA); (void)hipFree(dW); (void)hipFree(dC); (void)hipFree(dRef); (void)hipFree(dRows);
   return bad != 0;
 }
 
+#define RUN(name, M, N, K, all, ...) rc |= run(gemmd_kernel<__VA_ARGS__>, name, M, N, K, all)
 int main() {
-  int rc = run<0>(512, 512, 256, true);
-  rc |= run<0>(256, 256, 64, true);                      // a single K tile
-  rc |= run<0>(256, 512, 128, true);                     // two K tiles
-  rc |= run<1>(2048, 2048, 1024, true);
-  rc |= run<0>(8192, 8192, 8192, false);
-  rc |= run<0>(131072, 5120, 5120, false);
-  rc |= run<1>(131072, 5120, 5120, false);
-  rc |= run<0>(131072, 5120, 13824, false);
-  rc |= run<1>(131072, 5120, 13824, false);
-  rc |= run<0>(16384, 7168, 5120, false);
-  rc |= run<1>(16384, 7168, 5120, false);
+  int rc = 0;
+  RUN("base", 512, 512, 256, true, 0);
+  RUN("base", 256, 256, 64, true, 0);                      // a single K tile
+  RUN("base", 256, 512, 128, true, 0);                     // two K tiles
+  RUN("stag", 2048, 2048, 1024, true, 1);
+  RUN("next96/2", 2048, 2048, 1024, true, 0, 2, 36, 40, 3, 96, 2);
+  RUN("early", 2048, 2048, 1024, true, 0, 1, 20, 24, 4, 96, 2);
+  const int shapes[4][3] = {{131072, 5120, 5120}, {131072, 5120, 13824}, {16384, 7168, 5120}, {8192, 8192, 8192}};
+  for (auto& sh : shapes) {
+    const int M = sh[0], N = sh[1], K = sh[2];
+    RUN("base", M, N, K, false, 0);
+    RUN("next96/2 dgap3", M, N, K, false, 0, 2, 36, 40, 3, 96, 2);
+    RUN("early rgap1 bar20", M, N, K, false, 0, 1, 20, 24, 4, 96, 2);
+    RUN("early rgap1 bar20 nx104", M, N, K, false, 0, 1, 20, 24, 5, 104, 1);
+    RUN("dgap2", M, N, K, false, 0, 2, 36, 40, 2, 104, 1);
+    RUN("group_m 8", M, N, K, false, 0, 2, 36, 40, 4, 104, 1, 8);
+    RUN("group_m 2", M, N, K, false, 0, 2, 36, 40, 4, 104, 1, 2);
+    RUN("base again", M, N, K, false, 0);
+  }
   printf(rc ? "FAILED\n" : "all checks passed\n");
   return rc;
 }
