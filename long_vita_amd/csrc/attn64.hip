@@ -150,21 +150,21 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
   // LDS address of this wave's first piece in K / V ring slot 0.  The descriptor is re-based on the tile's first row: no
   // 4 GiB limit on the K / V buffers, no address VALU.  `opaque` keeps the 16 piece addresses from being hoisted into 16 SGPRs.
   const unsigned lds_kw = lds0 + LDS_K + wave * 4096, lds_vw = lds0 + LDS_V + wave * 4096;
+  // issued from inline asm (vita_lds_dma16, vita_common.h): through the builtin, hipcc put an `s_waitcnt vmcnt(0)` in front of the first
+  // V^T read of every P.V phase — the next tile's DMA, issued one phase earlier, was waited for in the middle of the current tile
   auto dma_k = [&](const TileIt& t, int slot) __attribute__((always_inline)) {
-    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)t.kp, 0, 0x7fffffff, 0x00020000);
+    const vita_rsrc_t r = vita_make_rsrc_uniform(t.kp);
     unsigned base = lds_kw;
     asm volatile("" : "+s"(base));
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lvoid*)(uintptr_t)(base + slot * TILEB + q * 1024), 16, dk_off[q], 0, 0, 0);
+    for (int q = 0; q < 4; ++q) vita_lds_dma16(r, dk_off[q], base + slot * TILEB + q * 1024);
   };
   auto dma_v = [&](const TileIt& t, int slot) __attribute__((always_inline)) {
-    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)t.vp, 0, 0x7fffffff, 0x00020000);
+    const vita_rsrc_t r = vita_make_rsrc_uniform(t.vp);
     unsigned base = lds_vw;
     asm volatile("" : "+s"(base));
 #pragma unroll
-    for (int q = 0; q < 4; ++q)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lvoid*)(uintptr_t)(base + slot * TILEB + q * 1024), 16, dv_off[q], 0, 0, 0);
+    for (int q = 0; q < 4; ++q) vita_lds_dma16(r, dv_off[q], base + slot * TILEB + q * 1024);
   };
 
   // ---- tile iterator -----------------------------------------------------------------------------------------------------------

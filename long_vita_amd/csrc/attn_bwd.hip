@@ -18,6 +18,7 @@
 // (32-byte chunk ^ 2*(row & 3), ds_read_b64_tr_b16 transposed fragments); tiles are staged with
 // the LDS-DMA, swizzles applied on the source address.
 #include "vita_common.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -55,17 +56,22 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 __device__ __forceinline__ int frag_off(int row, int slot) { return row * ROWB + ((slot ^ (row & 15)) << 4); }
 __device__ __forceinline__ int tr_off(int row, int chunk, int b) { return row * ROWB + ((chunk ^ ((row & 3) << 1)) << 5) + b; }
 
-// DMA one 1-KiB piece (4 rows x 256 B) of a [rows][128] bf16 matrix into LDS; lane -> (row piece*4 +
-// lane/16, physical 16-B slot lane%16); `tr` selects the layout (source-side swizzle).
-__device__ __forceinline__ void dma_piece(const bf16_t* base, int64_t rs, int row_lo, int row_hi, int piece,
-                                          int lane, bool tr, unsigned lds_dst) {
+// DMA one 1-KiB piece (4 rows x 256 B) of a [rows][128] bf16 tile into LDS; tile = descriptor of its first row (wave-uniform),
+// rows_valid = rows that exist (later ones are clamped, masked afterwards); lane -> (row piece*4 + lane/16, physical 16-B slot
+// lane%16); `tr` selects the layout (source-side swizzle).  Issued from inline asm (vita_lds_dma16, see vita_common.h): through the
+// builtin hipcc put an s_waitcnt vmcnt(0) in front of the first ds_read_b64_tr_b16 of every tile — the prefetch of the next tile was
+// a blocking load, the reason the round-1 kernels ran at 0.39 / 0.52 PFLOP/s.
+__device__ __forceinline__ void dma_piece(vita_rsrc_t tile, int64_t rs, int rows_valid, int piece, int lane, bool tr,
+                                          unsigned lds_dst) {
   int row = piece * 4 + (lane >> 4);
   const int ps = lane & 15;
   const int ls = tr ? ((((ps >> 1) ^ ((row & 3) << 1)) << 1) | (ps & 1)) : (ps ^ (row & 15));
-  int grow = row_lo + row;
-  grow = grow < row_hi ? grow : row_hi - 1;            // clamp (masked later)
-  __builtin_amdgcn_global_load_lds((gvoid*)(base + (int64_t)grow * rs + ls * 8),
-                                   (lvoid*)(uintptr_t)(lds_dst + piece * 1024), 16, 0, 0);
+  const int r = row < rows_valid ? row : rows_valid - 1;
+  vita_lds_dma16(tile, (unsigned)(r * rs * 2 + ls * 16), (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_dst + piece * 1024)));
+}
+// 64 floats / ints: lane -> element lane % 32 of a wave-uniform array (both halves of the wave fetch the same 32)
+__device__ __forceinline__ void dma_words32(vita_rsrc_t base, int lane, unsigned lds_dst) {
+  vita_lds_dma4(base, (unsigned)((lane & 31) * 4), (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst));
 }
 
 __device__ __forceinline__ bf16x8 read_frag(unsigned tile, int row, int slot) {
@@ -93,8 +99,11 @@ __device__ __forceinline__ bf16x8 pack8(const f32x16& s, int base) {
 // ================================================================================================
 constexpr int QT_DQ = 128;      // query rows per workgroup
 constexpr int KT_DQ = 64;       // keys per tile
-// LDS per stage: K frag (16 KiB) | K tr (16 KiB) | V frag (16 KiB)
+// LDS per stage: K frag (16 KiB) | K tr (16 KiB) | V frag (16 KiB); a ring of three stages, tiles fetched two ahead (a tile of
+// 48 MFMAs per wave is ~0.7 us of work against 1-2 us of memory latency: with one tile in flight the kernel waited on every tile)
 constexpr int DQ_STAGE = 3 * KT_DQ * ROWB;
+constexpr int DQ_NSTAGE = 3;
+constexpr int DQ_DMA_PER_STAGE = 12;   // LDS-DMA instructions a wave issues per stage (3 images x 4 pieces)
 
 __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -136,6 +145,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
   }
   const float lse2 = p.lse[(int64_t)head * p.n_q_rows + q_row] * 1.44269504088896340736f;
   const float dlt = p.delta[(int64_t)head * p.n_q_rows + q_row];
+  // consume the loads here: the compiler then waits for them HERE and not at their first use inside the loop, where its
+  // s_waitcnt vmcnt() would also wait for the LDS-DMA pieces in flight (issued from asm, it does not know about them)
+#pragma unroll
+  for (int ds = 0; ds < 8; ++ds) asm volatile("" :: "v"(qf[ds]), "v"(dof[ds]));
+  asm volatile("" :: "v"(lse2), "v"(dlt));
 
   f32x16 dq_acc[4];
 #pragma unroll
@@ -154,33 +168,47 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
     return min(all, q_last_wg / KT_DQ + 1);
   };
   auto stage_tile = [&](int c, int j, unsigned sl) __attribute__((always_inline)) {
-    const int64_t crow = p.kv_row[c];
-    const int lo = j * KT_DQ;
+    const int64_t row0 = p.kv_row[c] + (int64_t)j * KT_DQ;
+    const int valid = p.chunk_len - j * KT_DQ;
+    const vita_rsrc_t kt0 = vita_make_rsrc(kbase + row0 * p.k_rs);
+    const vita_rsrc_t vt0 = vita_make_rsrc(vbase + row0 * p.v_rs);
     // 16 pieces per 64-row image; 4 waves -> 4 pieces each per image
 #pragma unroll
     for (int q = 0; q < 4; ++q) {
       const int piece = wave * 4 + q;
-      dma_piece(kbase + crow * p.k_rs, p.k_rs, lo, p.chunk_len, piece, lane, false, sl);
-      dma_piece(kbase + crow * p.k_rs, p.k_rs, lo, p.chunk_len, piece, lane, true, sl + KT_DQ * ROWB);
-      dma_piece(vbase + crow * p.v_rs, p.v_rs, lo, p.chunk_len, piece, lane, false, sl + 2 * KT_DQ * ROWB);
+      dma_piece(kt0, p.k_rs, valid, piece, lane, false, sl);
+      dma_piece(kt0, p.k_rs, valid, piece, lane, true, sl + KT_DQ * ROWB);
+      dma_piece(vt0, p.v_rs, valid, piece, lane, false, sl + 2 * KT_DQ * ROWB);
     }
   };
 
+  // two iterators over the same tile sequence: `f` = the tile fetched next (two ahead), `cur` = the tile computed
+  auto advance = [&](int& c, int& j, int& n) __attribute__((always_inline)) {
+    if (++j == n) {
+      j = 0;
+      ++c;
+      while (c < p.n_kv_chunks && (n = chunk_tiles(c)) == 0) ++c;
+    }
+  };
   int c_cur = 0, j_cur = wg_first_start / KT_DQ, n_cur = 0;
   while (c_cur < p.n_kv_chunks && (n_cur = chunk_tiles(c_cur)) == 0) ++c_cur;
-  if (c_cur < p.n_kv_chunks) stage_tile(c_cur, j_cur, lds0);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  int c_f = c_cur, j_f = j_cur, n_f = n_cur;
+  int fstage = 0;                                        // ring slot the next fetched tile goes to
+  auto fetch_next = [&]() __attribute__((always_inline)) -> bool {
+    if (c_f >= p.n_kv_chunks) return false;
+    stage_tile(c_f, j_f, lds0 + fstage * DQ_STAGE);
+    fstage = fstage + 1 == DQ_NSTAGE ? 0 : fstage + 1;
+    advance(c_f, j_f, n_f);
+    return true;
+  };
+  fetch_next();
+  if (fetch_next()) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DQ_DMA_PER_STAGE) : "memory");
+  else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
 
   int stage = 0;
   while (c_cur < p.n_kv_chunks) {
-    int c_n = c_cur, j_n = j_cur + 1, n_n = n_cur;
-    if (j_n == n_cur) {
-      j_n = 0;
-      ++c_n;
-      while (c_n < p.n_kv_chunks && (n_n = chunk_tiles(c_n)) == 0) ++c_n;
-    }
-    if (c_n < p.n_kv_chunks) stage_tile(c_n, j_n, lds0 + (stage ^ 1) * DQ_STAGE);
+    const bool issued = fetch_next();                    // tile t+2 -> the slot tile t-1 was read from (barrier at the end of t-1)
 
     const unsigned kf = lds0 + stage * DQ_STAGE, kt = kf + KT_DQ * ROWB, vf = kf + 2 * KT_DQ * ROWB;
     const int kv_off = j_cur * KT_DQ;
@@ -202,29 +230,40 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
         const bool need_mask = diag && kv_off + 32 * h + 31 > q_off;
         const bool seg_mask = kv_off + 32 * h < wg_last_start;
 #pragma unroll
-        for (int r = 0; r < 16; ++r) {
-          const int key = kv_off + 32 * h + (r & 3) + 8 * (r >> 2) + 4 * hi;
-          float pr = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale_log2e, -lse2));
-          if ((need_mask && key > my_q) || (seg_mask && key < my_start)) pr = 0.f;
-          s[r] = pr * (dp[r] - dlt) * p.scale;           // dS^T
+        for (int r = 0; r < 16; ++r) s[r] = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale_log2e, -lse2));      // P^T
+        if (need_mask || seg_mask) {                     // wave-uniform: only tiles on the diagonal / at a sample boundary
+          const int lim_hi = need_mask ? my_q : 0x7fffffff, lim_lo = seg_mask ? my_start : 0;
+#pragma unroll
+          for (int r = 0; r < 16; ++r) {
+            const int key = kv_off + 32 * h + (r & 3) + 8 * (r >> 2) + 4 * hi;
+            s[r] = (key > lim_hi) | (key < lim_lo) ? 0.f : s[r];
+          }
         }
 #pragma unroll
+        for (int r = 0; r < 16; ++r) s[r] = s[r] * (dp[r] - dlt) * p.scale;                                 // dS^T
+#pragma unroll
         for (int t = 0; t < 2; ++t) {
-          const bf16x8 dsf = pack8(s, 8 * t);
+          bf16x8 dsf = pack8(s, 8 * t);
+          // VALU result -> inline-asm MFMA operand: the compiler does not know the asm is an MFMA and inserts no wait states
+          asm volatile("s_nop 4" : "+v"(dsf));
 #pragma unroll
           for (int db = 0; db < 4; ++db) {
             const bf16x8 ktf = read_tr(kt, lane, 32 * h + 16 * t, db);               // K^T[d, keys]
-            dq_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ktf, dsf, dq_acc[db], 0, 0, 0);
+            asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(dq_acc[db]) : "v"(ktf), "v"(dsf));
           }
         }
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // tile t+1 must have landed; the pieces of tile t+2 (issued above) may stay in flight
+    if (issued) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(DQ_DMA_PER_STAGE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    stage ^= 1;
-    c_cur = c_n; j_cur = j_n; n_cur = n_n;
+    stage = stage + 1 == DQ_NSTAGE ? 0 : stage + 1;
+    advance(c_cur, j_cur, n_cur);
   }
 
+  // the inline-asm MFMAs are invisible to the compiler's hazard tracking: wait for the matrix pipe, accumulators tied to the wait
+  asm volatile("s_nop 15\n\ts_nop 15" : "+a"(dq_acc[0]), "+a"(dq_acc[1]), "+a"(dq_acc[2]), "+a"(dq_acc[3]));
   bf16_t* op = p.dq + q_row * p.dq_rs + (int64_t)kvh * p.dq_gs + (int64_t)hq * p.dq_hs;
 #pragma unroll
   for (int db = 0; db < 4; ++db)
@@ -242,9 +281,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
 // ================================================================================================
 constexpr int KT_KV = 128;      // keys per workgroup (4 waves x 32)
 constexpr int QT_KV = 32;       // query rows per step
-// LDS: K frag (32 KiB) | V frag (32 KiB) | 2 stages x [Q frag 8 | Q tr 8 | dO frag 8 | dO tr 8 | lse 128 B | delta 128 B]
-constexpr int KV_FIXED = 2 * KT_KV * ROWB;
-constexpr int KV_STAGE = 4 * QT_KV * ROWB + 384;   // + lse, delta, segment start of the 32 rows
+// The workgroup's K / V fragments live in registers (they are the same for every step).  LDS: a ring of four stages of
+// [Q frag 8 KiB | Q tr 8 | dO frag 8 | dO tr 8 | lse, delta, segment starts of the 32 rows (2 KiB)], steps fetched three ahead:
+// a 32-row step is 32 MFMAs per wave (~0.45 us) against 1-2 us of memory latency.
+constexpr int KV_STAGE = 4 * QT_KV * ROWB + 2048;
+constexpr int KV_NSTAGE = 4;
+constexpr int KV_DMA_PER_STAGE = 10;   // LDS-DMA instructions a wave issues per stage (4 images x 2 pieces + two statistics pieces)
 
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -264,16 +306,19 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
   const int my_key = k_off + wave * 32 + l31;           // this lane's key (column of S)
   const int64_t k_row0 = p.kv_row[kc] + k_off;
 
-  // K / V of this workgroup: frag layout, once
+  // K / V fragments of this wave's 32 keys (MFMA B operand: lane -> key l31, k slot 2 ds + hi), straight from global memory
+  bf16x8 kfr[8], vfr[8];
   {
-    const bf16_t* kb = p.k + (int64_t)kvh * p.k_hs + k_row0 * p.k_rs;
-    const bf16_t* vb = p.v + (int64_t)kvh * p.v_hs + k_row0 * p.v_rs;
+    const bf16_t* kb = p.k + (int64_t)kvh * p.k_hs + (k_row0 + wave * 32 + l31) * p.k_rs + hi * 8;
+    const bf16_t* vb = p.v + (int64_t)kvh * p.v_hs + (k_row0 + wave * 32 + l31) * p.v_rs + hi * 8;
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {                        // 32 pieces per 128-row image, 8 per wave
-      const int piece = wave * 8 + q;
-      dma_piece(kb, p.k_rs, 0, KT_KV, piece, lane, false, lds0);
-      dma_piece(vb, p.v_rs, 0, KT_KV, piece, lane, false, lds0 + KT_KV * ROWB);
+    for (int ds = 0; ds < 8; ++ds) {
+      kfr[ds] = *reinterpret_cast<const bf16x8*>(kb + ds * 16);
+      vfr[ds] = *reinterpret_cast<const bf16x8*>(vb + ds * 16);
     }
+    // consume the loads here (see the dQ kernel): no compiler-placed vmcnt wait inside the loop
+#pragma unroll
+    for (int ds = 0; ds < 8; ++ds) asm volatile("" :: "v"(kfr[ds]), "v"(vfr[ds]));
   }
 
   f32x16 dk_acc[4], dv_acc[4];
@@ -294,25 +339,25 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
   auto stage_q = [&](int hq, int qc, int qt, unsigned sl) __attribute__((always_inline)) {
     const int head = kvh * G + hq;
     const int64_t row0 = (int64_t)qc * p.chunk_len + qt * QT_KV;
-    const bf16_t* qb = p.q + (int64_t)kvh * p.q_gs + (int64_t)hq * p.q_hs + row0 * p.q_rs;
-    const bf16_t* db = p.d_o + (int64_t)head * p.do_hs + row0 * p.do_rs;
+    const vita_rsrc_t qb = vita_make_rsrc(p.q + (int64_t)kvh * p.q_gs + (int64_t)hq * p.q_hs + row0 * p.q_rs);
+    const vita_rsrc_t db = vita_make_rsrc(p.d_o + (int64_t)head * p.do_hs + row0 * p.do_rs);
     // 8 pieces per 32-row image: 4 waves x 2
 #pragma unroll
     for (int q = 0; q < 2; ++q) {
       const int piece = wave * 2 + q;
-      dma_piece(qb, p.q_rs, 0, QT_KV, piece, lane, false, sl);
-      dma_piece(qb, p.q_rs, 0, QT_KV, piece, lane, true, sl + QT_KV * ROWB);
-      dma_piece(db, p.do_rs, 0, QT_KV, piece, lane, false, sl + 2 * QT_KV * ROWB);
-      dma_piece(db, p.do_rs, 0, QT_KV, piece, lane, true, sl + 3 * QT_KV * ROWB);
+      dma_piece(qb, p.q_rs, QT_KV, piece, lane, false, sl);
+      dma_piece(qb, p.q_rs, QT_KV, piece, lane, true, sl + QT_KV * ROWB);
+      dma_piece(db, p.do_rs, QT_KV, piece, lane, false, sl + 2 * QT_KV * ROWB);
+      dma_piece(db, p.do_rs, QT_KV, piece, lane, true, sl + 3 * QT_KV * ROWB);
     }
-    if (wave == 0) {                                     // lse (x log2e) and delta of the 32 rows
-      const int64_t sidx = (int64_t)head * p.n_q_rows + row0 + l31;
-      const float val = hi == 0 ? p.lse[sidx] * 1.44269504088896340736f : p.delta[sidx];
-      *(__attribute__((address_space(3))) float*)(uintptr_t)(sl + 4 * QT_KV * ROWB + hi * 128 + l31 * 4) = val;
-    }
-    if (wave == 1 && hi == 0)
-      *(__attribute__((address_space(3))) int*)(uintptr_t)(sl + 4 * QT_KV * ROWB + 256 + l31 * 4) =
-          p.seg_start ? p.seg_start[row0 + l31] : 0;
+    // statistics of the 32 rows, by DMA as well (no register round trip, so nothing waits on it).  Every wave issues two pieces,
+    // so that one counted vmcnt serves all waves: wave 0 the ones that are read (lse at +0, delta at +256), wave 1 the segment starts
+    // of packed sequences (+512) and a spare, waves 2 / 3 spares
+    const int64_t sidx = (int64_t)head * p.n_q_rows + row0;
+    const unsigned stat = sl + 4 * QT_KV * ROWB;
+    const void* first = (wave == 1 && p.seg_start) ? (const void*)(p.seg_start + row0) : (const void*)(p.lse + sidx);
+    dma_words32(vita_make_rsrc(first), lane, stat + wave * 512);
+    dma_words32(vita_make_rsrc(p.delta + sidx), lane, stat + wave * 512 + 256);
   };
 
   int hq_c = 0, qc_c = 0, qt_c = 0;
@@ -328,18 +373,33 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
   };
   qt_c = first_tile(0);
   normalize(hq_c, qc_c, qt_c);
-  const unsigned st0 = lds0 + KV_FIXED;
-  if (hq_c < G) stage_q(hq_c, qc_c, qt_c, st0);
-  asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+  // two iterators over the same step sequence: `f` = the step fetched next (three ahead), `c` = the step computed
+  int hq_f = hq_c, qc_f = qc_c, qt_f = qt_c;
+  int fstage = 0, in_flight = 0;                         // ring slot of the next fetch; steps issued and not yet consumed
+  const unsigned st0 = lds0;
+  auto fetch_next = [&]() __attribute__((always_inline)) {
+    if (hq_f >= G) return;
+    stage_q(hq_f, qc_f, qt_f, st0 + fstage * KV_STAGE);
+    fstage = fstage + 1 == KV_NSTAGE ? 0 : fstage + 1;
+    ++in_flight;
+    ++qt_f;
+    normalize(hq_f, qc_f, qt_f);
+  };
+  // wait until all but the `n` most recently issued steps have landed
+  auto wait_keep = [&](int n) __attribute__((always_inline)) {
+    if (n >= 2) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(2 * KV_DMA_PER_STAGE) : "memory");
+    else if (n == 1) asm volatile("s_waitcnt vmcnt(%0)" :: "n"(KV_DMA_PER_STAGE) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  };
+  fetch_next(); fetch_next(); fetch_next();
+  wait_keep(in_flight - 1);
   __syncthreads();
 
-  const unsigned kfrag = lds0, vfrag = lds0 + KT_KV * ROWB;
-  const int krow = wave * 32 + l31;                     // this lane's key row inside the K/V images
+  const int krow = wave * 32 + l31;                     // this lane's key inside the workgroup's 128
+  (void)krow;
   int stage = 0;
   while (hq_c < G) {
-    int hq_n = hq_c, qc_n = qc_c, qt_n = qt_c + 1;
-    normalize(hq_n, qc_n, qt_n);
-    if (hq_n < G) stage_q(hq_n, qc_n, qt_n, st0 + (stage ^ 1) * KV_STAGE);
+    fetch_next();                                        // step t+3 -> the slot step t-1 was read from
 
     const unsigned sl = st0 + stage * KV_STAGE;
     const unsigned qfr = sl, qtr = sl + QT_KV * ROWB, dofr = sl + 2 * QT_KV * ROWB, dotr = sl + 3 * QT_KV * ROWB;
@@ -355,49 +415,64 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
 #pragma unroll
       for (int ds = 0; ds < 8; ++ds) {
         const bf16x8 qa = read_frag(qfr, l31, 2 * ds + hi);
-        const bf16x8 kb = read_frag(kfrag, krow, 2 * ds + hi);
         const bf16x8 da = read_frag(dofr, l31, 2 * ds + hi);
-        const bf16x8 vb = read_frag(vfrag, krow, 2 * ds + hi);
-        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kb, s, 0, 0, 0);            // S[q, key]
-        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vb, dp, 0, 0, 0);          // dP[q, key]
+        s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kfr[ds], s, 0, 0, 0);       // S[q, key]
+        dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vfr[ds], dp, 0, 0, 0);     // dP[q, key]
       }
       const bool need_mask = diag && q_off < k_off + wave * 32 + 31;
       f32x16 pr;
 #pragma unroll
       for (int rg = 0; rg < 4; ++rg) {
         const f32x4 l4 = *(lds_f32x4*)(uintptr_t)(stat + (8 * rg + 4 * hi) * 4);
-        const f32x4 d4 = *(lds_f32x4*)(uintptr_t)(stat + 128 + (8 * rg + 4 * hi) * 4);
-        typedef __attribute__((ext_vector_type(4))) int i32x4;
-        const i32x4 st4 = *(__attribute__((address_space(3))) const i32x4*)(uintptr_t)(stat + 256 + (8 * rg + 4 * hi) * 4);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          const int r = rg * 4 + j;
-          const int qrow = q_off + 8 * rg + 4 * hi + j;
-          float e = __builtin_amdgcn_exp2f(fmaf(s[r], p.scale_log2e, -l4[j]));
-          if ((need_mask && my_key > qrow) || my_key < st4[j]) e = 0.f;
-          pr[r] = e;
-          s[r] = e * (dp[r] - d4[j]) * p.scale;          // dS[q, key]
+        for (int j = 0; j < 4; ++j)
+          pr[rg * 4 + j] = __builtin_amdgcn_exp2f(fmaf(s[rg * 4 + j], p.scale_log2e, -l4[j] * 1.44269504088896340736f));
+      }
+      if (need_mask || p.seg_start) {                    // wave-uniform: only steps on the diagonal, or packed sequences
+#pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          typedef __attribute__((ext_vector_type(4))) int i32x4;
+          i32x4 st4 = {0, 0, 0, 0};
+          if (p.seg_start) st4 = *(__attribute__((address_space(3))) const i32x4*)(uintptr_t)(stat + 512 + (8 * rg + 4 * hi) * 4);
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            const int qrow = need_mask ? q_off + 8 * rg + 4 * hi + j : 0x7fffffff;
+            pr[rg * 4 + j] = (my_key > qrow) | (my_key < st4[j]) ? 0.f : pr[rg * 4 + j];
+          }
         }
+      }
+#pragma unroll
+      for (int rg = 0; rg < 4; ++rg) {
+        const f32x4 d4 = *(lds_f32x4*)(uintptr_t)(stat + 256 + (8 * rg + 4 * hi) * 4);
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s[rg * 4 + j] = pr[rg * 4 + j] * (dp[rg * 4 + j] - d4[j]) * p.scale;      // dS[q, key]
       }
 #pragma unroll
       for (int t = 0; t < 2; ++t) {
-        const bf16x8 pf = pack8(pr, 8 * t);
-        const bf16x8 dsf = pack8(s, 8 * t);
+        bf16x8 pf = pack8(pr, 8 * t);
+        bf16x8 dsf = pack8(s, 8 * t);
+        // VALU result -> inline-asm MFMA operand: the compiler does not know the asm is an MFMA and inserts no wait states
+        asm volatile("s_nop 4" : "+v"(pf), "+v"(dsf));
 #pragma unroll
         for (int db = 0; db < 4; ++db) {
           const bf16x8 dot = read_tr(dotr, lane, 16 * t, db);                        // dO^T[d, q]
-          dv_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(dot, pf, dv_acc[db], 0, 0, 0);
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(dv_acc[db]) : "v"(dot), "v"(pf));
           const bf16x8 qtf = read_tr(qtr, lane, 16 * t, db);                         // Q^T[d, q]
-          dk_acc[db] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qtf, dsf, dk_acc[db], 0, 0, 0);
+          asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(dk_acc[db]) : "v"(qtf), "v"(dsf));
         }
       }
     }
-    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    // step t+1 must have landed; steps t+2 and t+3 may stay in flight
+    --in_flight;
+    wait_keep(in_flight - 1);
     __syncthreads();
-    stage ^= 1;
-    hq_c = hq_n; qc_c = qc_n; qt_c = qt_n;
+    stage = stage + 1 == KV_NSTAGE ? 0 : stage + 1;
+    ++qt_c;
+    normalize(hq_c, qc_c, qt_c);
   }
 
+  asm volatile("s_nop 15\n\ts_nop 15" : "+a"(dk_acc[0]), "+a"(dk_acc[1]), "+a"(dk_acc[2]), "+a"(dk_acc[3]), "+a"(dv_acc[0]),
+               "+a"(dv_acc[1]), "+a"(dv_acc[2]), "+a"(dv_acc[3]));
   const int64_t orow = k_row0 + wave * 32 + l31;
   bf16_t* okp = p.dk + orow * p.dk_rs + (int64_t)kvh * p.dk_hs;
   bf16_t* ovp = p.dv + orow * p.dv_rs + (int64_t)kvh * p.dv_hs;
@@ -455,7 +530,7 @@ extern "C" int vita_flash_attn_bwd(const vita_attn_bwd_params* p, void* stream) 
 
   hipStream_t st = (hipStream_t)stream;
   static std::atomic<unsigned long long> attr_set{0};
-  constexpr int lds_dq = 2 * DQ_STAGE, lds_kv = KV_FIXED + 2 * KV_STAGE;
+  constexpr int lds_dq = DQ_NSTAGE * DQ_STAGE, lds_kv = KV_NSTAGE * KV_STAGE;
   vita_device_once(attr_set, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel),
                               hipFuncAttributeMaxDynamicSharedMemorySize, lds_dq);
@@ -465,7 +540,8 @@ extern "C" int vita_flash_attn_bwd(const vita_attn_bwd_params* p, void* stream) 
   const int64_t n_dq = (int64_t)p->n_q_heads * p->n_q_chunks * (p->chunk_len / QT_DQ);
   const int64_t n_kv = (int64_t)p->n_kv_heads * p->n_kv_chunks * (p->chunk_len / KT_KV);
   if (n_dq > 0x7fffffff || n_kv > 0x7fffffff) return VITA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)n_dq), dim3(256), lds_dq, st, a);
-  hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)n_kv), dim3(256), lds_kv, st, a);
+  const char* only = getenv("VITA_ATTN_BWD_ONLY");     // developer measurement aid: "dq" / "dkv" launch one of the two kernels
+  if (!only || only[1] == 'q') hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)n_dq), dim3(256), lds_dq, st, a);
+  if (!only || only[1] == 'k') hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)n_kv), dim3(256), lds_kv, st, a);
   return vita_check_launch();
 }

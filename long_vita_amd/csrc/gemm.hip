@@ -807,9 +807,21 @@ int launch_gemm_w4(GemmArgs a, hipStream_t st) {
   const int64_t tn = (a.N + bn_out - 1) / bn_out;
   if (tm * tn > 0x7fffffff) return VITA_ERR_UNSUPPORTED;
   a.tiles_m = (int)tm; a.tiles_n = (int)tn;
-  const bool interior = a.M % 256 == 0 && a.N % bn_out == 0 && (a.ldc & 3) == 0 &&
-                        (!a.R || (a.ldr & 3) == 0);             // 8-byte vector accesses of whole quads
-  return interior ? launch_gemm_w4_cfg<EPI, true>(a, st) : launch_gemm_w4_cfg<EPI, false>(a, st);
+  const bool whole_n = a.N % bn_out == 0 && (a.ldc & 3) == 0 && (!a.R || (a.ldr & 3) == 0);   // 8-byte accesses of whole quads
+  if (whole_n && a.M % 256 == 0) return launch_gemm_w4_cfg<EPI, true>(a, st);
+  if (whole_n && a.M > 256) {
+    // ragged M only (the ViT's frames x 1025 rows): whole tile rows through the mask-free instantiation, the last rows separately
+    GemmArgs top = a;
+    top.M = a.M / 256 * 256; top.tiles_m = (int)(top.M / 256);
+    const int rc = launch_gemm_w4_cfg<EPI, true>(top, st);
+    if (rc != VITA_OK) return rc;
+    GemmArgs rest = a;
+    rest.M = a.M - top.M; rest.tiles_m = 1;
+    rest.A = a.A + top.M * a.lda; rest.C = a.C + top.M * a.ldc;
+    if (a.R) rest.R = a.R + top.M * a.ldr;
+    return launch_gemm_w4_cfg<EPI, false>(rest, st);
+  }
+  return launch_gemm_w4_cfg<EPI, false>(a, st);
 }
 
 // the w4 kernel addresses a tile's rows with 32-bit byte offsets from the tile's first row

@@ -98,3 +98,35 @@ static inline int vita_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? VITA_OK : VITA_ERR_LAUNCH;
 }
+
+// ---- LDS-DMA issued from inline asm ------------------------------------------------------------------------------------------
+// `buffer_load_dword[x4] ... lds` moves 4 / 16 bytes per lane from a buffer address (descriptor base + per-lane byte offset) to
+// LDS address m0 + lane * size.  Issued through the compiler's builtin, hipcc remembers that an LDS write is in flight and puts
+// `s_waitcnt vmcnt(0)` in front of the next LDS read it cannot tell apart from it (every ds_read_b64_tr_b16, many ds_read_b128) —
+// which turns a prefetch into a blocking load in the middle of the tile being computed.  From inline asm the compiler knows
+// nothing about it; the kernels order DMA and reads themselves (counted `s_waitcnt vmcnt(n)` + barrier at stage boundaries).
+typedef __attribute__((ext_vector_type(4))) unsigned int vita_rsrc_t;
+__device__ __forceinline__ vita_rsrc_t vita_make_rsrc(const void* base) {      // raw buffer, no bounds, base must be wave-uniform
+  const unsigned long long v = (unsigned long long)(uintptr_t)base;
+  vita_rsrc_t r;
+  r[0] = __builtin_amdgcn_readfirstlane((unsigned)v);
+  r[1] = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32)) & 0xffffu;
+  r[2] = 0x7fffffffu;
+  r[3] = 0x00020000u;
+  return r;
+}
+__device__ __forceinline__ vita_rsrc_t vita_make_rsrc_uniform(const void* base) {   // base already lives in SGPRs (no readfirstlane)
+  const unsigned long long v = (unsigned long long)(uintptr_t)base;
+  vita_rsrc_t r;
+  r[0] = (unsigned)v; r[1] = (unsigned)(v >> 32) & 0xffffu; r[2] = 0x7fffffffu; r[3] = 0x00020000u;
+  return r;
+}
+__device__ __forceinline__ void vita_lds_dma16(vita_rsrc_t rsrc, unsigned voff_bytes, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :: "s"(lds_addr), "v"(voff_bytes), "s"(rsrc) : "memory", "m0");
+}
+__device__ __forceinline__ void vita_lds_dma4(vita_rsrc_t rsrc, unsigned voff_bytes, unsigned lds_addr) {
+  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
+               :: "s"(lds_addr), "v"(voff_bytes), "s"(rsrc) : "memory", "m0");
+}
+

@@ -60,6 +60,27 @@ def bench_attn(S, Hq=40, Hkv=8, D=128, causal=True, B=1, tag=""):
     emit(kind="attn", tag=tag, S=S, Hq=Hq, Hkv=Hkv, D=D, causal=causal, B=B, ms=med, ms_best=best, tflops=fl / med / 1e9)
 
 
+def bench_attn_bwd(S, Hq=40, Hkv=8, D=128, tag=""):
+    """Attention backward (dQ kernel + dK/dV kernel + the delta pre-pass) on a plain causal sequence; VITA_ATTN_BWD_ONLY=dq|dkv
+    times one of the two kernels alone (developer switch in attn_bwd.hip).  flops: 5 GEMM units of the forward's 2 (algorithmic);
+    the two-kernel scheme executes 7."""
+    q = torch.randn(1, S, Hq, D, device=DEV).bfloat16()
+    k = torch.randn(1, S, Hkv, D, device=DEV).bfloat16()
+    v = torch.randn(1, S, Hkv, D, device=DEV).bfloat16()
+    o, lse = ops.flash_attn(q, k, v, causal=True, return_lse=True)
+    d_o = torch.randn_like(o)
+    dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+    pairs = S * (S + 1) / 2
+    unit = 2.0 * D * Hq * pairs
+    for only, units in (("", 7), ("dq", 3), ("dkv", 4)):
+        if only:
+            os.environ["VITA_ATTN_BWD_ONLY"] = only
+        med, best = timeit(lambda: ops.flash_attn_bwd(q, k, v, o, d_o, lse, dq5=dq, dk=dk, dv=dv), warmup=1, iters=3)
+        os.environ.pop("VITA_ATTN_BWD_ONLY", None)
+        emit(kind="attn_bwd", tag=tag, only=only or "both", S=S, ms=med, ms_best=best, executed_tflops=units * unit / med / 1e9,
+             algorithmic_tflops=(5 * unit / med / 1e9) if not only else None)
+
+
 def bench_hbm():
     rows, cols = 131072, 5120
     x = torch.randn(rows, cols, device=DEV).bfloat16()
@@ -182,5 +203,8 @@ if __name__ == "__main__":
         for S in (4096, 16384, 32768, 131072):
             bench_attn(S, tag=f"llm{S}")
         bench_attn(1025, 16, 16, 64, False, 64, tag="vit64f")
+    if "attn_bwd" in which:
+        for S in (16384, 32768):
+            bench_attn_bwd(S, tag=f"llm{S}")
     if "hbm" in which:
         bench_hbm()
