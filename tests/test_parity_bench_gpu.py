@@ -35,6 +35,11 @@ LIMITS = {
     "attn_fwd_S131072": (1.8e-3, 1.4e-2),
     "attn_cp8_Sl16384_S131072": (3.5e-3, 2.2e-4),
     "attn_cp8_Sl131072_S1048576": (3.5e-3, 5.5e-5),
+    # attention backward at 16K (dQ / dK / dV of kv groups 0 and 7 against fp32 autograd through the oracle on the same rows):
+    # measured rel-L2 2.43e-3 / 2.42e-3 / 2.32e-3, max-abs 8.4e-3 / 1.6e-2 / 2.6e-2 (gradient rms 0.034 / 0.076 / 0.083)
+    "attn_bwd_S16384_dq": (3.6e-3, 1.3e-2),
+    "attn_bwd_S16384_dk": (3.6e-3, 2.4e-2),
+    "attn_bwd_S16384_dv": (3.6e-3, 4.0e-2),
 }
 
 
@@ -102,6 +107,35 @@ def test_attention_at_the_benchmark_sequence(ops, S):
     got = out[0, rows.to(DEV)].view(len(rows), Hkv, G, D)
     ref = torch.stack([oracle_rows(q[0, rows.to(DEV), g * G:(g + 1) * G], k[0], v[0], rows, g) for g in range(Hkv)], 1)
     check(f"attn_fwd_S{S}", got, ref, rows=len(rows), heads=Hq, note="single chunk, causal, 40:8, d=128; sampled rows vs fp32 oracle")
+
+
+def test_attention_backward_at_16k(ops):
+    """vita_flash_attn_bwd (dQ kernel + dK/dV kernel, reworked in round 2) at the 16K training sequence, 40:8 heads: every row of
+    dQ / dK / dV of the first and the last kv group against fp32 autograd through oracle.attention.core_attention (evaluated as torch
+    ops on the GPU: 5 heads x 16384^2 scores in fp32)."""
+    S, Hq, Hkv, D = 16384, 40, 8, 128
+    G = Hq // Hkv
+    q, k, v = randn_bf16((1, S, Hq, D), 70), randn_bf16((1, S, Hkv, D), 71), randn_bf16((1, S, Hkv, D), 72)
+    d_o = randn_bf16((1, S, Hq, D), 73)
+    o, lse = ops.flash_attn(q, k, v, causal=True, return_lse=True)
+    dq, dk, dv = ops.flash_attn_bwd(q, k, v, o, d_o, lse)
+    torch.cuda.synchronize()
+    got = {"dq": [], "dk": [], "dv": []}
+    ref = {"dq": [], "dk": [], "dv": []}
+    for g in (0, Hkv - 1):
+        qf = q[0, :, g * G:(g + 1) * G].float().reshape(S, 1, G, D).requires_grad_(True)
+        kf = k[0, :, g:g + 1].float().reshape(S, 1, 1, D).requires_grad_(True)
+        vf = v[0, :, g:g + 1].float().reshape(S, 1, 1, D).requires_grad_(True)
+        out = oattn.core_attention(qf, kf, vf, True)                                  # [S, 1, G * D] fp32
+        out.backward(d_o[0, :, g * G:(g + 1) * G].float().reshape(S, 1, G * D))
+        ref["dq"].append(qf.grad.reshape(S, G, D).cpu()); got["dq"].append(dq[0, :, g * G:(g + 1) * G].float().cpu())
+        ref["dk"].append(kf.grad.reshape(S, D).cpu()); got["dk"].append(dk[0, :, g].float().cpu())
+        ref["dv"].append(vf.grad.reshape(S, D).cpu()); got["dv"].append(dv[0, :, g].float().cpu())
+        del qf, kf, vf, out
+        torch.cuda.empty_cache()
+    for name in ("dq", "dk", "dv"):
+        check(f"attn_bwd_S{S}_{name}", torch.stack(got[name]), torch.stack(ref[name]), rows=S, groups=2,
+              note="all rows of kv groups 0 and 7 vs fp32 autograd through the oracle attention")
 
 
 @pytest.mark.parametrize("S,rank", [(131072, 3), (1048576, 5)])
