@@ -179,8 +179,6 @@ class GPTVLModel:
                 logit_mask = ip.logit_mask
             if hasattr(ip, "use_kv_cache") and not ip.use_kv_cache:                                  # :285-286
                 ip = None
-        if ip is not None and mpu.get_tensor_model_parallel_world_size() > 1:
-            raise NotImplementedError("the KV-cache decode path is not tensor-parallel")
         if ip is not None and ip.key_value_memory_dict:
             return self._decode_forward(input_ids, position_ids, ip)
         if decoder_input is None:                                                         # :252-277
@@ -287,6 +285,7 @@ class GPTVLModel:
         import torch.distributed as dist
         c = self.cfg
         cp, r = mpu.get_context_parallel_world_size(), mpu.get_context_parallel_rank()
+        tp = mpu.get_tensor_model_parallel_world_size()     # TP > 1: cfg / params / cache hold this rank's heads, groups and ffn slice
         ws = self._decode_workspace(token.device)
         h = ops.row_gather(self.p["embed"], token.reshape(1), out=ws["h"], check_bounds=False)   # [1, hidden]
         cos, sin = ops.rope_table(position.reshape(1), self.rotary_pos_emb.inv_freq)
@@ -317,10 +316,20 @@ class GPTVLModel:
                 dist.all_gather_into_tensor(ws["gmsg"].view(-1), ws["msg"], group=mpu.get_context_parallel_group())
                 gm, gl, go = ops.unpack_partials(ws["gmsg"], c.heads, c.head_dim)
                 ctx = ops.decode_attn_merge(gm, gl, go, True, out=ws["ctx"])
-            ops.gemv(ctx.view(-1), lp["o_w"], ops.EPI_RESIDUAL, residual=h.view(-1), out=h.view(-1))
+            if tp == 1:
+                ops.gemv(ctx.view(-1), lp["o_w"], ops.EPI_RESIDUAL, residual=h.view(-1), out=h.view(-1))
+            else:   # row-parallel: this rank's heads give a partial sum -> bf16 all-reduce over TP -> residual add (as in prefill)
+                part = ops.gemv(ctx.view(-1), lp["o_w"], ops.EPI_NONE, out=ws["x"].view(-1))
+                dist.all_reduce(part, group=mpu.get_tensor_model_parallel_group())
+                ops.add_(h, part.view(1, -1))
             x = ops.rmsnorm(h, lp["ln2"], c.eps, out=ws["x"])
             act = ops.gemv(x.view(-1), lp["fc1_w"], ops.EPI_SWIGLU, out=ws["act"])
-            ops.gemv(act, lp["fc2_w"], ops.EPI_RESIDUAL, residual=h.view(-1), out=h.view(-1))
+            if tp == 1:
+                ops.gemv(act, lp["fc2_w"], ops.EPI_RESIDUAL, residual=h.view(-1), out=h.view(-1))
+            else:
+                part = ops.gemv(act, lp["fc2_w"], ops.EPI_NONE, out=ws["x"].view(-1))
+                dist.all_reduce(part, group=mpu.get_tensor_model_parallel_group())
+                ops.add_(h, part.view(1, -1))
         if counters is not None:
             counters[0].add_(1)
             counters[1].add_(1)
@@ -434,14 +443,18 @@ class GPTVLModel:
         if position_ids is None:
             position_ids = (torch.arange(t, device=input_ids.device) + ip.sequence_len_offset)[None]
         ip.consumed_tokens = t
-        if t == 1 and self.decode_graph and mpu.get_context_parallel_world_size() == 1:
+        tp = mpu.get_tensor_model_parallel_world_size()
+        if t == 1 and self.decode_graph and mpu.get_context_parallel_world_size() == 1 and tp == 1:
             kv = ip.key_value_memory_dict[1]
             if ip.local_len + 1 > kv.shape[1]:
                 raise RuntimeError("KV cache shard is full (max_sequence_length reached)")
             return self._decode_graphed(input_ids[0], position_ids[0], ip).view(1, 1, -1).clone()
         ip._graph = None                      # eager steps move the python-side counters only
-        step = self._decode_token_fused if self.decode_fused else self._decode_token
+        # tensor parallelism (the released server runs TP 8 x CP 4, server_cp .sh:102-104): the kernel-by-kernel step, whose
+        # row-parallel GEMVs all-reduce their partial sums; the C-side fused layer adds the residual inside the GEMV epilogue
+        step = self._decode_token_fused if (self.decode_fused and tp == 1) else self._decode_token
         rows = [step(input_ids[0, j: j + 1], position_ids[0, j: j + 1], ip) for j in range(t)]
         rows = rows[0] if t == 1 else torch.cat(rows, dim=0)
         logits, _ = self.output_layer(rows.view(t, 1, -1), weight=None, logit_mask=None)
+        logits = self._gather_vocab_parallel(logits)
         return logits.transpose(0, 1).contiguous()

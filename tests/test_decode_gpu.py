@@ -213,3 +213,33 @@ def test_fused_decode_layer_equals_separate_kernels(amd):
     toks_s, lp_s = _decode_run(amd, model, prompt, n_new, max_len, True)
     assert torch.equal(toks_f, toks_s)
     assert lp_err(lp_f, lp_s) < 2e-3
+
+
+@pytest.mark.parametrize("tp,cp", [(2, 1), (2, 2)])
+def test_cached_decode_tensor_parallel(amd, monkeypatch, tp, cp):
+    """TP in the decode path (the released server runs TP 8 x CP 4, R/scripts/megatron/qwen25/..._server_cp.sh:102-104): every
+    tensor-parallel rank keeps the K/V rows of ITS kv groups, the row-parallel GEMVs all-reduce their bf16 partial sums before the
+    residual add, the vocab-parallel logits are gathered — simulated ranks == TP = 1 cached decode (and the oracle's logits)."""
+    from long_vita_amd import tensor_parallel as tpar
+    from test_train_gpu import _run_grid
+    cfgd = dict(SMALL, kv_groups=4)                        # 4 kv groups: 2 per tensor-parallel rank
+    ocfg, p, model1 = _llm_pair(amd, cfgd)
+    G = amd["gpt"]
+    P, n_new, max_len = 1536, 5, 4096
+    prompt = torch.randint(0, cfgd["vocab"], (1, P), generator=torch.Generator().manual_seed(P)).to(DEV)
+    toks1, lp1 = _decode_run(amd, model1, prompt, n_new, max_len, True)
+
+    def rank_fn(ci, ti):
+        shard, cfg_l = tpar.shard_llm_params(p, G.GPTConfig(**cfgd), tp, ti)
+        m = G.GPTVLModel.from_oracle_layout(cfg_l, shard, None, DEV)
+        return _decode_run(amd, m, prompt, n_new, max_len, True)
+
+    outs = _run_grid(tp, cp, rank_fn, amd, monkeypatch)
+    first = outs[(0, 0)]
+    for key, o in outs.items():
+        assert torch.equal(o[0], first[0]) and torch.equal(o[1], first[1]), key
+    assert lp_err(first[1][:, 0], lp1[:, 0]) < 1.5e-2
+    if torch.equal(first[0], toks1):
+        assert lp_err(first[1], lp1) < 1.5e-2
+    ora = ollm.prefill_logits(first[0].cpu(), p, ocfg, list(range(P - 1, P - 1 + n_new)))[0]
+    assert lp_err(first[1][0], torch.log_softmax(ora.float(), dim=1)) < 2.5e-2
