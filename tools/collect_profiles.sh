@@ -14,6 +14,6 @@ DB=$(find /tmp/prof_ks -name "*.db" | head -1)
 if [ -n "$DB" ]; then python tools/rocpd_summary.py $DB $OUT/${TAG}_bench128k_kernel_stats.txt | head -12; else find /tmp/prof_ks | head; CSV=$(find /tmp/prof_ks -name "*kernel_stats.csv" | head -1); [ -n "$CSV" ] && cp $CSV $OUT/${TAG}_bench128k_kernel_stats.csv && head -8 $CSV; fi
 for C in FETCH_SIZE WRITE_SIZE "SQ_VALU_MFMA_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_INSTS_VALU SQ_INSTS_MFMA GRBM_GUI_ACTIVE"; do
   D=/tmp/prof_pmc_$(echo $C | cut -d' ' -f1); rm -rf $D
-  PMC_S=131072 PMC_GEMM=0 rocprofv3 --pmc $C --output-format csv -d $D -- python tools/pmc_kernels.py > /dev/null 2> $D.err
+  PMC_S=131072 PMC_GEMM=1 rocprofv3 --pmc $C --output-format csv -d $D -- python tools/pmc_kernels.py > /dev/null 2> $D.err
   python tools/pmc_summary.py $D | tee -a $OUT/${TAG}_attn128k_pmc_raw.txt
 done

@@ -155,21 +155,27 @@ def bench_gemm_variants():
         del a, w, out
 
 
-def bench_gemm_env(name, values):
-    """Sweep one developer env switch of the GEMM (VITA_GEMM_STAGGER, ...) over the four decoder GEMMs with their epilogues."""
-    for (M, N, K, epi, tag) in [(131072, 7168, 5120, 1, "S128K/qkv"), (131072, 5120, 5120, 3, "S128K/o"),
-                                (131072, 13824, 5120, 5, "S128K/fc1_swiglu"), (131072, 5120, 13824, 3, "S128K/fc2"),
-                                (16384, 7168, 5120, 1, "S16K/qkv"), (16384, 5120, 13824, 3, "S16K/fc2")]:
+LLM_SHAPES = [(131072, 7168, 5120, 1, "S128K/qkv"), (131072, 5120, 5120, 3, "S128K/o"),
+              (131072, 13824, 5120, 5, "S128K/fc1_swiglu"), (131072, 5120, 13824, 3, "S128K/fc2"),
+              (16384, 7168, 5120, 1, "S16K/qkv"), (16384, 5120, 13824, 3, "S16K/fc2")]
+VIT_SHAPES = [(262400, 3072, 1024, 1, "vit256f/qkv"), (262400, 1024, 1024, 4, "vit256f/proj"), (262400, 4096, 1024, 2, "vit256f/fc1_gelu"),
+              (262400, 1024, 4096, 4, "vit256f/fc2"), (65536, 1024, 4096, 0, "projector/fc1"), (65536, 5120, 1024, 0, "projector/fc2")]
+
+
+def bench_gemm_env(name, values, shapes=None):
+    """Sweep one developer env switch of the GEMM (VITA_GEMM_STAGGER, VITA_GEMM_KERNEL, ...) over GEMMs with their epilogues."""
+    for (M, N, K, epi, tag) in (shapes or LLM_SHAPES):
         a = (torch.randn(M, K, device=DEV) * 0.5).bfloat16()
         w = (torch.randn((2 * N if epi == 5 else N), K, device=DEV) * 0.02).bfloat16()
         out = torch.empty(M, N, dtype=torch.bfloat16, device=DEV)
-        res = torch.randn(M, N, device=DEV).bfloat16() if epi == 3 else None
-        bias = torch.randn(N, device=DEV).bfloat16() if epi == 1 else None
+        res = torch.randn(M, N, device=DEV).bfloat16() if epi in (3, 4) else None
+        bias = torch.randn(N, device=DEV).bfloat16() if epi in (1, 2, 4) else None
+        scale = torch.randn(N, device=DEV).bfloat16() if epi == 4 else None
         base = None
         for v in values:
             os.environ[name] = v
             out.zero_()
-            med, best = timeit(lambda: ops.gemm(a, w, epi, bias, None, res, out=out))
+            med, best = timeit(lambda: ops.gemm(a, w, epi, bias, scale, res, out=out))
             if base is None:
                 base = out[:2048].float().clone()
             err = float((out[:2048].float() - base).abs().max())
@@ -181,8 +187,8 @@ def bench_gemm_env(name, values):
 
 if __name__ == "__main__":
     which = sys.argv[1:] or ["gemm", "attn", "hbm"]
-    if which and which[0] == "env":
-        bench_gemm_env(which[1], which[2].split(","))
+    if which and which[0] in ("env", "envvit"):
+        bench_gemm_env(which[1], which[2].split(","), VIT_SHAPES if which[0] == "envvit" else None)
         sys.exit(0)
     if "variants" in which:
         bench_gemm_variants()

@@ -11,7 +11,7 @@ q = torch.randn(1, S, 40, 128, device=DEV).bfloat16(); k = torch.randn(1, S, 8, 
 v = torch.randn(1, S, 8, 128, device=DEV).bfloat16(); o = torch.empty_like(q)
 do_gemm = os.environ.get("PMC_GEMM", "1") != "0"
 if do_gemm:
-    M = 16384
+    M = 131072 if S >= 131072 else 16384      # the decoder's fc1 + SwiGLU GEMM at the same token count
     a = (torch.randn(M, 5120, device=DEV) * 0.5).bfloat16(); w = (torch.randn(2 * 13824, 5120, device=DEV) * 0.02).bfloat16()
     c = torch.empty(M, 13824, dtype=torch.bfloat16, device=DEV)
 for _ in range(3):
