@@ -17,33 +17,13 @@
 // LDS images: "frag" layout (16-byte slot ^ (row & 15), ds_read_b128 fragments) and "tr" layout
 // (32-byte chunk ^ 2*(row & 3), ds_read_b64_tr_b16 transposed fragments); tiles are staged with
 // the LDS-DMA, swizzles applied on the source address.
-#include "vita_common.h"
+#include "attn_bwd_args.h"
 #include <stdlib.h>
 
 namespace {
 
-constexpr int kMaxChunks = 32;
+constexpr int kMaxChunks = kBwdMaxChunks;
 constexpr int D = 128, ROWB = 256;     // bytes per row
-
-struct BwdArgs {
-  const bf16_t* q; int64_t q_rs, q_hs, q_gs;        // query rows (rotated), grouped head addressing
-  const bf16_t* k; int64_t k_rs, k_hs;
-  const bf16_t* v; int64_t v_rs, v_hs;
-  const bf16_t* d_o; int64_t do_rs, do_hs;           // [rows, Hq, 128]
-  const float* lse;                                   // [Hq, n_q_rows] natural log
-  const float* delta;                                 // [Hq, n_q_rows]
-  bf16_t* dq; int64_t dq_rs, dq_hs, dq_gs;
-  bf16_t* dk; int64_t dk_rs, dk_hs;                   // same row space as k / v
-  bf16_t* dv; int64_t dv_rs, dv_hs;
-  int n_q_heads, n_kv_heads;
-  int chunk_len, n_q_chunks, n_kv_chunks, n_q_rows;
-  float scale, scale_log2e;
-  const int* seg_start;   // packed sequences (single chunk): first row of each query row's segment, or null
-  const int* seg_end;     // one past the last row of each key row's segment, or null
-  int q_gid[kMaxChunks];
-  int kv_gid[kMaxChunks];
-  int64_t kv_row[kMaxChunks];
-};
 
 typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(3))) const bf16x8 lds_bf16x8;
@@ -541,7 +521,14 @@ extern "C" int vita_flash_attn_bwd(const vita_attn_bwd_params* p, void* stream) 
   const int64_t n_kv = (int64_t)p->n_kv_heads * p->n_kv_chunks * (p->chunk_len / KT_KV);
   if (n_dq > 0x7fffffff || n_kv > 0x7fffffff) return VITA_ERR_UNSUPPORTED;
   const char* only = getenv("VITA_ATTN_BWD_ONLY");     // developer measurement aid: "dq" / "dkv" launch one of the two kernels
-  if (!only || only[1] == 'q') hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)n_dq), dim3(256), lds_dq, st, a);
+  if (!only || only[1] == 'q') {
+    if (vita_attn_bwd_dq64_eligible(a)) {            // causal whole 256-row tiles: 64 query rows per wave (attn_bwd64.hip)
+      const int rc = vita_attn_bwd_dq64_launch(a, st);
+      if (rc != VITA_OK) return rc;
+    } else {
+      hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)n_dq), dim3(256), lds_dq, st, a);
+    }
+  }
   if (!only || only[1] == 'k') hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)n_kv), dim3(256), lds_kv, st, a);
   return vita_check_launch();
 }
