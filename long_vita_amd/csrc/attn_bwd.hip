@@ -529,6 +529,13 @@ extern "C" int vita_flash_attn_bwd(const vita_attn_bwd_params* p, void* stream) 
       hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)n_dq), dim3(256), lds_dq, st, a);
     }
   }
-  if (!only || only[1] == 'k') hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)n_kv), dim3(256), lds_kv, st, a);
+  if (!only || only[1] == 'k') {
+    if (vita_attn_bwd_kv64_eligible(a)) {            // whole 256-key tiles: 64 keys per wave, a dK and a dV launch (attn_bwd_kv64.hip)
+      const int rc = vita_attn_bwd_kv64_launch(a, st);
+      if (rc != VITA_OK) return rc;
+    } else {
+      hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)n_kv), dim3(256), lds_kv, st, a);
+    }
+  }
   return vita_check_launch();
 }

@@ -27,3 +27,6 @@ struct BwdArgs {
 // attn_bwd64.hip: dQ with 64 query rows per wave (causal, whole 256-row tiles, every query chunk also a key chunk)
 bool vita_attn_bwd_dq64_eligible(const BwdArgs& a);
 int vita_attn_bwd_dq64_launch(const BwdArgs& a, hipStream_t st);
+// attn_bwd_kv64.hip: dK and dV with 64 keys per wave, as two launches (causal, whole 256-key tiles)
+bool vita_attn_bwd_kv64_eligible(const BwdArgs& a);
+int vita_attn_bwd_kv64_launch(const BwdArgs& a, hipStream_t st);
