@@ -66,9 +66,15 @@ def _pad_rows(x: torch.Tensor, mult: int = 64) -> torch.Tensor:
 class TrainStep:
     """forward_backward(tokens, labels, loss_mask, external_inputs) -> (loss, grads)."""
 
-    def __init__(self, model: GPTVLModel, is_instruction_dataset: bool = True):
+    def __init__(self, model: GPTVLModel, is_instruction_dataset: bool = True, recompute_num_layers: Optional[int] = None):
+        """recompute_num_layers: Megatron's `--recompute-granularity full --recompute-method block --recompute-num-layers N`
+        (M/training/arguments.py; stage 3 passes 20, stage 4 all layers): the FIRST N decoder layers keep only their input and are
+        re-run in the backward, the others keep their activations.  None = every layer (what an 80 GB device needs at these
+        sequence lengths); on 288 GB of HBM a 16K / 32K step keeps everything (N = 0: 1.5 GB per layer at 16K) and skips the
+        second forward altogether."""
         self.m = model
         self.is_instruction = is_instruction_dataset
+        self.recompute_num_layers = recompute_num_layers
 
     # ------------------------------------------------------------------------------------------
     def _layer_recompute(self, h, lp, cos, sin):
@@ -103,6 +109,36 @@ class TrainStep:
         return dict(x1=x1, qkv=qkv, q5=q5, k_all=k_all, v_all=v_all, geo=geo, ctx=ctx, lse=lse, h_mid=h_mid, x2=x2,
                     y=y, act=act)
 
+    def _layer_forward_keep(self, h, lp, cos, sin):
+        """Forward of one decoder layer that KEEPS its activations for the backward (a layer outside the recompute block):
+        returns (layer output, what _layer_backward needs).  The cheap HBM-bound intermediates (both RMSNorm outputs, the
+        SwiGLU product) are dropped again and re-derived in the backward; under CP the gathered K / V are re-gathered."""
+        m = self.m
+        a = self._layer_recompute(h, lp, cos, sin)
+        if mpu.get_tensor_model_parallel_world_size() == 1:
+            out = ops.gemm(a["act"], lp["fc2_w"], ops.EPI_RESIDUAL, residual=a["h_mid"])
+        else:
+            out = m._row_parallel(a["act"], lp["fc2_w"], a["h_mid"].clone(), torch.empty_like(h))
+        keep = dict(qkv=a["qkv"], ctx=a["ctx"], lse=a["lse"], h_mid=a["h_mid"], y=a["y"])
+        return out, keep
+
+    def _rebuild(self, h, lp, keep):
+        """The dictionary _layer_recompute returns, from the kept activations of _layer_forward_keep."""
+        c = self.m.cfg
+        s = h.shape[0]
+        cp = mpu.get_context_parallel_world_size()
+        qkv = keep["qkv"]
+        m5 = qkv.view(1, s, c.kv_groups, c.qpg + 2, c.head_dim)
+        if cp > 1:
+            kv_local = torch.stack([m5[0, :, :, c.qpg], m5[0, :, :, c.qpg + 1]]).contiguous()      # rotated K, V of this rank
+            k_all, v_all, geo = self._gather_kv(kv_local)
+        else:
+            k_all, v_all, geo = m5[:, :, :, c.qpg], m5[:, :, :, c.qpg + 1], {}
+        x1 = ops.rmsnorm(h, lp["ln1"], c.eps)
+        x2 = ops.rmsnorm(keep["h_mid"], lp["ln2"], c.eps)
+        return dict(x1=x1, qkv=qkv, q5=m5[:, :, :, : c.qpg], k_all=k_all, v_all=v_all, geo=geo, ctx=keep["ctx"], lse=keep["lse"],
+                    h_mid=keep["h_mid"], x2=x2, y=keep["y"], act=ops.swiglu(keep["y"]))
+
     def _gather_kv(self, kv_local):
         c = self.m.cfg
         cp, r = mpu.get_context_parallel_world_size(), mpu.get_context_parallel_rank()
@@ -118,12 +154,13 @@ class TrainStep:
         geo = dict(chunk_len=ch, q_chunk_gid=mpu.zigzag_chunk_ids(cp, r), kv_chunk_gid=kv_gid, kv_chunk_row=kv_row)
         return rows.unsqueeze(0), rows[s_l:].unsqueeze(0), geo
 
-    def _layer_backward(self, dh, h, lp, cos, sin, g):
-        """dh = dL/d(layer output) [s, hidden]; returns dL/d(layer input); fills g (this layer's grads)."""
+    def _layer_backward(self, dh, h, lp, cos, sin, g, keep=None):
+        """dh = dL/d(layer output) [s, hidden]; returns dL/d(layer input); fills g (this layer's grads).
+        keep = the activations _layer_forward_keep stored, or None for a layer of the recompute block."""
         c = self.m.cfg
         s = h.shape[0]
         cp = mpu.get_context_parallel_world_size()
-        a = self._layer_recompute(h, lp, cos, sin)
+        a = self._layer_recompute(h, lp, cos, sin) if keep is None else self._rebuild(h, lp, keep)
         f32 = lambda n: torch.zeros(n, dtype=torch.float32, device=h.device)  # noqa: E731
         # ---- MLP: out = h_mid + fc2(swiglu(fc1(norm2(h_mid)))) ------------------------------------
         dh_t = _t(dh)
@@ -223,10 +260,18 @@ class TrainStep:
         h = m.embedding(tok, None, external_feature_dict=efd).view(s, c.hidden)
         cos, sin = m.rotary_pos_emb(s * cp)
         ws = m._workspace(s, h.device)
-        saved = []
-        for lp in m.p["layers"]:
-            saved.append(h.clone())
-            m.decoder_layer(h, lp, cos, sin, ws)
+        saved, kept = [], []
+        n_layers = len(m.p["layers"])
+        n_rec = n_layers if self.recompute_num_layers is None else max(0, min(n_layers, int(self.recompute_num_layers)))
+        for li, lp in enumerate(m.p["layers"]):
+            if li < n_rec:                                   # recompute block: keep the input only, fused fast path
+                saved.append(h.clone())
+                kept.append(None)
+                m.decoder_layer(h, lp, cos, sin, ws)
+            else:                                            # activations stay in HBM: no second forward for this layer
+                saved.append(h)
+                h, keep = self._layer_forward_keep(h, lp, cos, sin)
+                kept.append(keep)
         idx = ops.mask_to_index(logit_mask.transpose(0, 1).reshape(-1))
         n_sel = idx.numel()
         rows = ops.row_gather(h, idx)
@@ -271,8 +316,9 @@ class TrainStep:
         dh = torch.zeros(s, c.hidden, dtype=h.dtype, device=h.device)
         ops.row_scatter_(dh, idx, d_rows)                                # zeros.masked_scatter (layers.py:451)
         for li in range(len(m.p["layers"]) - 1, -1, -1):
-            dh = self._layer_backward(dh, saved[li], m.p["layers"][li], cos, sin, grads["layers"][li])
+            dh = self._layer_backward(dh, saved[li], m.p["layers"][li], cos, sin, grads["layers"][li], kept[li])
             saved[li] = None
+            kept[li] = None
         # ---- embedding / visual-token scatter backward ---------------------------------------------
         tok_idx = tok.reshape(-1).clone()
         d_embed = torch.zeros(m.p["embed"].shape, dtype=torch.float32, device=h.device)

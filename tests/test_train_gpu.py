@@ -407,3 +407,39 @@ def test_prefill_tensor_parallel(amd, monkeypatch):
     outs = _run_grid(2, 1, rank_fn, amd, monkeypatch)
     assert torch.equal(outs[(0, 0)], outs[(0, 1)]) and outs[(0, 0)].shape == single.shape
     assert rel_l2(outs[(0, 0)], single) < 1.5e-2
+
+
+@pytest.mark.parametrize("n_rec,cp", [(0, 1), (1, 1), (0, 2)])
+def test_train_step_selective_recompute_equals_full_recompute(amd, monkeypatch, n_rec, cp):
+    """`--recompute-method block --recompute-num-layers N` (stage 3 passes 20 of 48): layers outside the recompute block keep their
+    activations instead of being re-run in the backward.  Same kernels on the same values either way, so the loss and every
+    gradient must equal the full-recompute step's bit for bit (CP = 2: the kept layers re-gather their rotated K / V)."""
+    S = 1024
+    ocfg = ollm.LLMConfig(**SMALL)
+    p = ollm.init_llm_params(ocfg, seed=9)
+    tokens, labels, loss_mask = _data(S, SMALL["vocab"], 150, 16)
+    G = amd["gpt"]
+    base = G.GPTVLModel.from_oracle_layout(G.GPTConfig(**SMALL), p, None, DEV)
+
+    def run(rec):
+        def rank_fn(r):
+            m = G.GPTVLModel(base.cfg, base.p)
+            loss, g = amd["train"].TrainStep(m, recompute_num_layers=rec).forward_backward(tokens.to(DEV), labels.to(DEV),
+                                                                                           loss_mask.to(DEV))
+            if cp > 1:
+                amd["train"].allreduce_grads(g)
+            return loss, g
+        return _run_ranks(cp, rank_fn, amd, monkeypatch)[0] if cp > 1 else rank_fn(0)
+
+    loss_full, g_full = run(None)
+    loss_sel, g_sel = run(n_rec)
+    # the kept layers' forward is the kernel-by-kernel one (the backward needs gate / up), the recompute block's the fused fast path:
+    # same rounding chains, different fp32 summation order inside the GEMM epilogues -> equal to within bf16 rounding noise
+    assert abs(float(loss_full) - float(loss_sel)) < 1e-3 * abs(float(loss_full))
+    worst = 0.0
+    for k in ("embed", "lm_head", "final_ln"):
+        worst = max(worst, rel_l2(g_sel[k], g_full[k]))
+    for lf, ls in zip(g_full["layers"], g_sel["layers"]):
+        for k in lf:
+            worst = max(worst, rel_l2(ls[k], lf[k]))
+    assert worst < 1e-2, worst

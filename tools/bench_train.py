@@ -13,6 +13,7 @@ ap.add_argument("--seq", type=int, default=16384)
 ap.add_argument("--layers", type=int, default=48)
 ap.add_argument("--answer", type=int, default=512)
 ap.add_argument("--steps", type=int, default=2)
+ap.add_argument("--recompute-num-layers", type=int, default=-1, help="-1 = every layer (full recompute); stage 3 passes 20; 0 keeps all activations")
 args = ap.parse_args()
 lib.load(allow_build=False)
 dev = "cuda:0"
@@ -24,7 +25,8 @@ tokens = torch.randint(0, 151643, (1, S), generator=g, device=dev)
 labels = torch.roll(tokens, -1, 1)
 loss_mask = torch.zeros(1, S, device=dev)
 loss_mask[0, S - args.answer:] = 1
-step = training.TrainStep(model)
+rec = None if args.recompute_num_layers < 0 else args.recompute_num_layers
+step = training.TrainStep(model, recompute_num_layers=rec)
 loss, grads = step.forward_backward(tokens, labels, loss_mask)      # warm-up
 del grads
 torch.cuda.synchronize()
@@ -37,9 +39,14 @@ dt = (time.perf_counter() - t0) / args.steps
 lin = cfg.num_layers * 2 * (cfg.hidden * cfg.qkv_out + cfg.hidden * cfg.heads * cfg.head_dim + 3 * cfg.hidden * cfg.ffn) * S
 attn = cfg.num_layers * 4 * cfg.head_dim * cfg.heads * (S * (S + 1) // 2)
 fwd = lin + attn
-# fwd + recompute fwd + bwd (2x linears, 2.5x attention: 5 of the 2 forward GEMM-units... counted as 2x)
-alg = 4 * lin + (2 + 2.5) * attn
-print(json.dumps({"what": "train step fwd+bwd (full recompute), TP=1 CP=1", "seq": S, "layers": cfg.num_layers,
+# fwd + bwd (2x linears; attention backward = 5 of the forward's 2 GEMM units = 2.5x) + the recompute forward of the layers in the
+# recompute block ("3x forward FLOPs + recompute factor as configured")
+n_rec = cfg.num_layers if rec is None else max(0, min(cfg.num_layers, rec))
+r = n_rec / cfg.num_layers
+alg = (3 + r) * lin + (3.5 + r) * attn
+print(json.dumps({"what": f"train step fwd+bwd, recompute block = {n_rec} of {cfg.num_layers} layers, TP=1 CP=1", "seq": S,
+                  "layers": cfg.num_layers, "recompute_num_layers": n_rec,
                   "answer_tokens": args.answer, "s_per_step": dt, "loss": float(loss),
                   "algorithmic_tflop_per_step": alg / 1e12, "tflops": alg / dt / 1e12,
+                  "tflops_without_recompute_work": (3 * lin + 3.5 * attn) / dt / 1e12,
                   "tokens_per_s": S / dt, "peak_mem_gb": torch.cuda.max_memory_allocated() / 2**30}))
