@@ -357,6 +357,16 @@ typedef struct {
 
 int vita_flash_attn_bwd(const vita_attn_bwd_params* p, void* stream);
 
+/* Merge of two attention partials over DISJOINT key sets (their natural-log lse from vita_flash_attn_fwd), in place into the first:
+ *   lse = log(exp(lse_a) + exp(lse_b)),  O_a = O_a exp(lse_a - lse) + O_b exp(lse_b - lse)      (a part that saw no key: lse = -inf).
+ * o_a / o_b [rows, heads, 128] bf16 with row / head strides in elements, lse_a / lse_b [heads, rows] fp32.
+ * Context parallelism: a rank attends to its own zig-zag chunks while the K/V all-gather of the first kv-head split is in flight,
+ * then to the remote chunks, and merges — replaces the "local block first" step of TransformerEngine's AttnFuncWithCP ring
+ * (reached from M/core/models/gpt/gpt_layer_specs.py:40); SURVEY.md 8(e). */
+int vita_attn_merge(void* o_a, int64_t oa_row_stride, int64_t oa_head_stride, float* lse_a, const void* o_b,
+                    int64_t ob_row_stride, int64_t ob_head_stride, const float* lse_b, int64_t rows, int heads, int head_dim,
+                    void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Single-token decode against a sequence-sharded KV cache.
  * The decode loop M/inference/text_generation/generation.py:123-205 with --use-kv-cache feeds

@@ -494,6 +494,52 @@ extern "C" int vita_debug_attn_timing(unsigned long long* host_out16, int reset)
   return VITA_OK;
 }
 
+// ---- merge of two attention partials over disjoint key sets (context parallelism: own chunks first, remote chunks after the gather)
+//   lse = log(exp(lse_a) + exp(lse_b)),  O = O_a exp(lse_a - lse) + O_b exp(lse_b - lse);  a part that saw no key has lse = -inf.
+// HBM-bound: one thread per (row, head, 16-byte piece of d = 128); O_a / lse_a are updated in place.
+namespace {
+__global__ __launch_bounds__(256) void attn_merge_kernel(bf16_t* __restrict__ oa, int64_t oa_rs, int64_t oa_hs, float* __restrict__ lse_a,
+                                                         const bf16_t* __restrict__ ob, int64_t ob_rs, int64_t ob_hs,
+                                                         const float* __restrict__ lse_b, int64_t rows, int heads) {
+  const int64_t idx = (int64_t)blockIdx.x * 256 + threadIdx.x;
+  const int piece = (int)(idx & 15);
+  const int64_t rh = idx >> 4;
+  if (rh >= rows * heads) return;
+  const int64_t row = rh / heads;
+  const int h = (int)(rh % heads);
+  const float la = lse_a[(int64_t)h * rows + row], lb = lse_b[(int64_t)h * rows + row];
+  const float mx = fmaxf(la, lb);
+  float wa = 1.f, wb = 0.f, l = la;
+  if (mx > -INFINITY) {
+    const float ea = __expf(la - mx), eb = __expf(lb - mx);
+    const float inv = 1.0f / (ea + eb);
+    wa = ea * inv; wb = eb * inv;
+    l = mx + __logf(ea + eb);
+  }
+  u32x4* pa = reinterpret_cast<u32x4*>(oa + row * oa_rs + (int64_t)h * oa_hs + piece * 8);
+  const u32x4 a = *pa, bq = *reinterpret_cast<const u32x4*>(ob + row * ob_rs + (int64_t)h * ob_hs + piece * 8);
+  u32x4 r;
+#pragma unroll
+  for (int j = 0; j < 4; ++j)
+    r[j] = pack_bf16x2(bf16lo_to_f32(a[j]) * wa + bf16lo_to_f32(bq[j]) * wb, bf16hi_to_f32(a[j]) * wa + bf16hi_to_f32(bq[j]) * wb);
+  *pa = r;
+  if (piece == 0) lse_a[(int64_t)h * rows + row] = l;
+}
+}  // namespace
+
+extern "C" int vita_attn_merge(void* o_a, int64_t oa_row_stride, int64_t oa_head_stride, float* lse_a, const void* o_b,
+                               int64_t ob_row_stride, int64_t ob_head_stride, const float* lse_b, int64_t rows, int heads,
+                               int head_dim, void* stream) {
+  if (!o_a || !o_b || !lse_a || !lse_b || rows < 0 || heads <= 0) return VITA_ERR_INVALID_ARG;
+  if (head_dim != 128) return VITA_ERR_UNSUPPORTED;
+  if ((oa_row_stride & 7) || (oa_head_stride & 7) || (ob_row_stride & 7) || (ob_head_stride & 7)) return VITA_ERR_UNSUPPORTED;
+  if (rows == 0) return VITA_OK;
+  const int64_t n = rows * heads * 16;
+  hipLaunchKernelGGL(attn_merge_kernel, dim3((unsigned)((n + 255) / 256)), dim3(256), 0, (hipStream_t)stream, (bf16_t*)o_a, oa_row_stride,
+                     oa_head_stride, lse_a, (const bf16_t*)o_b, ob_row_stride, ob_head_stride, lse_b, rows, heads);
+  return vita_check_launch();
+}
+
 extern "C" int vita_flash_attn_fwd(const vita_attn_params* p, void* stream) {
   if (!p || !p->q || !p->k || !p->v || !p->o) return VITA_ERR_INVALID_ARG;
   if (p->batch <= 0 || p->n_q_heads <= 0 || p->n_kv_heads <= 0 || p->chunk_len <= 0 ||

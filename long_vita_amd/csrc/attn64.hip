@@ -194,6 +194,20 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
     const int gk = p.kv_gid[c];
     n_tiles += gk < gq ? tiles_per_chunk : (gk > gq ? 0 : q_off_wg / KVT + 4);
   }
+  if (n_tiles == 0) {
+    // a launch over REMOTE chunks only (context parallelism: the rank's own chunks are attended to before the gather lands,
+    // dot_product_attention.forward_cp): these rows see none of them -> O = 0, lse = -inf, the merge ignores this part
+    const u32x2 z = {0u, 0u};
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int64_t orow = (int64_t)qc * p.chunk_len + q_off + 32 * qb + l31;
+      bf16_t* op = p.o + (int64_t)b * p.o_bs + orow * p.o_rs + (int64_t)kvh * p.o_gs + (int64_t)hq * p.o_hs;
+#pragma unroll
+      for (int i = 0; i < 16; ++i) *reinterpret_cast<u32x2*>(op + 8 * i + 4 * hi) = z;
+      if (p.lse && hi == 0) p.lse[((int64_t)b * p.n_q_heads + head) * p.n_q_rows + orow] = -INFINITY;
+    }
+    return;
+  }
 
   // ---- state ----------------------------------------------------------------------------------------------------------
   f32x16 o[2][4];                                    // O^T[qb][db]: d = 32 db + (r & 3) + 8 (r >> 2) + 4 hi, row 32 qb + l31 (AGPRs)
@@ -420,11 +434,7 @@ bool vita_attn64_eligible(const AttnArgs& a, int head_dim, bool causal) {
   if (a.chunk_len % QTILE || a.q_valid != a.chunk_len || a.kv_valid != a.chunk_len) return false;
   // a tile's 64 rows x row stride must fit the 32-bit lane offset of the DMA
   if (a.k_rs * 2 * KVT >= (1ll << 31) || a.v_rs * 2 * KVT >= (1ll << 31)) return false;
-  for (int i = 0; i < a.n_q_chunks; ++i) {           // the pipeline is primed with >= 4 tiles: every query chunk needs its diagonal
-    bool found = false;
-    for (int j = 0; j < a.n_kv_chunks; ++j) found = found || a.kv_gid[j] == a.q_gid[i];
-    if (!found) return false;
-  }
+  // (a query chunk sees whole chunks, its own up to the diagonal, or nothing: the tile count is 0 or a multiple of 4)
   const char* e = getenv("VITA_ATTN64");
   return !(e && e[0] == '0');
 }

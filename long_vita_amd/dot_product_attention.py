@@ -64,6 +64,9 @@ class DotProductAttention:
         self.causal = causal
         self.softmax_scale = softmax_scale
         self._kv_gather = None
+        self._o_remote = None
+        # own chunks first, remote chunks after gather 0 has landed (VITA_CP_LOCAL_FIRST=0: everything waits for gather 0)
+        self.local_first = bool(int(os.environ.get("VITA_CP_LOCAL_FIRST", "1")))
         self._streams = []
         self.split_streams = bool(int(os.environ.get("VITA_CP_STREAMS", "1")))
 
@@ -135,12 +138,31 @@ class DotProductAttention:
             with torch.cuda.stream(stream):
                 if stream is not main:
                     stream.wait_event(ready)
-                if works[j] is not None:
-                    works[j].wait()                                 # this stream waits for gather j only
                 rows = gathered[j].view(cp * 2 * s_l, hg, d)        # K rows of rank p at p*2*s_l, V at +s_l
-                ops.flash_attn(q5[:, :, j * hg:(j + 1) * hg], rows.unsqueeze(0), rows[s_l:].unsqueeze(0), causal=True,
-                               softmax_scale=self.softmax_scale, chunk_len=c, q_chunk_gid=mpu.zigzag_chunk_ids(cp, r),
-                               kv_chunk_gid=kv_gid, kv_chunk_row=kv_row, out=out[:, :, j * hg * qpg:(j + 1) * hg * qpg])
+                qj, oj = q5[:, :, j * hg:(j + 1) * hg], out[:, :, j * hg * qpg:(j + 1) * hg * qpg]
+                own = mpu.zigzag_chunk_ids(cp, r)
+                if j == 0 and cp > 1 and self.local_first:
+                    # Gathers 1.. run under the attention of the split before them; gather 0 has nothing in front of it.  The rank's
+                    # OWN two chunks need no remote K / V: attend to them (straight from the packed send buffer) while gather 0
+                    # is in flight, then to the remote chunks, and merge the two partials (TE's ring does its
+                    # local block first for the same reason).
+                    _, lse_a = ops.flash_attn(qj, kv_local[0, 0].unsqueeze(0), kv_local[0, 1].unsqueeze(0), causal=True,
+                                              softmax_scale=self.softmax_scale, chunk_len=c, q_chunk_gid=own, kv_chunk_gid=own,
+                                              kv_chunk_row=[0, c], out=oj, return_lse=True)
+                    if works[j] is not None:
+                        works[j].wait()
+                    rem = [i for i in range(2 * cp) if i // 2 != r]
+                    o_b = self._remote_buffer(oj)
+                    _, lse_b = ops.flash_attn(qj, rows.unsqueeze(0), rows[s_l:].unsqueeze(0), causal=True,
+                                              softmax_scale=self.softmax_scale, chunk_len=c, q_chunk_gid=own,
+                                              kv_chunk_gid=[kv_gid[i] for i in rem], kv_chunk_row=[kv_row[i] for i in rem], out=o_b,
+                                              return_lse=True)
+                    ops.attn_merge_(oj, lse_a, o_b, lse_b)
+                else:
+                    if works[j] is not None:
+                        works[j].wait()                             # this stream waits for gather j only
+                    ops.flash_attn(qj, rows.unsqueeze(0), rows[s_l:].unsqueeze(0), causal=True, softmax_scale=self.softmax_scale,
+                                   chunk_len=c, q_chunk_gid=own, kv_chunk_gid=kv_gid, kv_chunk_row=kv_row, out=oj)
                 if stream is not main:
                     ev = torch.cuda.Event()
                     ev.record(stream)
@@ -150,6 +172,12 @@ class DotProductAttention:
         if events:
             events[1].record()
         return out
+
+    def _remote_buffer(self, like: torch.Tensor) -> torch.Tensor:
+        shape = tuple(like.shape)
+        if self._o_remote is None or tuple(self._o_remote.shape) != shape or self._o_remote.device != like.device:
+            self._o_remote = torch.empty(shape, dtype=like.dtype, device=like.device)
+        return self._o_remote
 
     def _side_streams(self, n: int, device):
         if len(self._streams) < n:

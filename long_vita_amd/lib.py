@@ -21,7 +21,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libvita_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "vita_hip.h")
 
-ABI_VERSION = 11
+ABI_VERSION = 12
 VITA_OK = 0
 VITA_ERR_INVALID_ARG = -1
 VITA_ERR_UNSUPPORTED = -2
@@ -158,6 +158,7 @@ PROTOTYPES = {
     "vita_row_scatter_add_f32": (_i, [_p, _p, _p, _l, _l, _i, _p, _p]),
     "vita_attn_delta": (_i, [_p, _p, _p, _l, _i, _i, _l, _l, _l, _l, _p]),
     "vita_flash_attn_bwd": (_i, [C.POINTER(AttnBwdParams), _p]),
+    "vita_attn_merge": (_i, [_p, _l, _l, _p, _p, _l, _l, _p, _l, _i, _i, _p]),
     "vita_gemv_bf16": (_i, [_p, _p, _l, _p, _l, _l, _i, _p, _p, _p]),
     "vita_decode_attn_partial": (_i, [_p, _l, _l, _p, _p, _l, _l, _i, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p]),
     "vita_add_bf16": (_i, [_p, _p, _p, _l, _p]),

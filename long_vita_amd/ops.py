@@ -331,6 +331,20 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, causal: boo
     return (o, lse) if return_lse else o
 
 
+def attn_merge_(o_a: torch.Tensor, lse_a: torch.Tensor, o_b: torch.Tensor, lse_b: torch.Tensor) -> torch.Tensor:
+    """In place: o_a, lse_a <- the attention over the union of the two DISJOINT key sets the partials (o_a, lse_a) and (o_b, lse_b) saw.
+    o [1, S, H, 128] bf16 views (any row / head stride), lse [1, H, S] fp32 contiguous (natural log, -inf = no key seen)."""
+    _, S, H, D = o_a.shape
+    if o_b.shape != o_a.shape or lse_a.shape != (1, H, S) or lse_b.shape != (1, H, S):
+        raise ValueError("attn_merge_: o [1, S, H, D] and lse [1, H, S] of both parts must agree")
+    if not (lse_a.is_contiguous() and lse_b.is_contiguous()) or o_a.stride(3) != 1 or o_b.stride(3) != 1:
+        raise ValueError("attn_merge_: contiguous lse, unit inner stride of o")
+    _L.check(_L.load().vita_attn_merge(_dev(o_a, "o_a", BF16), o_a.stride(1), o_a.stride(2), _dev(lse_a, "lse_a", torch.float32),
+                                       _dev(o_b, "o_b", BF16), o_b.stride(1), o_b.stride(2), _dev(lse_b, "lse_b", torch.float32),
+                                       S, H, D, _stream()), "vita_attn_merge")
+    return o_a
+
+
 # ------------------------------------------------------------------------------------------------
 # ViT helpers
 # ------------------------------------------------------------------------------------------------

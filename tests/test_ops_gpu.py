@@ -488,3 +488,35 @@ def test_cp_attention_through_the_c_abi_on_one_real_rccl_rank(ops):
         assert h.vita_cp_attn_fwd(ctx, C.byref(bad), st) == L.VITA_ERR_INVALID_ARG
     finally:
         L.check(h.vita_cp_destroy(ctx), "vita_cp_destroy")
+
+
+def test_attention_over_own_chunks_then_remote_chunks_merged_equals_one_launch(ops):
+    """What dot_product_attention.forward_cp does for the first kv-head split (the rank's own zig-zag chunks are attended
+    to while the K/V all-gather is in flight): a launch over the own chunks, a launch over the remote chunks only — a geometry without
+    a diagonal chunk, where the rows of the rank's FIRST chunk may see nothing at all (lse = -inf) — and vita_attn_merge of the two
+    partials == one launch over every chunk (and == the fp32 oracle)."""
+    cp, hg, G, D, C = 4, 2, 5, 128, 512
+    s_l, S = 2 * C, 2 * cp * C
+    for r in (0, 2, 3):                                      # rank 0: its chunk 0 sees no remote key
+        q = (torch.randn(1, s_l, hg * G, D, generator=g(300 + r)) * 0.5).bfloat16().to(DEV)
+        rows = torch.randn(cp * 2 * s_l, hg, D, generator=g(310 + r)).bfloat16().to(DEV)       # [rank p][K | V][s_l][hg][d]
+        own = [r, 2 * cp - 1 - r]
+        kv_gid, kv_row = [], []
+        for p in range(cp):
+            kv_gid += [p, 2 * cp - 1 - p]
+            kv_row += [p * 2 * s_l, p * 2 * s_l + C]
+        k_all, v_all = rows.unsqueeze(0), rows[s_l:].unsqueeze(0)
+        whole, lse_w = ops.flash_attn(q, k_all, v_all, causal=True, chunk_len=C, q_chunk_gid=own, kv_chunk_gid=kv_gid,
+                                      kv_chunk_row=kv_row, return_lse=True)
+        loc = [i for i in range(2 * cp) if i // 2 == r]
+        rem = [i for i in range(2 * cp) if i // 2 != r]
+        o_a, lse_a = ops.flash_attn(q, k_all, v_all, causal=True, chunk_len=C, q_chunk_gid=own, kv_chunk_gid=[kv_gid[i] for i in loc],
+                                    kv_chunk_row=[kv_row[i] for i in loc], return_lse=True)
+        o_b, lse_b = ops.flash_attn(q, k_all, v_all, causal=True, chunk_len=C, q_chunk_gid=own, kv_chunk_gid=[kv_gid[i] for i in rem],
+                                    kv_chunk_row=[kv_row[i] for i in rem], return_lse=True)
+        if r == 0:
+            assert torch.isinf(lse_b[0, :, :C]).all() and float(o_b[0, :C].abs().max()) == 0.0       # nothing remote is visible
+        ops.attn_merge_(o_a, lse_a, o_b, lse_b)
+        assert rel_l2(o_a, whole) < 4e-3, (r, rel_l2(o_a, whole))                                    # two bf16 roundings instead of one
+        assert float((lse_a - lse_w).abs().max()) < 2e-3
+        assert torch.isfinite(o_a.float()).all()
