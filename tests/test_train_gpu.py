@@ -356,10 +356,11 @@ def _run_grid(tp, cp, fn, amd, monkeypatch):
     return results
 
 
-@pytest.mark.parametrize("tp,cp", [(2, 1), (2, 2)])
-def test_train_step_tensor_parallel(amd, monkeypatch, tp, cp):
+@pytest.mark.parametrize("tp,cp,n_rec", [(2, 1, None), (2, 2, None), (2, 1, 1), (2, 2, 0)])
+def test_train_step_tensor_parallel(amd, monkeypatch, tp, cp, n_rec):
     """TP = 2 (x CP = 2): column / row-parallel shards, bf16 all-reduce of the row-parallel outputs and of the
-    column-parallel input gradients, vocab-parallel head with gathered logits == autograd over the unsharded model."""
+    column-parallel input gradients, vocab-parallel head with gathered logits == autograd over the unsharded model.
+    n_rec: --recompute-num-layers (None = every layer re-run in the backward, 1 = the second layer keeps its activations)."""
     from long_vita_amd import tensor_parallel as tpar
     S = 1024
     ocfg = ollm.LLMConfig(**SMALL)
@@ -372,7 +373,8 @@ def test_train_step_tensor_parallel(amd, monkeypatch, tp, cp):
     def rank_fn(ci, ti):
         shard, cfg_l = tpar.shard_llm_params(p, full_cfg, tp, ti)
         m = G.GPTVLModel.from_oracle_layout(cfg_l, shard, None, DEV)
-        loss, g = amd["train"].TrainStep(m).forward_backward(tokens.to(DEV), labels.to(DEV), loss_mask.to(DEV))
+        loss, g = amd["train"].TrainStep(m, recompute_num_layers=n_rec).forward_backward(tokens.to(DEV), labels.to(DEV),
+                                                                                          loss_mask.to(DEV))
         amd["train"].allreduce_grads(g)                       # over the CP group
         return loss, g
 
