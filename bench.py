@@ -241,7 +241,9 @@ def main():
                    "weights": "seeded random bf16 (N(0,0.02))",
                    "algorithmic_gflop_per_token": fpt / 1e9,
                    "end_to_end_tflops_per_gpu": fpt * value / world / 1e12,
-                   "end_to_end_frac_of_mfma_peak": fpt * value / world / 1e12 / MFMA_BF16_PEAK_TFLOPS},
+                   "end_to_end_frac_of_mfma_peak": fpt * value / world / 1e12 / MFMA_BF16_PEAK_TFLOPS,
+                   # measured on rank 0, to set against the byte model of DESIGN.md 6.1 (weights + workspace + frames)
+                   "peak_hbm_gb_rank0": torch.cuda.max_memory_allocated() / 2 ** 30},
         "roofline": {"bound": "mfma", "kernel": "flash_fwd64_kernel (d = 128, causal; 4 waves x 64 rows)" if os.environ.get("VITA_ATTN64", "1") != "0" else "flash_fwd_kernel<128, causal>", "achieved": achieved,
                      "peak": MFMA_BF16_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / MFMA_BF16_PEAK_TFLOPS,
                      "traffic": traffic, "traffic_source": traffic_src, "launches_timed": len(ev_ms), "ms_per_launch": attn_ms,
