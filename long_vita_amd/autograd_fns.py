@@ -154,6 +154,25 @@ class ReduceScatterToSP(torch.autograd.Function):
         return _gather_sequence(g, ctx.tp, ctx.group)
 
 
+class ScatterToSP(torch.autograd.Function):
+    """scatter_to_sequence_parallel_region (language_model_embedding.py:157-160): this rank's s / TP rows forward, ALL-GATHER along the
+    sequence backward — every tensor-parallel rank needs dL/d(embeddings) of the whole sequence: its vocabulary rows may be hit
+    by tokens of any shard, and the replicated projector must see the same feature gradient on every rank."""
+
+    @staticmethod
+    def forward(ctx, x):
+        tp, group = ctx.tp, ctx.group = _tp()
+        if tp == 1:
+            return x
+        n = x.shape[0] // tp
+        r = mpu.get_tensor_model_parallel_rank()
+        return x[r * n:(r + 1) * n].contiguous()
+
+    @staticmethod
+    def backward(ctx, g):
+        return _gather_sequence(g, ctx.tp, ctx.group)
+
+
 class CopyToTP(torch.autograd.Function):
     """copy_to_tensor_model_parallel_region: identity forward, all-reduce backward (ColumnParallelLinear.forward :872)."""
 
@@ -253,23 +272,89 @@ class RopeFn(torch.autograd.Function):
 
 
 # ------------------------------------------------------------------------------------------------
-# core attention (CP = 1; causal, d = 128: vita_flash_attn_fwd / vita_flash_attn_bwd)
+# core attention (vita_flash_attn_fwd / vita_flash_attn_bwd)
 # ------------------------------------------------------------------------------------------------
 class FlashAttnFn(torch.autograd.Function):
-    """q [1, S, Hq, D], k / v [1, S, Hkv, D] -> [1, S, Hq, D]."""
+    """CP = 1.  q [1, S, Hq, D], k / v [1, S, Hkv, D] -> [1, S, Hq, D]; seg_start / seg_end int32 [S] | None: packed samples
+    (position ids with resets; _flash_attention_forward(position_ids=...), M/core/transformer/dot_product_attention.py:374-390)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, softmax_scale):
-        o, lse = ops.flash_attn(q, k, v, causal=True, softmax_scale=softmax_scale, return_lse=True)
-        ctx.save_for_backward(q, k, v, o, lse)
+    def forward(ctx, q, k, v, softmax_scale, causal=True, seg_start=None, seg_end=None):
+        if not causal:
+            raise NotImplementedError("the non-causal (ViT) attention backward goes through FlashAttnNonCausalFn")
+        o, lse = ops.flash_attn(q, k, v, causal=True, softmax_scale=softmax_scale, return_lse=True, seg_start=seg_start)
+        ctx.save_for_backward(q, k, v, o, lse, seg_start, seg_end)
         ctx.softmax_scale = softmax_scale
         return o
 
     @staticmethod
     def backward(ctx, d_o):
+        q, k, v, o, lse, seg_start, seg_end = ctx.saved_tensors
+        dq, dk, dv = ops.flash_attn_bwd(q, k, v, o, d_o.contiguous(), lse, softmax_scale=ctx.softmax_scale,
+                                        seg_start=seg_start, seg_end=seg_end)
+        return dq, dk, dv, None, None, None, None
+
+
+def zigzag_geometry(cp: int, rank: int, s_l: int) -> dict:
+    """Chunk tables of the rank-ordered gathered K / V buffer [CP][2][S_l] rows (K rows of rank p at p * 2 * S_l, V at + S_l):
+    chunk 2p + h of the buffer is global chunk (h ? 2CP - 1 - p : p) (M/training/utils.py:329-341)."""
+    c = s_l // 2
+    kv_gid, kv_row = [], []
+    for p in range(cp):
+        kv_gid += [p, 2 * cp - 1 - p]
+        kv_row += [p * 2 * s_l, p * 2 * s_l + c]
+    return dict(chunk_len=c, q_chunk_gid=mpu.zigzag_chunk_ids(cp, rank), kv_chunk_gid=kv_gid, kv_chunk_row=kv_row)
+
+
+class FlashAttnCPFn(torch.autograd.Function):
+    """Context-parallel causal attention as ONE autograd node — what TransformerEngine's AttnFuncWithCP is to the reference's TE
+    layer spec (M/core/models/gpt/gpt_layer_specs.py:40; every long-context script trains with CP, stage3 .sh:125,145).
+
+    q [1, S_l, Hq, D], k / v [1, S_l, Hkv, D]: the rank's two zig-zag chunks (rotated).  Forward =
+    dot_product_attention.DotProductAttention.forward_cp (K / V all-gather per kv-head split over the CP group, own chunks first,
+    chunk-table kernel) keeping O and the log-sum-exp over ALL keys.  Backward = K / V re-gathered (one message; keeping the
+    gathered copy alive per layer would cost CP x the local K / V), vita_flash_attn_bwd writing dK / dV of every visible key in
+    the gathered layout, ONE reduce-scatter returning each rank the sum for its own rows — the same two collectives
+    training.TrainStep issues, instead of TE's CP - 1 P2P ring steps in each direction."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, impl):
+        cp, r, group = mpu.get_context_parallel_world_size(), mpu.get_context_parallel_rank(), mpu.get_context_parallel_group()
+        _, s_l, hq, d = q.shape
+        hkv = k.shape[2]
+        if s_l % 2:
+            raise ValueError("local sequence must hold two zig-zag chunks")
+        n_split = 4 if hkv % 4 == 0 else (2 if hkv % 2 == 0 else 1)      # gather j + 1 runs under the attention of split j
+        hg = hkv // n_split
+        kv_local = torch.empty(n_split, 2, s_l, hg, d, dtype=q.dtype, device=q.device)
+        kv_local[:, 0].copy_(k[0].reshape(s_l, n_split, hg, d).permute(1, 0, 2, 3))
+        kv_local[:, 1].copy_(v[0].reshape(s_l, n_split, hg, d).permute(1, 0, 2, 3))
+        lse = torch.empty(1, hq, s_l, dtype=torch.float32, device=q.device)
+        o = torch.empty(1, s_l, hq, d, dtype=q.dtype, device=q.device)
+        impl.forward_cp(q.reshape(1, s_l, hkv, hq // hkv, d), kv_local, out=o, lse=lse)
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.cp, ctx.rank, ctx.group, ctx.softmax_scale = cp, r, group, impl.softmax_scale   # the backward runs on autograd's thread
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
         q, k, v, o, lse = ctx.saved_tensors
-        dq, dk, dv = ops.flash_attn_bwd(q, k, v, o, d_o.contiguous(), lse, softmax_scale=ctx.softmax_scale)
-        return dq, dk, dv, None
+        cp, r, group = ctx.cp, ctx.rank, ctx.group
+        _, s_l, hq, d = q.shape
+        hkv = k.shape[2]
+        kv_local = torch.stack([k[0], v[0]]).contiguous()                                   # [2, S_l, Hkv, D]
+        gathered = torch.empty(cp * kv_local.numel(), dtype=kv_local.dtype, device=kv_local.device)
+        dist.all_gather_into_tensor(gathered, kv_local.view(-1), group=group)
+        rows = gathered.view(cp * 2 * s_l, hkv, d)
+        d_rows = torch.empty_like(rows)                                                     # dK rows of rank p at p * 2 * S_l, dV at + S_l
+        dq = torch.empty(q.shape, dtype=q.dtype, device=q.device)
+        ops.flash_attn_bwd(q, rows.unsqueeze(0), rows[s_l:].unsqueeze(0), o, d_o.contiguous(), lse, dq5=dq,
+                           dk=d_rows.unsqueeze(0), dv=d_rows[s_l:].unsqueeze(0), softmax_scale=ctx.softmax_scale,
+                           **zigzag_geometry(cp, r, s_l))
+        dkv = torch.empty(kv_local.numel(), dtype=kv_local.dtype, device=kv_local.device)
+        dist.reduce_scatter_tensor(dkv, d_rows.view(-1), group=group)
+        dkv = dkv.view(2, 1, s_l, hkv, d)
+        return dq, dkv[0], dkv[1], None
 
 
 # ------------------------------------------------------------------------------------------------

@@ -458,7 +458,7 @@ int launch_attn_v(const AttnArgs& a, int64_t nblocks, hipStream_t st) {
 // VITA_ATTN_VARIANT (developer tuning aid): bits 0-3 = kernel VARIANT (default 6 = LDS-DMA + QK_AHEAD 3), bit 4 = phase timers.
 inline int attn_variant() {
   static const int v = [] {
-    const char* e = getenv("VITA_ATTN_VARIANT");
+    const char* e = vita_dev_getenv("VITA_ATTN_VARIANT");
     return e ? atoi(e) : 6;
   }();
   return v;

@@ -435,7 +435,7 @@ bool vita_attn64_eligible(const AttnArgs& a, int head_dim, bool causal) {
   // a tile's 64 rows x row stride must fit the 32-bit lane offset of the DMA
   if (a.k_rs * 2 * KVT >= (1ll << 31) || a.v_rs * 2 * KVT >= (1ll << 31)) return false;
   // (a query chunk sees whole chunks, its own up to the diagonal, or nothing: the tile count is 0 or a multiple of 4)
-  const char* e = getenv("VITA_ATTN64");
+  const char* e = vita_dev_getenv("VITA_ATTN64");
   return !(e && e[0] == '0');
 }
 

@@ -520,7 +520,7 @@ extern "C" int vita_flash_attn_bwd(const vita_attn_bwd_params* p, void* stream) 
   const int64_t n_dq = (int64_t)p->n_q_heads * p->n_q_chunks * (p->chunk_len / QT_DQ);
   const int64_t n_kv = (int64_t)p->n_kv_heads * p->n_kv_chunks * (p->chunk_len / KT_KV);
   if (n_dq > 0x7fffffff || n_kv > 0x7fffffff) return VITA_ERR_UNSUPPORTED;
-  const char* only = getenv("VITA_ATTN_BWD_ONLY");     // developer measurement aid: "dq" / "dkv" launch one of the two kernels
+  const char* only = vita_dev_getenv("VITA_ATTN_BWD_ONLY");     // developer measurement aid: "dq" / "dkv" launch one of the two kernels
   if (!only || only[1] == 'q') {
     if (vita_attn_bwd_dq64_eligible(a)) {            // causal whole 256-row tiles: 64 query rows per wave (attn_bwd64.hip)
       const int rc = vita_attn_bwd_dq64_launch(a, st);

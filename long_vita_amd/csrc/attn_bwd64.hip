@@ -348,7 +348,7 @@ bool vita_attn_bwd_dq64_eligible(const BwdArgs& a) {
     if (!found) return false;
   }
   if ((int64_t)KVT * a.k_rs * 2 > 0x7fffffffLL || (int64_t)KVT * a.v_rs * 2 > 0x7fffffffLL) return false;
-  const char* e = getenv("VITA_ATTN_BWD64");
+  const char* e = vita_dev_getenv("VITA_ATTN_BWD64");
   return !(e && e[0] == '0');
 }
 

@@ -403,7 +403,7 @@ int launch_kv64(const BwdArgs& a, hipStream_t st) {
 bool vita_attn_bwd_kv64_eligible(const BwdArgs& a) {
   if (a.seg_start || a.chunk_len % KTILE) return false;     // (a key chunk sees whole chunks, its own from the diagonal on, or nothing)
   if ((int64_t)QT * a.q_rs * 2 > 0x7fffffffLL || (int64_t)QT * a.do_rs * 2 > 0x7fffffffLL) return false;
-  const char* e = getenv("VITA_ATTN_BWD64");
+  const char* e = vita_dev_getenv("VITA_ATTN_BWD64");
   return !(e && e[0] == '0');
 }
 

@@ -893,7 +893,7 @@ int launch_gemm_cfg(GemmArgs a, hipStream_t st) {
 inline int gemm_tile_override() {
   static int v = -1;
   if (v < 0) {
-    const char* e = getenv("VITA_GEMM_TILE");
+    const char* e = vita_dev_getenv("VITA_GEMM_TILE");
     v = e ? atoi(e) : 0;
   }
   return v;
@@ -907,16 +907,16 @@ int launch_gemm(const GemmArgs& a, hipStream_t st) {
   bool big = big_tiles >= 192;
   if (gemm_tile_override() == 128) big = false;
   if (gemm_tile_override() == 256) big = true;
-  static const bool nopin = getenv("VITA_GEMM_NOPIN") != nullptr;     // developer tuning aid
+  static const bool nopin = vita_dev_getenv("VITA_GEMM_NOPIN") != nullptr;     // developer tuning aid
   if (gemm_tile_override() == 2564) return launch_gemm_cfg<EPI, 256, 256, 2, 2>(a, st);   // 4 waves x (128 x 128), compiler-scheduled
   // VITA_GEMM_KERNEL (developer aid, read per launch): "w4" / "w8" force the large-problem kernel, "128" the small tile
-  const char* kn = getenv("VITA_GEMM_KERNEL");
+  const char* kn = vita_dev_getenv("VITA_GEMM_KERNEL");
   const bool w4_ok = gemm_w4_addressable(a, EPI == VITA_EPI_SWIGLU);
   if (kn && kn[0] == 'w' && kn[1] == '4' && w4_ok) return launch_gemm_w4<EPI>(a, st);
   if (kn && kn[0] == 'w' && kn[1] == '8') return launch_gemm_cfg<EPI, 256, 256, 2, 4>(a, st);
   if (kn && kn[0] == '1') return launch_gemm_cfg<EPI, 128, 128, 2, 2>(a, st);
   if (EPI == VITA_EPI_NONE) {     // developer measurement aids, read per launch (tools/microbench.py variants)
-    const char* e = getenv("VITA_GEMM_EXP");
+    const char* e = vita_dev_getenv("VITA_GEMM_EXP");
     const int v = e ? atoi(e) : 0;
     if (v == 10) { GemmArgs b = a; b.ldr = -1; return launch_gemm_cfg<EPI, 256, 256, 2, 4>(b, st); }   // 8 waves, L2-hit loads
     if (v == 4) return launch_gemm4<EPI>(a, st);                                                        // 4 waves x (128 x 128)
@@ -945,7 +945,7 @@ extern "C" int vita_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
   a.bias = (const bf16_t*)bias; a.scale = (const bf16_t*)scale; a.R = (const bf16_t*)R; a.ldr = ldr;
   a.tiles_m = a.tiles_n = 0;
   {
-    const char* e = getenv("VITA_GEMM_STAGGER");          // developer tuning aid, read per launch
+    const char* e = vita_dev_getenv("VITA_GEMM_STAGGER");          // developer tuning aid, read per launch
     a.stagger = e ? atoi(e) : 0;
   }
   hipStream_t st = (hipStream_t)stream;

@@ -94,6 +94,14 @@ __device__ __forceinline__ void rope_rotate8(u32x4& x1, u32x4& x2, const u32x4& 
   x2 = o2;
 }
 
+// Developer switches (VITA_ATTN_*, VITA_GEMM_*: kernel selection and timing aids) are honoured only when VITA_DEBUG
+// is set in the environment; that flag is read ONCE per process, so a production process never consults them.
+#include <stdlib.h>
+static inline const char* vita_dev_getenv(const char* name) {
+  static const bool on = [] { const char* d = getenv("VITA_DEBUG"); return d && d[0] && d[0] != '0'; }();
+  return on ? getenv(name) : nullptr;
+}
+
 static inline int vita_check_launch() {
   hipError_t e = hipGetLastError();
   return e == hipSuccess ? VITA_OK : VITA_ERR_LAUNCH;

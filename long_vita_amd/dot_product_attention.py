@@ -16,7 +16,7 @@ from typing import Optional
 import torch
 import torch.distributed as dist
 
-from . import ops, parallel_state as mpu
+from . import ops, parallel_state as mpu, training_utils
 
 
 class HipDotProductAttention(torch.nn.Module):
@@ -48,12 +48,23 @@ class HipDotProductAttention(torch.nn.Module):
         assert packed_seq_params is None, (
             "Packed sequence is not supported by DotProductAttention."
             "Please use TEDotProductAttention instead.")
-        if mpu.get_context_parallel_world_size() > 1 or not self._impl.causal:
-            raise NotImplementedError("autograd through the module is built for causal CP = 1; the context-parallel training "
-                                      "step is long_vita_amd.training.TrainStep")
-        from .autograd_fns import FlashAttnFn
+        from .autograd_fns import FlashAttnCPFn, FlashAttnFn
         sq, b, np_, hn = query.shape
-        out = FlashAttnFn.apply(query.transpose(0, 1), key.transpose(0, 1), value.transpose(0, 1), self._impl.softmax_scale)
+        if b != 1:
+            # vita_flash_attn_bwd is a batch-1 kernel (every Long-VITA script trains --micro-batch-size 1)
+            raise ValueError("the autograd path of HipDotProductAttention runs micro-batch 1 "
+                             f"(got batch {b}); split the batch or run under torch.no_grad()")
+        q, k, v = query.transpose(0, 1), key.transpose(0, 1), value.transpose(0, 1)
+        if self._impl.causal and mpu.get_context_parallel_world_size() > 1:
+            # TE's AttnFuncWithCP behind M/core/models/gpt/gpt_layer_specs.py:40: K / V all-gather forward,
+            # dK / dV reduce-scatter backward
+            if training_utils.get_packed_segments() is not None:
+                raise NotImplementedError("packed samples under context parallelism are not built (reference stage 2 is CP = 1)")
+            out = FlashAttnCPFn.apply(q, k, v, self._impl)
+        else:
+            seg = training_utils.get_packed_segments() if self._impl.causal else None
+            out = FlashAttnFn.apply(q, k, v, self._impl.softmax_scale, self._impl.causal,
+                                    None if seg is None else seg[0], None if seg is None else seg[1])
         return out.transpose(0, 1).reshape(sq, b, np_ * hn)
 
 
@@ -86,16 +97,23 @@ class DotProductAttention:
             kv = torch.stack([key.reshape(sq, self.ng, hn), value.reshape(sq, self.ng, hn)]).contiguous()
             out = self.forward_cp(q.reshape(1, sq, self.ng, np_ // self.ng, hn), kv)
         else:
-            out = ops.flash_attn(q, k, v, causal=self.causal, softmax_scale=self.softmax_scale)
+            # position ids with resets -> packed samples (_flash_attention_forward(position_ids=...), :374-390)
+            seg = training_utils.get_packed_segments() if self.causal else None
+            if seg is not None and (b != 1 or cp > 1):
+                raise NotImplementedError("packed samples run micro-batch 1, CP = 1 (reference stage 2)")
+            out = ops.flash_attn(q, k, v, causal=self.causal, softmax_scale=self.softmax_scale,
+                                 seg_start=None if seg is None else seg[0])
         return out.transpose(0, 1).reshape(sq, b, np_ * hn)                           # [sq, b, hp] :285-289
 
     __call__ = forward
 
     # -- context-parallel core ----------------------------------------------------------------------
-    def forward_cp(self, q5: torch.Tensor, kv_local: torch.Tensor, out: Optional[torch.Tensor] = None, events=None):
+    def forward_cp(self, q5: torch.Tensor, kv_local: torch.Tensor, out: Optional[torch.Tensor] = None, events=None,
+                   lse: Optional[torch.Tensor] = None):
         """q5 [1, S_l, ng, qpg, d] grouped query view; kv_local packed [kv_split, 2, S_l, ng/kv_split, d]
         (vita_rope_qkv_fwd).  One all-gather per kv-head split, all issued up front on RCCL's stream;
-        the attention over split j waits only for gather j, so gather j+1 runs under it."""
+        the attention over split j waits only for gather j, so gather j+1 runs under it.
+        lse: fp32 [1, np, S_l] (contiguous) receives the row log-sum-exp over ALL keys (what the backward needs)."""
         cp, r = mpu.get_context_parallel_world_size(), mpu.get_context_parallel_rank()
         if kv_local.dim() == 4:
             kv_local = kv_local.unsqueeze(0)
@@ -140,6 +158,7 @@ class DotProductAttention:
                     stream.wait_event(ready)
                 rows = gathered[j].view(cp * 2 * s_l, hg, d)        # K rows of rank p at p*2*s_l, V at +s_l
                 qj, oj = q5[:, :, j * hg:(j + 1) * hg], out[:, :, j * hg * qpg:(j + 1) * hg * qpg]
+                lj = None if lse is None else lse[:, j * hg * qpg:(j + 1) * hg * qpg]     # batch 1: a head slice is contiguous
                 own = mpu.zigzag_chunk_ids(cp, r)
                 if j == 0 and cp > 1 and self.local_first:
                     # Gathers 1.. run under the attention of the split before them; gather 0 has nothing in front of it.  The rank's
@@ -148,7 +167,7 @@ class DotProductAttention:
                     # local block first for the same reason).
                     _, lse_a = ops.flash_attn(qj, kv_local[0, 0].unsqueeze(0), kv_local[0, 1].unsqueeze(0), causal=True,
                                               softmax_scale=self.softmax_scale, chunk_len=c, q_chunk_gid=own, kv_chunk_gid=own,
-                                              kv_chunk_row=[0, c], out=oj, return_lse=True)
+                                              kv_chunk_row=[0, c], out=oj, return_lse=True, lse_out=lj)
                     if works[j] is not None:
                         works[j].wait()
                     rem = [i for i in range(2 * cp) if i // 2 != r]
@@ -162,7 +181,7 @@ class DotProductAttention:
                     if works[j] is not None:
                         works[j].wait()                             # this stream waits for gather j only
                     ops.flash_attn(qj, rows.unsqueeze(0), rows[s_l:].unsqueeze(0), causal=True, softmax_scale=self.softmax_scale,
-                                   chunk_len=c, q_chunk_gid=own, kv_chunk_gid=kv_gid, kv_chunk_row=kv_row, out=oj)
+                                   chunk_len=c, q_chunk_gid=own, kv_chunk_gid=kv_gid, kv_chunk_row=kv_row, out=oj, lse_out=lj)
                 if stream is not main:
                     ev = torch.cuda.Event()
                     ev.record(stream)

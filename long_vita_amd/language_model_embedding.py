@@ -129,10 +129,8 @@ class LanguageModelEmbedding(torch.nn.Module):
             we = F_.EmbeddingScatterFn.apply(we_mod.weight, ids, feats, tgt, src)
         out = we.view(b, s, h).transpose(0, 1).contiguous()                            # [b s h] -> [s b h] (:143)
         cfg = self.config
-        if cfg is not None and getattr(cfg, "sequence_parallel", False) and tp > 1:    # :157-166: this rank's sequence shard
-            r = mpu.get_tensor_model_parallel_rank()
-            n = out.shape[0] // tp
-            out = out[r * n:(r + 1) * n].contiguous()
+        if cfg is not None and getattr(cfg, "sequence_parallel", False) and tp > 1:    # :157-166: this rank's sequence shard;
+            out = F_.ScatterToSP.apply(out)                                            # backward = all-gather along the sequence
         if self.training and self.embedding_dropout.p > 0:
             out = self.embedding_dropout(out)
         return out

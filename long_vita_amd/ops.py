@@ -276,12 +276,14 @@ def gemm_skinny(a: torch.Tensor, w: torch.Tensor, out_f32: bool = False) -> torc
 def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, causal: bool, softmax_scale: Optional[float] = None,
                chunk_len: Optional[int] = None, q_chunk_gid: Optional[Sequence[int]] = None,
                kv_chunk_gid: Optional[Sequence[int]] = None, kv_chunk_row: Optional[Sequence[int]] = None,
-               out: Optional[torch.Tensor] = None, return_lse: bool = False, seg_start: Optional[torch.Tensor] = None):
+               out: Optional[torch.Tensor] = None, return_lse: bool = False, seg_start: Optional[torch.Tensor] = None,
+               lse_out: Optional[torch.Tensor] = None):
     """q [B, Sq, Hq, D] or grouped [B, Sq, Hkv, G, D]; k/v [B, Sk, Hkv, D] — *views* (any batch / row /
     head / group stride, D contiguous).  Returns o [B, Sq, Hq, D] (contiguous unless `out` given).
 
     Chunk geometry (zig-zag context parallelism): Sq = len(q_chunk_gid) * chunk_len local rows,
-    kv chunk j starts at row kv_chunk_row[j] of k/v.  Defaults: one chunk, gid 0."""
+    kv chunk j starts at row kv_chunk_row[j] of k/v.  Defaults: one chunk, gid 0.
+    lse_out: fp32 [B, Hq, Sq] contiguous destination of the row log-sum-exp (implies return_lse)."""
     if q.dim() == 5:
         B, Sq, Hkv_q, G, D = q.shape
         Hq = Hkv_q * G
@@ -308,7 +310,12 @@ def flash_attn(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, *, causal: boo
             raise ValueError("Sq must equal len(q_chunk_gid) * chunk_len")
         q_valid = kv_valid = chunk_len
     o = torch.empty((B, Sq, Hq, D), dtype=BF16, device=q.device) if out is None else out
-    lse = torch.empty((B, Hq, Sq), dtype=torch.float32, device=q.device) if return_lse else None
+    if lse_out is not None:
+        if tuple(lse_out.shape) != (B, Hq, Sq) or not lse_out.is_contiguous() or lse_out.dtype != torch.float32:
+            raise ValueError("lse_out must be contiguous fp32 [B, Hq, Sq]")
+        lse, return_lse = lse_out, True
+    else:
+        lse = torch.empty((B, Hq, Sq), dtype=torch.float32, device=q.device) if return_lse else None
     p = AttnParams()
     p.q, p.q_batch_stride, p.q_row_stride, p.q_head_stride, p.q_group_stride = _dev(q, "q", BF16), q_bs, q_rs, q_hs, q_gs
     p.k, p.k_batch_stride, p.k_row_stride, p.k_head_stride = _dev(k, "k", BF16), k.stride(0), k.stride(1), k.stride(2)

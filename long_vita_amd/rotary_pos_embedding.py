@@ -7,6 +7,7 @@ position_ids gather (:114-117) and the zig-zag CP slice (:36-47, :119-121) into 
 """
 from __future__ import annotations
 
+import weakref
 from typing import Optional
 
 import torch
@@ -48,18 +49,20 @@ class RotaryEmbedding:
         return local_rows * mpu.get_context_parallel_world_size()
 
 
-_COS_SIN_CACHE = {"key": None, "val": None}
+_COS_SIN_CACHE = {"ref": None, "version": None, "val": None}
 
 
 def _cos_sin(freqs):
     """`freqs` is either this module's (cos, sin) pair or Megatron's fp32 angle tensor [s, 1, 1, dim]
     (rotary_pos_embedding.py:106-108), which every one of the 48 layers passes again: the bf16 tables are built once per
-    tensor (keyed by storage, shape and version counter)."""
+    tensor — keyed by the tensor OBJECT (a weak reference: a freed tensor whose address is re-used by another one never hits)
+    and its version counter."""
     if isinstance(freqs, (tuple, list)):
         return freqs
-    key = (freqs.data_ptr(), tuple(freqs.shape), freqs._version, freqs.device)
-    if _COS_SIN_CACHE["key"] != key:
-        _COS_SIN_CACHE["key"], _COS_SIN_CACHE["val"] = key, ops.rope_cos_sin(freqs)
+    ref = _COS_SIN_CACHE["ref"]
+    if ref is None or ref() is not freqs or _COS_SIN_CACHE["version"] != freqs._version:
+        _COS_SIN_CACHE["val"] = ops.rope_cos_sin(freqs)
+        _COS_SIN_CACHE["ref"], _COS_SIN_CACHE["version"] = weakref.ref(freqs), freqs._version
     return _COS_SIN_CACHE["val"]
 
 

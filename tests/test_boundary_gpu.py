@@ -14,6 +14,8 @@ pytestmark = pytest.mark.gpu
 import dummy_megatron as dm  # noqa: E402
 from oracle import attention as oattn, glue, llm as ollm  # noqa: E402
 
+from conftest import tol  # noqa: E402
+
 DEV = "cuda"
 CFG = dict(num_layers=1, hidden=1024, heads=8, kv_groups=2, head_dim=128, ffn=2816, vocab=512)
 
@@ -21,6 +23,11 @@ CFG = dict(num_layers=1, hidden=1024, heads=8, kv_groups=2, head_dim=128, ffn=28
 def rel_l2(a, b):
     a, b = a.float().cpu(), b.float().cpu()
     return float((a - b).norm() / (b.norm() + 1e-30))
+
+
+def _record(name, errs):
+    from conftest import record_parity
+    record_parity("boundary/" + name, **{k: float(v) for k, v in errs.items()})
 
 
 @pytest.fixture()
@@ -78,7 +85,7 @@ def test_decoder_layer_built_by_megatron_matches_the_oracle_forward_and_backward
     out, _ = layer(xh, attention_mask=None, rotary_pos_emb=freqs.to(DEV))
     assert out.shape == (S, 1, CFG["hidden"]) and out.dtype == torch.bfloat16
     e_fwd = rel_l2(out, ref)
-    assert e_fwd < 1e-2, e_fwd
+    tol("forward", e_fwd, 1e-2)
     (out.float() * w_out.to(DEV).float()).sum().backward()
     names = {"qkv_w": "self_attention.linear_qkv.weight", "qkv_b": "self_attention.linear_qkv.bias",
              "o_w": "self_attention.linear_proj.weight", "fc1_w": "mlp.linear_fc1.weight", "fc2_w": "mlp.linear_fc2.weight",
@@ -89,12 +96,13 @@ def test_decoder_layer_built_by_megatron_matches_the_oracle_forward_and_backward
     for k, n in names.items():
         assert params[n].grad is not None, n
         errs[k] = rel_l2(params[n].grad, lpo[k].grad)
-    assert max(errs.values()) < 5e-2, errs
+    _record("layer_" + spec, errs)
+    tol("worst gradient", max(errs.values()), 5e-2)
 
     # inference call (no autograd): the in-place fast path gives the same values
     with torch.no_grad():
         out2, _ = layer(x.to(DEV), attention_mask=None, rotary_pos_emb=freqs.to(DEV))
-    assert rel_l2(out2, out) < 2e-3
+    tol("out2, out", rel_l2(out2, out), 2e-3)
 
 
 def test_embedding_and_masked_output_layer_modules_against_the_reference_fixtures(megatron):
@@ -132,8 +140,8 @@ def test_embedding_and_masked_output_layer_modules_against_the_reference_fixture
     we = wr[g["ids"]].clone()
     we[g["tgt"][0], g["tgt"][1]] = fr[g["src"][0], g["src"][1]]
     we.transpose(0, 1).contiguous().backward(go.float())
-    assert rel_l2(f.grad, fr.grad) < 1e-6                      # pure row moves
-    assert rel_l2(emb16.word_embeddings.weight.grad, wr.grad) < 4e-3       # fp32 sums of bf16 rows, rounded once to bf16
+    tol("f.grad, fr.grad", rel_l2(f.grad, fr.grad), 1e-6)                      # pure row moves
+    tol("emb16.word_embeddings.weight.grad, wr.grad", rel_l2(emb16.word_embeddings.weight.grad, wr.grad), 4e-3)       # fp32 sums of bf16 rows, rounded once to bf16
 
     m = load_golden("masked_linear_bf16.pt")
     n_out, n_in = m["w"].shape
@@ -198,8 +206,8 @@ def test_sequence_parallel_tensor_parallel_layer_matches_the_unsharded_oracle(me
     outs = _run_grid(tp, 1, rank_fn, {"mpu": mpu}, monkeypatch)
     out = torch.cat([outs[(0, t)][0] for t in range(tp)], 0)
     dx = torch.cat([outs[(0, t)][1] for t in range(tp)], 0)
-    assert rel_l2(out, ref) < 1e-2, rel_l2(out, ref)
-    assert rel_l2(dx, xo.grad) < 5e-2, rel_l2(dx, xo.grad)
+    tol("out, ref", rel_l2(out, ref), 1e-2)
+    tol("dx, xo.grad", rel_l2(dx, xo.grad), 5e-2)
     gs = [outs[(0, t)][2] for t in range(tp)]
     d, qpg, ng = CFG["head_dim"], CFG["heads"] // CFG["kv_groups"], CFG["kv_groups"]
     cat0 = lambda k: torch.cat([g_[k] for g_ in gs], 0)                               # noqa: E731
@@ -212,4 +220,121 @@ def test_sequence_parallel_tensor_parallel_layer_matches_the_unsharded_oracle(me
             "ln2": rel_l2(sum(g_["mlp.linear_fc1.layer_norm_weight"].float() for g_ in gs), lpo["ln2"].grad)}
     halves = [g_["mlp.linear_fc1.weight"].chunk(2, 0) for g_ in gs]
     errs["fc1_w"] = rel_l2(torch.cat([h_[0] for h_ in halves] + [h_[1] for h_ in halves], 0), lpo["fc1_w"].grad)
-    assert max(errs.values()) < 5e-2, errs
+    _record("sp_tp2_layer", errs)
+    tol("worst gradient", max(errs.values()), 5e-2)
+
+
+@pytest.mark.parametrize("tp,cp", [(1, 2), (2, 2), (1, 4)])
+def test_context_parallel_layer_trains_through_the_megatron_built_module(megatron, monkeypatch, tp, cp):
+    """VERDICT r2 "missing" 1 / BASELINE config 5 (TP = 2 x CP = 4 training): the Megatron-built TE-spec layer on simulated
+    TP x CP ranks with autograd ON.  core_attention = HipDotProductAttention -> autograd_fns.FlashAttnCPFn (K / V all-gather over
+    the CP group forward, dK / dV reduce-scatter backward — TE's AttnFuncWithCP behind M/core/models/gpt/gpt_layer_specs.py:40);
+    every rank holds its two zig-zag chunks (M/training/utils.py:329-341), under TP = 2 also `--sequence-parallel`.  Reassembled
+    output, input gradient and EVERY parameter gradient (summed over the CP ranks, concatenated over the TP ranks) vs the
+    unsharded oracle layer and torch autograd over it."""
+    from long_vita_amd import parallel_state as mpu, tensor_parallel as tpar, training_utils
+    from long_vita_amd.gpt_vl_model import GPTConfig
+    from test_train_gpu import _run_grid
+    S = 2048 if cp == 4 else 1024
+    ocfg = ollm.LLMConfig(**CFG)
+    p = ollm.init_llm_params(ocfg, seed=51)
+    lp = p["layers"][0]
+    g = torch.Generator().manual_seed(52)
+    x = (torch.randn(S, 1, CFG["hidden"], generator=g) * 0.5).bfloat16()
+    w_out = torch.randn(S, 1, CFG["hidden"], generator=g).bfloat16()
+    freqs = glue.rope_emb(S, glue.rope_inv_freq(ocfg.head_dim, ocfg.rope_theta))
+    xo = x.clone().requires_grad_(True)
+    lpo = {k: v.clone().requires_grad_(True) for k, v in lp.items()}
+    ref, _ = ollm.decoder_layer(xo, lpo, ocfg, freqs, lambda q, k, v: oattn.core_attention(q, k, v, causal=True))
+    (ref.float() * w_out.float()).sum().backward()
+
+    def rank_fn(ci, ti):
+        with torch.autograd.set_multithreading_enabled(False):       # each simulated rank's backward (and its collectives) on its own thread
+            return rank_body(ci, ti)
+
+    def rank_body(ci, ti):
+        sl = tpar.shard_llm_params(p, GPTConfig(**CFG), tp, ti)[0]["layers"][0] if tp > 1 else lp
+        mcfg = dm.TransformerConfig(hidden_size=CFG["hidden"], num_attention_heads=CFG["heads"], num_query_groups=CFG["kv_groups"],
+                                    kv_channels=CFG["head_dim"], ffn_hidden_size=CFG["ffn"], sequence_parallel=tp > 1,
+                                    tensor_model_parallel_size=tp, context_parallel_size=cp)
+        layer = dm.build_module(megatron.get_gpt_layer_with_transformer_engine_spec(), config=mcfg, layer_number=1)
+        _load(layer, sl, True)
+        zz = lambda t: training_utils.zigzag_slice(t, cp, ci, seq_dim=0)                  # noqa: E731  this CP rank's two chunks
+        n = S // cp // tp
+        xs = zz(x)[ti * n:(ti + 1) * n].to(DEV).requires_grad_(True)                       # ... and this TP rank's sequence shard
+        out, _ = layer(xs, attention_mask=None, rotary_pos_emb=zz(freqs).to(DEV))         # get_pos_emb_on_this_cp_rank (:36-47)
+        assert out.shape == (n, 1, CFG["hidden"])
+        (out.float() * zz(w_out)[ti * n:(ti + 1) * n].to(DEV).float()).sum().backward()
+        return out.detach(), xs.grad.detach(), {k: v.grad.detach().clone() for k, v in layer.named_parameters()}
+
+    outs = _run_grid(tp, cp, rank_fn, {"mpu": mpu}, monkeypatch)
+
+    def unzig(parts):              # parts[ci] = the rank's [2 * C, ...] rows -> global order
+        c = S // (2 * cp)
+        full = torch.empty((S,) + tuple(parts[0].shape[1:]), dtype=parts[0].dtype, device=parts[0].device)
+        for ci, t in enumerate(parts):
+            full[ci * c:(ci + 1) * c], full[(2 * cp - 1 - ci) * c:(2 * cp - ci) * c] = t[:c], t[c:]
+        return full
+
+    out = unzig([torch.cat([outs[(ci, t)][0] for t in range(tp)], 0) for ci in range(cp)])
+    dx = unzig([torch.cat([outs[(ci, t)][1] for t in range(tp)], 0) for ci in range(cp)])
+    e_out, e_dx = rel_l2(out, ref), rel_l2(dx, xo.grad)
+    # per TP rank: the sum over the CP ranks (Megatron reduces parameter gradients over the DP x CP group)
+    gs = [{k: sum(outs[(ci, t)][2][k].float() for ci in range(cp)) for k in outs[(0, t)][2]} for t in range(tp)]
+    cat0 = lambda k: torch.cat([g_[k] for g_ in gs], 0)                                  # noqa: E731
+    errs = {"out": e_out, "dx": e_dx,
+            "qkv_w": rel_l2(cat0("self_attention.linear_qkv.weight"), lpo["qkv_w"].grad),
+            "qkv_b": rel_l2(cat0("self_attention.linear_qkv.bias"), lpo["qkv_b"].grad),
+            "o_w": rel_l2(torch.cat([g_["self_attention.linear_proj.weight"] for g_ in gs], 1), lpo["o_w"].grad),
+            "fc2_w": rel_l2(torch.cat([g_["mlp.linear_fc2.weight"] for g_ in gs], 1), lpo["fc2_w"].grad)}
+    # norm weights: replicated at TP = 1; sequence-parallel parameters under TP > 1 (each rank saw its shard, Megatron all-reduces)
+    ln = lambda k: (sum(g_[k] for g_ in gs) if tp > 1 else gs[0][k])                      # noqa: E731
+    errs["ln1"] = rel_l2(ln("self_attention.linear_qkv.layer_norm_weight"), lpo["ln1"].grad)
+    errs["ln2"] = rel_l2(ln("mlp.linear_fc1.layer_norm_weight"), lpo["ln2"].grad)
+    halves = [g_["mlp.linear_fc1.weight"].chunk(2, 0) for g_ in gs]
+    errs["fc1_w"] = rel_l2(torch.cat([h_[0] for h_ in halves] + [h_[1] for h_ in halves], 0), lpo["fc1_w"].grad)
+    _record("cp_layer_tp%d_cp%d" % (tp, cp), errs)
+    tol("forward", e_out, 1e-2)
+    tol("worst gradient", max(errs.values()), 5e-2)
+
+
+def test_embedding_backward_under_sequence_parallelism_reaches_every_vocab_row_and_the_projector(megatron, monkeypatch):
+    """with `--sequence-parallel` the embedding output is scattered along the sequence
+    (scatter_to_sequence_parallel_region, language_model_embedding.py:157-160) and its BACKWARD is an all-gather: each tensor-parallel
+    rank owns a vocabulary slice hit by tokens of every sequence shard, and the replicated projector must receive the full
+    feature gradient on every rank.  Two simulated TP ranks vs torch autograd over the reference's expression, unsharded."""
+    from long_vita_amd import parallel_state as mpu
+    from test_train_gpu import _run_grid
+    emb_cls = sys.modules["megatron.core.models.common.embeddings.language_model_embedding"].LanguageModelEmbedding
+    tp, V, H, S, N, L = 2, 512, 256, 256, 3, 16
+    gen = torch.Generator().manual_seed(77)
+    table = torch.randn(V, H, generator=gen).bfloat16()
+    ids = torch.randint(0, V, (1, S), generator=gen)
+    feats = torch.randn(N, L, H, generator=gen).bfloat16()
+    pos = torch.randperm(S, generator=gen)[:N * L].sort().values                     # visual rows spread over BOTH sequence shards
+    indices = torch.stack([torch.zeros(N, L, dtype=torch.int64), pos.view(N, L)])
+    go = torch.randn(S, 1, H, generator=gen).bfloat16()
+    wr, fr = table.float().requires_grad_(True), feats.float().requires_grad_(True)
+    we = wr[ids].clone()
+    we[indices[0].reshape(-1), indices[1].reshape(-1)] = fr.reshape(-1, H)
+    we.transpose(0, 1).contiguous().backward(go.float())
+
+    def rank_fn(ci, ti):
+        with torch.autograd.set_multithreading_enabled(False):
+            cfg = dm.TransformerConfig(hidden_size=H, sequence_parallel=True, tensor_model_parallel_size=tp)
+            emb = emb_cls(config=cfg, vocab_size=V, max_sequence_length=S, position_embedding_type="rope")
+            emb.load_state_dict({"word_embeddings.weight": table[ti * V // tp:(ti + 1) * V // tp]})
+            f = feats.to(DEV).requires_grad_(True)
+            out = emb(ids.to(DEV), None, external_feature_dict={"features": f, "indices": indices.to(DEV)})
+            n = S // tp
+            assert out.shape == (n, 1, H)
+            out.backward(go[ti * n:(ti + 1) * n].to(DEV))
+            return out.detach(), f.grad.detach(), emb.word_embeddings.weight.grad.detach()
+
+    outs = _run_grid(tp, 1, rank_fn, {"mpu": mpu}, monkeypatch)
+    assert torch.equal(torch.cat([outs[(0, t)][0] for t in range(tp)], 0).cpu(), we.detach().transpose(0, 1).bfloat16())
+    for t in range(tp):
+        tol("feature gradient on every TP rank", rel_l2(outs[(0, t)][1], fr.grad), 1e-6)               # pure row moves
+    tol("vocab-parallel table gradient", rel_l2(torch.cat([outs[(0, t)][2] for t in range(tp)], 0), wr.grad), 4e-3)
+    hit_other_shard = int((wr.grad[:V // tp].abs().sum(-1) > 0).sum())                # rank 0's rows hit from rank 1's sequence shard
+    assert hit_other_shard > 0

@@ -8,7 +8,7 @@
 The oracle is evaluated on SAMPLED query rows only (first / last row of chunks and 256-row tiles, 64-key tile edges,
 random rows): fp32 `oracle.attention.core_attention` on the CPU with the rows' global positions — restating
 M/core/transformer/dot_product_attention.py:186-289 with the zig-zag ownership of M/training/utils.py:329-341.
-Every achieved rel-L2 / max-abs lands in gpurun_out/r02_parity.json (copied to profiles/); each limit below is
+Every achieved rel-L2 / max-abs lands in gpurun_out/r03_parity.json (copied to profiles/); each limit below is
 <= 1.5 x the value measured on the MI355X.
 """
 import json
@@ -24,7 +24,7 @@ from oracle import attention as oattn, glue, llm as ollm  # noqa: E402
 
 DEV = "cuda"
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-PARITY_OUT = os.environ.get("VITA_PARITY_OUT", os.path.join(ROOT, "gpurun_out", "r02_parity.json"))
+from conftest import record_parity  # noqa: E402
 
 # name -> (rel-L2 limit, max-abs limit) = 1.5 x the values measured on the MI355X (profiles/r02_parity.json):
 #   attention, single chunk : rel-L2 1.18e-3, max-abs 9.3e-3 (outputs of rms 0.16: early rows dominate the norm)
@@ -44,13 +44,7 @@ LIMITS = {
 
 
 def record(name, **metrics):
-    try:
-        os.makedirs(os.path.dirname(PARITY_OUT), exist_ok=True)
-        data = json.load(open(PARITY_OUT)) if os.path.exists(PARITY_OUT) else {}
-        data[name] = metrics
-        json.dump(data, open(PARITY_OUT, "w"), indent=1, sort_keys=True)
-    except OSError:
-        pass
+    record_parity(name, **metrics)
 
 
 def check(name, got, ref, **extra):

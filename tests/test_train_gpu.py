@@ -8,6 +8,8 @@ pytestmark = pytest.mark.gpu
 
 from oracle import llm as ollm, train as otrain, vit as ovit  # noqa: E402
 
+from conftest import tol  # noqa: E402
+
 DEV = "cuda"
 SMALL = dict(num_layers=2, hidden=1024, heads=8, kv_groups=2, head_dim=128, ffn=2816, vocab=1024)
 
@@ -24,20 +26,17 @@ def amd():
     return dict(ops=ops, gpt=gpt_vl_model, mpu=parallel_state, train=training, vision=vision, syn=synthetic)
 
 
-def _check_grads(g, ref, tol, skip=()):
-    bad = []
+def _check_grads(g, ref, limit, skip=()):
+    """Every gradient within `limit` rel-L2; the worst one (and which) is recorded."""
+    errs = {}
     for k in ("embed", "final_ln", "lm_head"):
-        if k in skip:
-            continue
-        e = rel_l2(g[k], ref[k])
-        if e > tol:
-            bad.append((k, e))
+        if k not in skip:
+            errs[k] = rel_l2(g[k], ref[k])
     for li, (gl, rl) in enumerate(zip(g["layers"], ref["layers"])):
         for k in rl:
-            e = rel_l2(gl[k], rl[k])
-            if e > tol:
-                bad.append((f"layers.{li}.{k}", e))
-    assert not bad, bad
+            errs[f"layers.{li}.{k}"] = rel_l2(gl[k], rl[k])
+    worst = max(errs, key=errs.get)
+    tol(f"worst gradient ({worst})", errs[worst], limit)
 
 
 def _data(S, vocab, n_ans, seed):
@@ -203,7 +202,7 @@ def test_train_step_with_projector(amd):
     assert abs(float(loss) - float(loss_ref)) < 2e-2 * abs(float(loss_ref))
     _check_grads(g, g_ref, 5e-2)
     for k in proj_keys:
-        assert rel_l2(g["projector"][k], g_ref[k]) < 6e-2, (k, rel_l2(g["projector"][k], g_ref[k]))
+        tol("g['projector'][k], g_ref[k]", rel_l2(g["projector"][k], g_ref[k]), 6e-2)
 
 
 def test_train_step_cp_with_a_text_only_rank(amd, monkeypatch):
@@ -260,7 +259,7 @@ def test_train_step_cp_with_a_text_only_rank(amd, monkeypatch):
     assert abs(float(outs[0][0]) - float(loss_ref)) < 2e-2 * abs(float(loss_ref))
     _check_grads(outs[0][1], g_ref, 5e-2)
     for k in proj_keys:
-        assert rel_l2(outs[1][1]["projector"][k], g_ref[k]) < 6e-2, k
+        tol("outs[1][1]['projector'][k], g_ref[k]", rel_l2(outs[1][1]["projector"][k], g_ref[k]), 6e-2)
 
 
 def test_train_step_packed_samples_vs_autograd(amd):
@@ -385,8 +384,8 @@ def test_train_step_tensor_parallel(amd, monkeypatch, tp, cp, n_rec):
     full = tpar.unshard_llm_grads([outs[(0, ti)][1] for ti in range(tp)], full_cfg, tp)
     _check_grads(full, g_ref, 5e-2)
     # replicated parameters get the same gradients on the TP ranks (fp32 atomics: equal up to summation order)
-    assert rel_l2(outs[(0, 0)][1]["final_ln"], outs[(0, 1)][1]["final_ln"]) < 1e-5
-    assert rel_l2(outs[(0, 0)][1]["embed"], outs[(0, 1)][1]["embed"]) < 1e-5
+    tol("outs[(0, 0)][1]['final_ln'], outs[(0, 1)][1]['final_ln']", rel_l2(outs[(0, 0)][1]["final_ln"], outs[(0, 1)][1]["final_ln"]), 1e-5)
+    tol("outs[(0, 0)][1]['embed'], outs[(0, 1)][1]['embed']", rel_l2(outs[(0, 0)][1]["embed"], outs[(0, 1)][1]["embed"]), 1e-5)
 
 
 def test_prefill_tensor_parallel(amd, monkeypatch):
@@ -408,14 +407,16 @@ def test_prefill_tensor_parallel(amd, monkeypatch):
 
     outs = _run_grid(2, 1, rank_fn, amd, monkeypatch)
     assert torch.equal(outs[(0, 0)], outs[(0, 1)]) and outs[(0, 0)].shape == single.shape
-    assert rel_l2(outs[(0, 0)], single) < 1.5e-2
+    tol("outs[(0, 0)], single", rel_l2(outs[(0, 0)], single), 1.5e-2)
 
 
 @pytest.mark.parametrize("n_rec,cp", [(0, 1), (1, 1), (0, 2)])
 def test_train_step_selective_recompute_equals_full_recompute(amd, monkeypatch, n_rec, cp):
     """`--recompute-method block --recompute-num-layers N` (stage 3 passes 20 of 48): layers outside the recompute block keep their
-    activations instead of being re-run in the backward.  Same kernels on the same values either way, so the loss and every
-    gradient must equal the full-recompute step's bit for bit (CP = 2: the kept layers re-gather their rotated K / V)."""
+    activations instead of being re-run in the backward.  The kept layers' forward is the kernel-by-kernel one (the backward needs
+    gate / up), the recompute block's forward the fused fast path: the same rounding chain with a different fp32 summation order in
+    the GEMM epilogues, so loss and gradients agree to bf16 rounding noise (measured 0.6e-2 .. 1.0e-2 rel-L2 on the gradients, not
+    bit for bit; CP = 2: the kept layers re-gather their rotated K / V)."""
     S = 1024
     ocfg = ollm.LLMConfig(**SMALL)
     p = ollm.init_llm_params(ocfg, seed=9)

@@ -1,5 +1,6 @@
 """Developer aid: error structure of vita_flash_attn_fwd (new vs old kernel) against fp32 torch on the GPU."""
 import math, os, sys
+os.environ.setdefault("VITA_DEBUG", "1")      # developer switches (VITA_GEMM_*, VITA_ATTN_*) are honoured only with this set
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch

@@ -1,5 +1,6 @@
 """Developer aid: per-phase shader-clock breakdown of flash_fwd_kernel (VITA_ATTN_VARIANT bit 3)."""
 import ctypes as C, os, sys
+os.environ.setdefault("VITA_DEBUG", "1")      # developer switches (VITA_GEMM_*, VITA_ATTN_*) are honoured only with this set
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT)
 import torch

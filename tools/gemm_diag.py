@@ -1,5 +1,6 @@
 """Developer aid: where do two GEMM kernels (VITA_GEMM_KERNEL values) disagree?  Prints the (row, column) pattern of the outliers."""
 import os, sys, math
+os.environ.setdefault("VITA_DEBUG", "1")      # developer switches (VITA_GEMM_*, VITA_ATTN_*) are honoured only with this set
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
 from long_vita_amd import ops

@@ -4,6 +4,7 @@ Writes one JSON line per case to stdout (and gpurun_out/microbench.jsonl)."""
 import json
 import math
 import os
+os.environ.setdefault("VITA_DEBUG", "1")      # developer switches (VITA_GEMM_*, VITA_ATTN_*) are honoured only with this set
 import sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
