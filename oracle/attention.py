@@ -8,11 +8,36 @@ import torch
 from .glue import zigzag_chunk_ids
 
 
+class _BaddbmmChain(torch.autograd.Function):
+    """torch.baddbmm(beta=0, alpha) on half-precision operands as autograd sees it (what Megatron's unfused path runs, :206-212):
+    forward rounds alpha * (q k^T) ONCE; the backward formula `grad.bmm(other) * alpha` rounds the bmm result and then the scaled
+    result — two roundings whenever alpha is not a power of two (hn = 128).  Operands arrive as fp32 copies of half values."""
+
+    @staticmethod
+    def forward(ctx, qf, kf, alpha, dtype):
+        ctx.save_for_backward(qf, kf)
+        ctx.alpha, ctx.dtype = alpha, dtype
+        return (torch.matmul(qf, kf.transpose(-1, -2)) * alpha).to(dtype).float()
+
+    @staticmethod
+    def backward(ctx, g):
+        qf, kf = ctx.saved_tensors
+        g = g.to(ctx.dtype).float()
+        dq = torch.matmul(g, kf).to(ctx.dtype).float() * ctx.alpha
+        dk = torch.matmul(g.transpose(-1, -2), qf).to(ctx.dtype).float() * ctx.alpha
+        return dq, dk, None, None
+
+
 def core_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bool, scale: float = None,
-                   q_pos: torch.Tensor = None, k_pos: torch.Tensor = None, cu_seqlens: torch.Tensor = None) -> torch.Tensor:
+                   q_pos: torch.Tensor = None, k_pos: torch.Tensor = None, cu_seqlens: torch.Tensor = None,
+                   chain: bool = False) -> torch.Tensor:
     """M/core/transformer/dot_product_attention.py:171-175 (GQA repeat_interleave) + :186-289
     (baddbmm / softmax / bmm).  q [sq, b, np, hn], k/v [sk, b, ng, hn] -> [sq, b, np*hn].
     Computed in fp32 (attention_softmax_in_fp32), result cast to q.dtype.
+    chain=True (with bf16 / fp16 inputs): the dtype chain of that UNFUSED path as Megatron runs it in half precision — the
+    reference's CPU-capable attention: `torch.baddbmm(..., alpha = 1 / norm_factor)` writes the scores in q.dtype (:206-212, one
+    rounding of the scaled product), scale_mask_softmax computes in fp32 and casts the probabilities back to q.dtype, `torch.bmm`
+    (:268) rounds the context to q.dtype; under autograd the gradients are rounded at the same three tensors.
     q_pos / k_pos: global positions for the causal rule (default arange).
     cu_seqlens: packed samples (flash_attn_varlen_func branch, :334-367) — a query only sees keys of its own sample."""
     sq, b, np_, hn = q.shape
@@ -25,7 +50,11 @@ def core_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bo
     qf = q.float().permute(1, 2, 0, 3)          # [b, np, sq, hn]
     kf = k.float().permute(1, 2, 0, 3)
     vf = v.float().permute(1, 2, 0, 3)
-    scores = torch.matmul(qf, kf.transpose(-1, -2)) * scale          # [b, np, sq, sk]
+    chain = chain and q.dtype != torch.float32
+    if chain:
+        scores = _BaddbmmChain.apply(qf, kf, scale, q.dtype)
+    else:
+        scores = torch.matmul(qf, kf.transpose(-1, -2)) * scale      # [b, np, sq, sk]
     if causal:
         dev = q.device                                   # (the tensors' device: the 16K / 48-layer parity test evaluates this on the GPU)
         qp = torch.arange(sq, device=dev) if q_pos is None else q_pos.to(dev)
@@ -37,6 +66,8 @@ def core_attention(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, causal: bo
         seg = torch.bucketize(torch.arange(sq), cu_seqlens.to(torch.int64)[1:], right=True)     # sample id of every row
         scores = scores.masked_fill((seg[:, None] != seg[None, :])[None, None], float("-inf"))
     probs = torch.softmax(scores, dim=-1)
+    if chain:
+        probs = probs.to(q.dtype).float()
     ctx = torch.matmul(probs, vf)                                   # [b, np, sq, hn]
     return ctx.permute(2, 0, 1, 3).reshape(sq, b, np_ * hn).to(q.dtype)
 

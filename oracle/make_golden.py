@@ -653,6 +653,46 @@ def golden_unfused_attention():
     torch.save(out, os.path.join(OUT, "unfused_attention.pt"))
 
 
+def golden_unfused_attention_bf16():
+    """The same reference wrapper run as Megatron runs it in half precision (`--bf16`): bf16 q / k / v, so `torch.baddbmm` writes
+    bf16 scores, scale_mask_softmax (core_r0.7.0 fused_softmax.py forward_torch_softmax, restated: `input.float()` when
+    input_in_float16 and softmax_in_fp32 — `--attention-softmax-in-fp32` — then masked_fill(-10000), softmax,
+    `probs.bfloat16()`) hands bf16 probabilities to `torch.bmm`, which writes a bf16 context — the dtype chain that
+    oracle.attention.core_attention(chain=True) restates; plus torch autograd through it (bf16 gradients)."""
+    dpa = importlib.import_module("long_vita_megatron.core.transformer.dot_product_attention")
+    STATE["args"].use_flash_attn = False
+    dpa.parallel_state = types.SimpleNamespace(get_global_memory_buffer=lambda: types.SimpleNamespace(
+        get_tensor=lambda shape, dtype, name: torch.empty(shape, dtype=dtype)))
+
+    def scale_mask_softmax(scores, mask):
+        assert scores.dtype == torch.bfloat16
+        x = scores.float()
+        if mask is not None:
+            x = x.masked_fill(mask, -10000.0)
+        return torch.nn.Softmax(dim=-1)(x).bfloat16()
+
+    fwd = dpa.dot_product_attention_forward_wrapper(lambda *a_, **k_: None)
+    out = {"cases": []}
+    for case in ATTN_CASES_BF16:
+        q, k, v = (t.bfloat16().requires_grad_(True) for t in attn_case_inputs(case))
+        me = types.SimpleNamespace(num_attention_heads_per_partition=case["np"], num_query_groups_per_partition=case["ng"],
+                                   alibi=None, norm_factor=case["hn"] ** 0.5, attn_logit_softcapping=None, square_alibi_mask=False,
+                                   scale_mask_softmax=scale_mask_softmax, attention_dropout=lambda x: x,
+                                   config=types.SimpleNamespace(sequence_parallel=False),
+                                   hidden_size_per_partition=case["np"] * case["hn"])
+        mask = torch.triu(torch.ones(case["sq"], case["sq"], dtype=torch.bool), 1)[None, None] if case["causal"] else None
+        ctx = fwd(me, q, k, v, mask, None, None)
+        assert ctx.dtype == torch.bfloat16
+        go = torch.randn(ctx.shape, generator=torch.Generator().manual_seed(77 + case["sq"])).bfloat16()
+        ctx.backward(go)
+        out["cases"].append(dict(case, out=ctx.detach().clone(), go=go, dq=q.grad.clone(), dk=k.grad.clone(), dv=v.grad.clone()))
+    torch.save(out, os.path.join(OUT, "unfused_attention_bf16.pt"))
+
+
+ATTN_CASES_BF16 = [dict(name="llm_gqa_causal_bf16", sq=320, b=1, np=10, ng=2, hn=128, causal=True),
+                   dict(name="vit_mha_full_bf16", sq=65, b=2, np=4, ng=4, hn=64, causal=False)]
+
+
 VIT_CONVERT_SHAPES = {        # one InternViT-300M layer at full width (the converter hard-codes 16 heads x 64, hidden 1024)
     "embeddings.class_embedding": (1, 1, 1024), "embeddings.position_embedding": (1, 1025, 1024),
     "embeddings.patch_embedding.weight": (1024, 3, 14, 14), "embeddings.patch_embedding.bias": (1024,),
@@ -1168,6 +1208,7 @@ def main():
                      ("embedding_scatter", golden_embedding_scatter), ("masked_linear", golden_masked_linear),
                      ("hf_vit", golden_hf_vit), ("image_processor", golden_image_processor),
                      ("external_inputs", golden_external_inputs), ("decode_loop", golden_decode_loop), ("loss_func", golden_loss_func), ("unfused_attention", golden_unfused_attention),
+                     ("unfused_attention_bf16", golden_unfused_attention_bf16),
                      ("converters", golden_converters), ("sampling", golden_sampling), ("patch_manager", golden_patch_manager),
                      ("adaptor_targets", golden_adaptor_targets), ("packed_positions", golden_packed_positions),
                      ("ckpt_scripts", golden_ckpt_scripts), ("tp_batch", golden_tp_batch)]:

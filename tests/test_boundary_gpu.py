@@ -85,7 +85,7 @@ def test_decoder_layer_built_by_megatron_matches_the_oracle_forward_and_backward
     out, _ = layer(xh, attention_mask=None, rotary_pos_emb=freqs.to(DEV))
     assert out.shape == (S, 1, CFG["hidden"]) and out.dtype == torch.bfloat16
     e_fwd = rel_l2(out, ref)
-    tol("forward", e_fwd, 1e-2)
+    tol("forward", e_fwd, 3.7e-03)
     (out.float() * w_out.to(DEV).float()).sum().backward()
     names = {"qkv_w": "self_attention.linear_qkv.weight", "qkv_b": "self_attention.linear_qkv.bias",
              "o_w": "self_attention.linear_proj.weight", "fc1_w": "mlp.linear_fc1.weight", "fc2_w": "mlp.linear_fc2.weight",
@@ -97,7 +97,7 @@ def test_decoder_layer_built_by_megatron_matches_the_oracle_forward_and_backward
         assert params[n].grad is not None, n
         errs[k] = rel_l2(params[n].grad, lpo[k].grad)
     _record("layer_" + spec, errs)
-    tol("worst gradient", max(errs.values()), 5e-2)
+    tol("worst gradient", max(errs.values()), 8.6e-03)
 
     # inference call (no autograd): the in-place fast path gives the same values
     with torch.no_grad():
@@ -206,8 +206,8 @@ def test_sequence_parallel_tensor_parallel_layer_matches_the_unsharded_oracle(me
     outs = _run_grid(tp, 1, rank_fn, {"mpu": mpu}, monkeypatch)
     out = torch.cat([outs[(0, t)][0] for t in range(tp)], 0)
     dx = torch.cat([outs[(0, t)][1] for t in range(tp)], 0)
-    tol("out, ref", rel_l2(out, ref), 1e-2)
-    tol("dx, xo.grad", rel_l2(dx, xo.grad), 5e-2)
+    tol("out, ref", rel_l2(out, ref), 4.1e-03)
+    tol("dx, xo.grad", rel_l2(dx, xo.grad), 4.7e-03)
     gs = [outs[(0, t)][2] for t in range(tp)]
     d, qpg, ng = CFG["head_dim"], CFG["heads"] // CFG["kv_groups"], CFG["kv_groups"]
     cat0 = lambda k: torch.cat([g_[k] for g_ in gs], 0)                               # noqa: E731
@@ -221,7 +221,7 @@ def test_sequence_parallel_tensor_parallel_layer_matches_the_unsharded_oracle(me
     halves = [g_["mlp.linear_fc1.weight"].chunk(2, 0) for g_ in gs]
     errs["fc1_w"] = rel_l2(torch.cat([h_[0] for h_ in halves] + [h_[1] for h_ in halves], 0), lpo["fc1_w"].grad)
     _record("sp_tp2_layer", errs)
-    tol("worst gradient", max(errs.values()), 5e-2)
+    tol("worst gradient", max(errs.values()), 9.4e-03)
 
 
 @pytest.mark.parametrize("tp,cp", [(1, 2), (2, 2), (1, 4)])
@@ -294,8 +294,8 @@ def test_context_parallel_layer_trains_through_the_megatron_built_module(megatro
     halves = [g_["mlp.linear_fc1.weight"].chunk(2, 0) for g_ in gs]
     errs["fc1_w"] = rel_l2(torch.cat([h_[0] for h_ in halves] + [h_[1] for h_ in halves], 0), lpo["fc1_w"].grad)
     _record("cp_layer_tp%d_cp%d" % (tp, cp), errs)
-    tol("forward", e_out, 1e-2)
-    tol("worst gradient", max(errs.values()), 5e-2)
+    tol("forward", e_out, 4.0e-03)
+    tol("worst gradient", max(errs.values()), 9.7e-03)
 
 
 def test_embedding_backward_under_sequence_parallelism_reaches_every_vocab_row_and_the_projector(megatron, monkeypatch):
@@ -335,6 +335,6 @@ def test_embedding_backward_under_sequence_parallelism_reaches_every_vocab_row_a
     assert torch.equal(torch.cat([outs[(0, t)][0] for t in range(tp)], 0).cpu(), we.detach().transpose(0, 1).bfloat16())
     for t in range(tp):
         tol("feature gradient on every TP rank", rel_l2(outs[(0, t)][1], fr.grad), 1e-6)               # pure row moves
-    tol("vocab-parallel table gradient", rel_l2(torch.cat([outs[(0, t)][2] for t in range(tp)], 0), wr.grad), 4e-3)
+    tol("vocab-parallel table gradient", rel_l2(torch.cat([outs[(0, t)][2] for t in range(tp)], 0), wr.grad), 1.3e-03)
     hit_other_shard = int((wr.grad[:V // tp].abs().sum(-1) > 0).sum())                # rank 0's rows hit from rank 1's sequence shard
     assert hit_other_shard > 0

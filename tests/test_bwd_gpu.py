@@ -48,7 +48,7 @@ def test_rmsnorm_bwd(ops, rows, cols):
     dw = torch.zeros(cols, dtype=torch.float32, device=DEV)
     dx = ops.rmsnorm_bwd(dy.to(DEV), x.detach().to(DEV), w.detach().to(DEV), 1e-6, dw)
     tol("dx, x.grad", rel_l2(dx, x.grad), 4e-3)
-    tol("dw, w.grad", rel_l2(dw, w.grad), 4e-3)                     # autograd sums bf16 products in bf16 storage
+    tol("dw, w.grad", rel_l2(dw, w.grad), 2.6e-03)                     # autograd sums bf16 products in bf16 storage
 
 
 def test_swiglu_fwd_bwd(ops):
@@ -92,7 +92,7 @@ def test_ce_loss_and_grad(ops):
     (ref * scale).sum().backward()
     loss, dl = ops.ce_loss(logits.to(DEV), labels.to(DEV), scale.to(DEV), want_grad=True)
     torch.testing.assert_close(loss.cpu(), ref.detach(), rtol=1e-5, atol=1e-5)
-    tol("dl, lf.grad", rel_l2(dl, lf.grad), 4e-3)
+    tol("dl, lf.grad", rel_l2(dl, lf.grad), 1.9e-03)
     with pytest.raises(IndexError):
         ops.ce_loss(logits.to(DEV), torch.full((n,), V, dtype=torch.int64, device=DEV))
 
@@ -133,9 +133,9 @@ def test_flash_attn_bwd_single_chunk(ops, S, Hq, Hkv):
     o, lse = ops.flash_attn(qd, kd, vd, causal=True, return_lse=True)
     dq, dk, dv = ops.flash_attn_bwd(qd, kd, vd, o, d_o.to(DEV), lse)
     # P and dS are rounded to bf16 before their MFMAs (as flash-attn does): 1.5e-2 relative L2
-    tol("dv, dv_r", rel_l2(dv, dv_r), 1.5e-2)
-    tol("dq, dq_r", rel_l2(dq, dq_r), 1.5e-2)
-    tol("dk, dk_r", rel_l2(dk, dk_r), 1.5e-2)
+    tol("dv, dv_r", rel_l2(dv, dv_r), 3.5e-03)
+    tol("dq, dq_r", rel_l2(dq, dq_r), 4.1e-03)
+    tol("dk, dk_r", rel_l2(dk, dk_r), 4.0e-03)
 
 
 def test_flash_attn_bwd_mixed_qkv_layout(ops):
@@ -149,9 +149,9 @@ def test_flash_attn_bwd_mixed_qkv_layout(ops):
     ops.flash_attn_bwd(q5, kview, vview, o, d_o, lse, dq5=dmixed[:, :, :, :qpg], dk=dmixed[:, :, :, qpg],
                        dv=dmixed[:, :, :, qpg + 1])
     _, dq_r, dk_r, dv_r = _attn_grads_ref(q5.reshape(1, S, ng * qpg, d).cpu(), kview.cpu(), vview.cpu(), d_o.cpu())
-    tol("dmixed[:, :, :, :qpg].reshape(1, S, ng * qpg, d), dq_r", rel_l2(dmixed[:, :, :, :qpg].reshape(1, S, ng * qpg, d), dq_r), 1.5e-2)
-    tol("dmixed[:, :, :, qpg], dk_r", rel_l2(dmixed[:, :, :, qpg], dk_r), 1.5e-2)
-    tol("dmixed[:, :, :, qpg + 1], dv_r", rel_l2(dmixed[:, :, :, qpg + 1], dv_r), 1.5e-2)
+    tol("dmixed[:, :, :, :qpg].reshape(1, S, ng * qpg, d), dq_r", rel_l2(dmixed[:, :, :, :qpg].reshape(1, S, ng * qpg, d), dq_r), 3.9e-03)
+    tol("dmixed[:, :, :, qpg], dk_r", rel_l2(dmixed[:, :, :, qpg], dk_r), 3.8e-03)
+    tol("dmixed[:, :, :, qpg + 1], dv_r", rel_l2(dmixed[:, :, :, qpg + 1], dv_r), 3.5e-03)
 
 
 @pytest.mark.parametrize("cp,S", [(2, 1024), (4, 2048)])
@@ -179,11 +179,11 @@ def test_flash_attn_bwd_zigzag(ops, cp, S):
         do_l = glue.zigzag_slice(d_o, cp, r).to(DEV)
         o, lse = ops.flash_attn(q_l, k_g, v_g, causal=True, return_lse=True, **geo)
         dq, dk, dv = ops.flash_attn_bwd(q_l, k_g, v_g, o, do_l, lse, **geo)
-        tol("dq, glue.zigzag_slice(dq_r, cp, r)", rel_l2(dq, glue.zigzag_slice(dq_r, cp, r)), 1.5e-2)
+        tol("dq, glue.zigzag_slice(dq_r, cp, r)", rel_l2(dq, glue.zigzag_slice(dq_r, cp, r)), 3.8e-03)
         dk_sum += dk.float().cpu()
         dv_sum += dv.float().cpu()
     # un-zig-zag the gathered layout: buffer rows of rank p = zigzag_slice(., cp, p)
     dk_ref_g = torch.cat([glue.zigzag_slice(dk_r, cp, r) for r in range(cp)], 1)
     dv_ref_g = torch.cat([glue.zigzag_slice(dv_r, cp, r) for r in range(cp)], 1)
-    tol("dk_sum, dk_ref_g", rel_l2(dk_sum, dk_ref_g), 1.5e-2)
-    tol("dv_sum, dv_ref_g", rel_l2(dv_sum, dv_ref_g), 1.5e-2)
+    tol("dk_sum, dk_ref_g", rel_l2(dk_sum, dk_ref_g), 3.8e-03)
+    tol("dv_sum, dv_ref_g", rel_l2(dv_sum, dv_ref_g), 3.6e-03)

@@ -65,7 +65,7 @@ def test_gemv_epilogues(amd, N, K):
     # agrees with the MFMA GEMM on the same row
     if K % 64 == 0:
         big = ops.gemm(xd[None].contiguous(), wd, ops.EPI_BIAS, b.to(DEV))[0]
-        tol("ops.gemv(xd, wd, ops.EPI_BIAS, b.to(DEV)), big", rel_l2(ops.gemv(xd, wd, ops.EPI_BIAS, b.to(DEV)), big), 4e-3)
+        tol("ops.gemv(xd, wd, ops.EPI_BIAS, b.to(DEV)), big", rel_l2(ops.gemv(xd, wd, ops.EPI_BIAS, b.to(DEV)), big), 2.3e-04)
 
 
 def _attn_ref(q, k, v, scale):
@@ -89,7 +89,7 @@ def test_decode_attention_vs_fp32(amd, length, G, qpg):
     assert pm.shape[0] == ops.decode_splits(length)
     ctx = ops.decode_attn_merge(pm, pl, po, True)
     ref = _attn_ref(q.float().cpu(), kv[0, :length].float().cpu(), kv[1, :length].float().cpu(), 1 / math.sqrt(d))
-    tol("ctx, ref", rel_l2(ctx, ref), 4e-3)
+    tol("ctx, ref", rel_l2(ctx, ref), 2.6e-03)
 
 
 def test_decode_attention_sharded_merge_equals_whole(amd):

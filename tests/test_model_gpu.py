@@ -41,7 +41,7 @@ def test_vit_vs_oracle_and_reference_fixture(amd, nl, tag):
     feat = model.project(hid)
     ref = g[tag]
     # (b) bf16 path vs fp32 reference: tolerance = accumulated bf16 rounding over nl layers
-    lim = 2e-2 if nl <= 2 else 5e-2
+    lim = 8.5e-3 if nl <= 2 else 2e-2        # measured 5.4e-3 / 1.3e-2 (the fp32 HF reference)
     tol("hid[:, ::41, ::16], ref['hidden_sub']", rel_l2(hid[:, ::41, ::16], ref["hidden_sub"]), lim)
     tol("feat[:, ::8, ::40], ref['feat_sub']", rel_l2(feat[:, ::8, ::40], ref["feat_sub"]), lim)
     # (a) vs the oracle run with the same per-op bf16 rounding: much tighter
@@ -49,8 +49,8 @@ def test_vit_vs_oracle_and_reference_fixture(amd, nl, tag):
     for lp in p["layers"]:
         x = ovit.vit_layer(x, lp, ocfg)
     of = ovit.vit_project(x, p, ocfg)
-    tol("hid, x", rel_l2(hid, x), (6e-3 if nl <= 2 else 2e-2))
-    tol("feat, of", rel_l2(feat, of), (8e-3 if nl <= 2 else 2.5e-2))
+    tol("hid, x", rel_l2(hid, x), (1.7e-3 if nl <= 2 else 1.1e-2))           # measured 1.1e-3 / 7.0e-3
+    tol("feat, of", rel_l2(feat, of), (4.8e-3 if nl <= 2 else 1.3e-2))         # measured 3.2e-3 / 8.3e-3
 
 
 def test_vit_frame_chunking_and_batch(amd):
@@ -91,7 +91,7 @@ def test_llm_prefill_cp1_vs_oracle(amd, cfgd, S):
     out = model(tokens.to(DEV), None, None, logit_mask=mask.to(DEV))
     assert out.shape == ref.shape
     # bf16 trunk on both sides; differences = fp32 accumulation order + P rounding in attention
-    tol("out, ref", rel_l2(out, ref), 2e-2)
+    tol("out, ref", rel_l2(out, ref), 1.1e-02)
     # indexing: the selected rows are the requested positions in ascending order (masked head ==
     # rows of the full head, SURVEY.md §8c cross-check iii; skinny vs MFMA GEMM differ in
     # accumulation order only, a wrong row would differ by O(1))
@@ -114,7 +114,7 @@ def test_prefill_with_images_cp1(amd):
     feats = ovit.vision_model(ext["images"].cpu(), vp, vcfg)
     ref = ollm.prefill_logits(tokens.cpu(), p, ocfg, [S - 1], {"features": feats, "indices": ext["indices"].cpu()})
     out = amd["gen"].prefill_step(model, tokens, S, ext)
-    tol("out, ref[:, -1]", rel_l2(out, ref[:, -1]), 2.5e-2)
+    tol("out, ref[:, -1]", rel_l2(out, ref[:, -1]), 1.2e-02)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -177,8 +177,8 @@ def test_llm_prefill_context_parallel_vs_cp1(amd, monkeypatch, cp, S):
     outs = _run_ranks(cp, rank_fn, amd, monkeypatch)
     for r in range(cp):
         assert torch.equal(outs[r], outs[0])                  # every rank ends with the same logits
-    tol("outs[0], ref", rel_l2(outs[0], ref), 2e-2)
-    tol("outs[0], single", rel_l2(outs[0], single), 1.5e-2)                   # same math, different tile order
+    tol("outs[0], ref", rel_l2(outs[0], ref), 1.3e-02)
+    tol("outs[0], single", rel_l2(outs[0], single), 1.4e-02)                   # same math, different tile order
 
 
 def test_cp_prefill_with_video_tokens(amd, monkeypatch):
@@ -202,7 +202,7 @@ def test_cp_prefill_with_video_tokens(amd, monkeypatch):
 
     outs = _run_ranks(cp, rank_fn, amd, monkeypatch)
     assert torch.equal(outs[0], outs[1])
-    tol("outs[0], single", rel_l2(outs[0], single), 1.5e-2)
+    tol("outs[0], single", rel_l2(outs[0], single), 1.2e-02)
 
 
 def test_per_rank_frame_loading_gives_the_same_cp_prefill(amd, monkeypatch):
@@ -346,7 +346,7 @@ def test_siglip_400m_vs_oracle(amd, nl, frames):
     ref = ovit.vision_model(images, p, ocfg)                                  # [frames, 256, 5120]
     out = vit(images=images.to(DEV))
     assert out.shape == ref.shape == (frames, 256, 5120)
-    tol("out, ref", rel_l2(out, ref), (1.5e-2 if nl == 2 else 3e-2))
+    tol("out, ref", rel_l2(out, ref), (9e-3 if nl == 2 else 2.4e-2))           # measured 5.9e-3 / 1.54e-2
 
 
 def test_request_to_logits_end_to_end(amd):
@@ -392,4 +392,4 @@ def test_request_to_logits_end_to_end(amd):
     assert torch.equal(ext["images"].cpu(), opre.to_model_dtype(ref_imgs))     # pixels: bit-exact
     feats = ovit.vision_model(opre.to_model_dtype(ref_imgs), vp, vcfg_o)
     ref = ollm.prefill_logits(tokens.cpu(), p, ocfg, [ctx_len - 1], {"features": feats, "indices": ext["indices"].cpu()})[:, -1]
-    tol("out, ref", rel_l2(out, ref), 2e-2)
+    tol("out, ref", rel_l2(out, ref), 1.2e-02)

@@ -28,6 +28,12 @@ lib.load(allow_build=False)
 cfgd = dict(num_layers=2, hidden=1024, heads=8, kv_groups=4, head_dim=128, ffn=2816, vocab=1024)
 S = 2048
 def rel(a, b): return float((a.float() - b.float()).norm() / b.float().norm())
+MEASURED = {}
+def tol(name, value, limit):
+    # recorded next to its limit (rank 0 writes gpurun_out/r03_parity.json at the end): the limits are 1.5 x the values the same
+    # comparisons give on simulated ranks (tests/test_model_gpu.py, tests/test_train_gpu.py) until a >= 2-GPU box has measured them
+    MEASURED[name] = max(MEASURED.get(name, 0.0), float(value))
+    assert value < limit, (name, value, limit)
 g = torch.Generator().manual_seed(7)
 tokens = torch.randint(0, cfgd["vocab"], (1, S), generator=g).to(dev)
 labels = torch.randint(0, cfgd["vocab"], (1, S), generator=g).to(dev)
@@ -50,17 +56,27 @@ ref_gen = decode()
 mpu.initialize_model_parallel()
 assert mpu.get_context_parallel_world_size() == world
 out = generation.prefill_step(model, tokens, S, None, reference_compat=False)
-assert rel(out, ref_logits) < 1e-2, rel(out, ref_logits)
+tol("prefill logits, CP = world vs CP = 1", rel(out, ref_logits), 1.4e-2)
 loss, grads = training.TrainStep(model).forward_backward(tokens, labels, loss_mask)
 training.allreduce_grads(grads)
 assert abs(float(loss) - float(ref_loss)) < 1e-2 * abs(float(ref_loss)), (float(loss), float(ref_loss))
 for k in ("embed", "lm_head", "final_ln"):
-    assert rel(grads[k], ref_grads[k]) < 3e-2, (k, rel(grads[k], ref_grads[k]))
+    tol("gradients, CP = world vs CP = 1", rel(grads[k], ref_grads[k]), 2e-2)
 for gl, rl in zip(grads["layers"], ref_grads["layers"]):
     for k in rl:
-        assert rel(gl[k], rl[k]) < 3e-2, (k, rel(gl[k], rl[k]))
+        tol("gradients, CP = world vs CP = 1", rel(gl[k], rl[k]), 2e-2)
 gen = decode()
 assert torch.equal(gen.cpu(), ref_gen.cpu())
+if rank == 0:
+    import json
+    path = os.path.join(os.environ["VITA_ROOT"], "gpurun_out", "r03_parity.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[f"test_multigpu_gpu.py::real_rccl_world{world}"] = MEASURED
+        json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+    except (OSError, ValueError):
+        pass
 dist.barrier()
 dist.destroy_process_group()
 print("OK", rank)

@@ -251,7 +251,7 @@ def test_gemm_skinny(ops, M):
     out = ops.gemm_skinny(a.to(DEV), w.to(DEV), out_f32=True)
     torch.testing.assert_close(out.cpu(), ref, rtol=1e-4, atol=1e-4)
     outb = ops.gemm_skinny(a.to(DEV), w.to(DEV))
-    tol("outb, ref", rel_l2(outb, ref), 4e-3)
+    tol("outb, ref", rel_l2(outb, ref), 2.5e-03)
 
 
 # ---------------------------------------------------------------------------------------------
@@ -275,7 +275,7 @@ def test_flash_attention_single_chunk(ops, S, Hq, Hkv, D, causal):
     ref = _attn_ref(q, k, v, causal)
     out, lse = ops.flash_attn(q.to(DEV), k.to(DEV), v.to(DEV), causal=causal, return_lse=True)
     # P is rounded to bf16 before PV (as flash-attn / TE do): tolerance 1e-2 relative L2, 3e-2 abs
-    tol("out, ref", rel_l2(out, ref), 1e-2)
+    tol("out, ref", rel_l2(out, ref), 3.4e-03)
     assert float((out.cpu().float() - ref).abs().max()) < 3e-2
     # lse against fp32 math
     sc = torch.einsum("bqhd,bkhd->bhqk", q.float(), k.float().repeat_interleave(Hq // Hkv, 2)) / math.sqrt(D)
@@ -293,7 +293,7 @@ def test_flash_attention_forced_rescale(ops):
     k[0, 700] = (q[0, 900, 2].float() * 3).bfloat16()       # huge score for (row 900, key 700)
     ref = _attn_ref(q, k, v, True)
     out = ops.flash_attn(q.to(DEV), k.to(DEV), v.to(DEV), causal=True)
-    tol("out, ref", rel_l2(out, ref), 1e-2)
+    tol("out, ref", rel_l2(out, ref), 3.0e-03)
     assert float((out.cpu().float() - ref).abs().max()) < 5e-2
 
 
@@ -306,7 +306,7 @@ def test_flash_attention_mixed_qkv_views(ops):
     vview = mixed[:, :, :, qpg + 1]
     out = ops.flash_attn(q5, kview, vview, causal=True)
     ref = _attn_ref(q5.reshape(1, S, ng * qpg, d).cpu(), kview.cpu(), vview.cpu(), True)
-    tol("out, ref", rel_l2(out, ref), 1e-2)
+    tol("out, ref", rel_l2(out, ref), 3.1e-03)
 
 
 @pytest.mark.parametrize("cp,S", [(2, 2048), (4, 4096), (8, 4096)])
@@ -331,7 +331,7 @@ def test_flash_attention_zigzag_chunks(ops, cp, S):
         out = ops.flash_attn(q_l, k_g, v_g, causal=True, chunk_len=C, q_chunk_gid=[r, 2 * cp - 1 - r],
                              kv_chunk_gid=kv_gid, kv_chunk_row=kv_row)
         ref = glue.zigzag_slice(full, cp, r)
-        tol("out, ref", rel_l2(out, ref), 1e-2)
+        tol("out, ref", rel_l2(out, ref), 3.5e-03)
         assert float((out.cpu().float() - ref).abs().max()) < 3e-2
 
 
@@ -349,7 +349,7 @@ def test_vit_front_back_kernels(ops):
     pe = ops.gemm(patches, w.to(DEV), ops.EPI_BIAS, p["conv_b"].to(DEV))
     x = ops.vit_assemble(pe, p["cls"].to(DEV).view(-1), p["pos"].to(DEV), 2, 1024)
     xr = ovit.vit_embed(images, p, cfg)
-    tol("x, xr", rel_l2(x, xr), 3e-3)
+    tol("x, xr", rel_l2(x, xr), 4.4e-05)
     # pixel-shuffle + LayerNorm
     y = ops.pixel_shuffle_ln(xr.to(DEV), p["proj_ln_w"].to(DEV), p["proj_ln_b"].to(DEV), 32, True, 1e-5)
     t = glue.pixel_shuffle(xr[:, 1:].reshape(2, 32, 32, -1), 0.5).reshape(2, 256, 4096)
@@ -379,7 +379,7 @@ def test_flash_attn_packed_sequences_fwd_bwd(ops, S, cu):
     assert seg_start.tolist() == [max(c for c in cu_full.tolist() if c <= i) for i in range(S)]
     qd, kd, vd = (t.permute(1, 0, 2, 3).contiguous().to(DEV) for t in (q, k, v))          # [1, S, H, D]
     out, lse = ops.flash_attn(qd, kd, vd, causal=True, return_lse=True, seg_start=seg_start)
-    tol("out.reshape(S, -1), ref.detach().reshape(S, -1)", rel_l2(out.reshape(S, -1), ref.detach().reshape(S, -1)), 1.2e-2)
+    tol("out.reshape(S, -1), ref.detach().reshape(S, -1)", rel_l2(out.reshape(S, -1), ref.detach().reshape(S, -1)), 3.2e-03)
     # rows that start a sample attend to themselves only: output == their own V (GQA: head h uses kv head h // 5)
     for r in [c for c in cu_full.tolist()[:-1]]:
         want = vd[0, r].repeat_interleave(Hq // Hkv, dim=0)
@@ -387,9 +387,9 @@ def test_flash_attn_packed_sequences_fwd_bwd(ops, S, cu):
     if S % 128 == 0:
         dod = d_o.view(S, Hq, D)[None].contiguous().to(DEV)
         dq, dk, dv = ops.flash_attn_bwd(qd, kd, vd, out, dod, lse, seg_start=seg_start, seg_end=seg_end)
-        tol("dq[0], qf.grad[:, 0]", rel_l2(dq[0], qf.grad[:, 0]), 2.5e-2)
-        tol("dk[0], kf.grad[:, 0]", rel_l2(dk[0], kf.grad[:, 0]), 2.5e-2)
-        tol("dv[0], vf.grad[:, 0]", rel_l2(dv[0], vf.grad[:, 0]), 2.5e-2)
+        tol("dq[0], qf.grad[:, 0]", rel_l2(dq[0], qf.grad[:, 0]), 3.8e-03)
+        tol("dk[0], kf.grad[:, 0]", rel_l2(dk[0], kf.grad[:, 0]), 3.8e-03)
+        tol("dv[0], vf.grad[:, 0]", rel_l2(dv[0], vf.grad[:, 0]), 3.5e-03)
 
 
 def test_gemm_siglip_epilogues(ops):
@@ -429,7 +429,7 @@ def test_logit_scale_and_softcap(ops, scale, cap):
     glue.logit_postprocess(xf, scale or None, cap or None).backward(torch.ones_like(xf))
     gr = torch.ones(5, 152064).bfloat16().to(DEV)
     ops.logit_postprocess_bwd_(out.to(DEV), gr, scale, cap)
-    tol("gr, xf.grad", rel_l2(gr, xf.grad), 1e-2)
+    tol("gr, xf.grad", rel_l2(gr, xf.grad), 6.2e-03)
 
 
 # ---------------------------------------------------------------------------------------------

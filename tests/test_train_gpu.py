@@ -60,7 +60,7 @@ def test_train_step_cp1_vs_autograd(amd, S, n_ans):
     loss, g = step.forward_backward(tokens.to(DEV), labels.to(DEV), loss_mask.to(DEV))
     assert abs(float(loss) - float(loss_ref)) < 2e-2 * abs(float(loss_ref))
     # bf16 chain on both sides; the sweep rounds at the same points as autograd does
-    _check_grads(g, g_ref, 4e-2)
+    _check_grads(g, g_ref, 1.8e-2)
 
 
 def test_train_step_with_logit_scale_and_softcap(amd):
@@ -74,7 +74,7 @@ def test_train_step_with_logit_scale_and_softcap(amd):
     model = G.GPTVLModel.from_oracle_layout(G.GPTConfig(**SMALL, output_multiplier_scale=3.0, output_logit_softcapping=5.0), p, None, DEV)
     loss, g_ = amd["train"].TrainStep(model).forward_backward(tokens.to(DEV), labels.to(DEV), loss_mask.to(DEV))
     assert abs(float(loss) - float(loss_ref)) < 2e-2 * abs(float(loss_ref))
-    _check_grads(g_, g_ref, 5e-2)
+    _check_grads(g_, g_ref, 1.8e-2)
     plain_ref, _ = otrain.loss_and_grads(tokens, labels, loss_mask, p, ocfg)
     assert abs(float(plain_ref) - float(loss_ref)) > 1e-3          # the options really change the loss
 
@@ -156,7 +156,7 @@ def test_train_step_context_parallel(amd, monkeypatch):
     outs = _run_ranks(cp, rank_fn, amd, monkeypatch)
     assert float(outs[0][0]) == float(outs[1][0])
     assert abs(float(outs[0][0]) - float(loss_ref)) < 2e-2 * abs(float(loss_ref))
-    _check_grads(outs[0][1], g_ref, 5e-2)
+    _check_grads(outs[0][1], g_ref, 1.8e-2)
 
 
 def test_train_step_with_projector(amd):
@@ -200,9 +200,9 @@ def test_train_step_with_projector(amd):
     ext_d = {"images": images.to(DEV), "indices": ext["indices"].to(DEV)}
     loss, g = amd["train"].TrainStep(model).forward_backward(tokens.to(DEV), labels.to(DEV), loss_mask.to(DEV), ext_d)
     assert abs(float(loss) - float(loss_ref)) < 2e-2 * abs(float(loss_ref))
-    _check_grads(g, g_ref, 5e-2)
+    _check_grads(g, g_ref, 1.8e-2)
     for k in proj_keys:
-        tol("g['projector'][k], g_ref[k]", rel_l2(g["projector"][k], g_ref[k]), 6e-2)
+        tol("g['projector'][k], g_ref[k]", rel_l2(g["projector"][k], g_ref[k]), 1.6e-02)
 
 
 def test_train_step_cp_with_a_text_only_rank(amd, monkeypatch):
@@ -257,9 +257,9 @@ def test_train_step_cp_with_a_text_only_rank(amd, monkeypatch):
     assert seen == {0: True, 1: False}                                          # rank 1 really is text-only
     assert float(outs[0][0]) == float(outs[1][0])
     assert abs(float(outs[0][0]) - float(loss_ref)) < 2e-2 * abs(float(loss_ref))
-    _check_grads(outs[0][1], g_ref, 5e-2)
+    _check_grads(outs[0][1], g_ref, 1.8e-2)
     for k in proj_keys:
-        tol("outs[1][1]['projector'][k], g_ref[k]", rel_l2(outs[1][1]["projector"][k], g_ref[k]), 6e-2)
+        tol("outs[1][1]['projector'][k], g_ref[k]", rel_l2(outs[1][1]["projector"][k], g_ref[k]), 1.4e-02)
 
 
 def test_train_step_packed_samples_vs_autograd(amd):
@@ -280,7 +280,7 @@ def test_train_step_packed_samples_vs_autograd(amd):
     step = amd["train"].TrainStep(model)
     loss, g = step.forward_backward(tokens.to(DEV), labels.to(DEV), loss_mask.to(DEV), position_ids=position_ids.to(DEV))
     assert abs(float(loss) - float(loss_ref)) < 2e-2 * abs(float(loss_ref))
-    _check_grads(g, g_ref, 4e-2)
+    _check_grads(g, g_ref, 1.8e-2)
     from long_vita_amd import training_utils
     assert training_utils.get_position_ids() is None                  # the global does not leak out of the step
 
@@ -382,7 +382,7 @@ def test_train_step_tensor_parallel(amd, monkeypatch, tp, cp, n_rec):
     assert len(losses) == 1                                    # every rank reports the same loss
     assert abs(losses.pop() - float(loss_ref)) < 2e-2 * abs(float(loss_ref))
     full = tpar.unshard_llm_grads([outs[(0, ti)][1] for ti in range(tp)], full_cfg, tp)
-    _check_grads(full, g_ref, 5e-2)
+    _check_grads(full, g_ref, 1.8e-2)
     # replicated parameters get the same gradients on the TP ranks (fp32 atomics: equal up to summation order)
     tol("outs[(0, 0)][1]['final_ln'], outs[(0, 1)][1]['final_ln']", rel_l2(outs[(0, 0)][1]["final_ln"], outs[(0, 1)][1]["final_ln"]), 1e-5)
     tol("outs[(0, 0)][1]['embed'], outs[(0, 1)][1]['embed']", rel_l2(outs[(0, 0)][1]["embed"], outs[(0, 1)][1]["embed"]), 1e-5)
@@ -407,7 +407,7 @@ def test_prefill_tensor_parallel(amd, monkeypatch):
 
     outs = _run_grid(2, 1, rank_fn, amd, monkeypatch)
     assert torch.equal(outs[(0, 0)], outs[(0, 1)]) and outs[(0, 0)].shape == single.shape
-    tol("outs[(0, 0)], single", rel_l2(outs[(0, 0)], single), 1.5e-2)
+    tol("outs[(0, 0)], single", rel_l2(outs[(0, 0)], single), 1.3e-02)
 
 
 @pytest.mark.parametrize("n_rec,cp", [(0, 1), (1, 1), (0, 2)])
