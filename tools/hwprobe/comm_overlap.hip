@@ -16,9 +16,23 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 
+// HEAVY = RCCL's real footprint.  Read from this image's librccl.so (gfx950 code object, llvm-readelf --notes):
+// rcclGenericKernel<1|2|4, ...> — the one kernel behind every collective — is 256 threads with .vgpr_count 261 / 278 / 280
+// (VGPR + AGPR; allocation granule 8) and 19744 B of LDS, i.e. ONE wave per SIMD: a channel cannot share a CU with one of this
+// library's 448-to-512-register workgroups and has to wait for a whole CU.  The HEAVY variant pins the same 280 registers
+// (v255 + a23 clobbered) and the same LDS; the light one (a dozen registers) can slip into the registers an attention workgroup
+// leaves free.
+template <bool HEAVY>
 __global__ __launch_bounds__(256) void channel_copy_kernel(uint4* __restrict__ dst, const uint4* __restrict__ src, int64_t n16,
                                                            unsigned long long* __restrict__ stamps, unsigned long long min_ticks) {
   const unsigned long long t0 = wall_clock64();
+  if (HEAVY) {
+    __shared__ unsigned lds[19744 / 4];
+    asm volatile("" ::: "v255", "a23");
+    lds[threadIdx.x] = (unsigned)t0;
+    __syncthreads();
+    if (lds[(threadIdx.x + 1) & 255] == 0xdeadbeefu && min_ticks == 12345) stamps[0] = 0;     // keeps the LDS allocation alive
+  }
   const int64_t stride = (int64_t)gridDim.x * blockDim.x;
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n16; i += stride) dst[i] = src[i];
   __syncthreads();
@@ -36,9 +50,13 @@ __global__ __launch_bounds__(256) void channel_copy_kernel(uint4* __restrict__ d
 __global__ void stamp_kernel(unsigned long long* out) { *out = wall_clock64(); }
 
 extern "C" int probe_channel_copy(void* dst, const void* src, int64_t bytes, int n_channels, void* stamps, unsigned long long min_ticks,
-                                  void* stream) {
-  hipLaunchKernelGGL(channel_copy_kernel, dim3((unsigned)n_channels), dim3(256), 0, (hipStream_t)stream, (uint4*)dst, (const uint4*)src,
-                     bytes / 16, (unsigned long long*)stamps, min_ticks);
+                                  int heavy, void* stream) {
+  if (heavy)
+    hipLaunchKernelGGL(channel_copy_kernel<true>, dim3((unsigned)n_channels), dim3(256), 0, (hipStream_t)stream, (uint4*)dst,
+                       (const uint4*)src, bytes / 16, (unsigned long long*)stamps, min_ticks);
+  else
+    hipLaunchKernelGGL(channel_copy_kernel<false>, dim3((unsigned)n_channels), dim3(256), 0, (hipStream_t)stream, (uint4*)dst,
+                       (const uint4*)src, bytes / 16, (unsigned long long*)stamps, min_ticks);
   return (int)hipGetLastError();
 }
 

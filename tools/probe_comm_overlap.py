@@ -7,7 +7,9 @@ attention?  And a copy engine (SDMA) instead?
 
 Stream A: 4 attention launches (the 4 kv-head splits of one layer, ~5 ms each).  Stream B, per scenario, 4 messages of 16.8 MB (one
 rank's K/V shard of one split):
-  cu<N>/first   N-channel CU copy kernels (tools/hwprobe/comm_overlap.hip) enqueued BEFORE the attention (forward_cp's order: all
+  rccl280-...   the same channel kernels with RCCL's REAL footprint (rcclGenericKernel of this image's librccl.so: 256 threads,
+                280 registers, 19.7 KB LDS = one wave per SIMD, so a channel needs a CU with no attention workgroup on it);
+  cu<N>/first   N-channel light (12-register) CU copy kernels (tools/hwprobe/comm_overlap.hip) enqueued BEFORE the attention (forward_cp's order: all
                 gathers are issued up front);
   cu<N>/late    the same enqueued 2 ms AFTER the first attention launch (the chip is full of attention workgroups);
   ...paced      each channel stays resident 0.4 ms per message (a transfer paced by an xGMI link, not by HBM);
@@ -42,7 +44,7 @@ def say(s):
 
 lib.load(allow_build=False)
 P = C.CDLL(os.path.join(ROOT, "tools", "hwprobe", "bin", "libcomm_overlap.so"))
-P.probe_channel_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_uint64, C.c_void_p]
+P.probe_channel_copy.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p, C.c_uint64, C.c_int, C.c_void_p]
 P.probe_stamp.argtypes = [C.c_void_p, C.c_void_p]
 P.probe_memcpy_async.argtypes = [C.c_void_p, C.c_void_p, C.c_int64, C.c_int, C.c_void_p]
 
@@ -94,7 +96,7 @@ say(f"clock: {TICKS_PER_MS / 1e3:.2f} MHz; message = {MSG / 1e6:.1f} MB x {N_MSG
     f"{hg * G * s_l // 256} workgroups each (S_l = {s_l}, {2 * cp} key chunks of {c})")
 
 
-def run(kind, n_ch=0, late=False, pace_ms=0.0):
+def run(kind, n_ch=0, late=False, pace_ms=0.0, heavy=0):
     """One scenario -> dict(attn_ms, msgs=[(start_ms, end_ms) relative to the attention's first instruction])."""
     stamps_b.zero_()
     ea, eb0, eb1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -108,7 +110,7 @@ def run(kind, n_ch=0, late=False, pace_ms=0.0):
             for j in range(N_MSG):
                 if kind == "cu":
                     P.probe_channel_copy(dst[j].data_ptr(), src[j].data_ptr(), MSG, n_ch, stamps_b[j].data_ptr(),
-                                         int(pace_ms * TICKS_PER_MS), B.cuda_stream)
+                                         int(pace_ms * TICKS_PER_MS), heavy, B.cuda_stream)
                 elif kind == "d2d":
                     P.probe_memcpy_async(dst[j].data_ptr(), src[j].data_ptr(), MSG, 0, B.cuda_stream)
                 elif kind == "h2d":
@@ -178,7 +180,7 @@ for n_ch in (8, 32):
     torch.cuda.synchronize()
     with torch.cuda.stream(B):
         for j in range(N_MSG):
-            P.probe_channel_copy(dst[j].data_ptr(), src[j].data_ptr(), MSG, n_ch, stamps_b[j].data_ptr(), 0, B.cuda_stream)
+            P.probe_channel_copy(dst[j].data_ptr(), src[j].data_ptr(), MSG, n_ch, stamps_b[j].data_ptr(), 0, 0, B.cuda_stream)
     torch.cuda.synchronize()
     st = stamps_b[:, : 2 * n_ch].view(N_MSG, n_ch, 2)
     d = [(int(st[j, :, 1].max()) - int(st[j, :, 0].min())) / TICKS_PER_MS for j in range(N_MSG)]
@@ -189,6 +191,12 @@ for n_ch in (8, 16, 32):
 report("cu16/first paced 0.4 ms", kind="cu", n_ch=16, pace_ms=0.4)
 report("cu16/late paced 0.4 ms", kind="cu", n_ch=16, late=True, pace_ms=0.4)
 report("cu16/late paced 2 ms", kind="cu", n_ch=16, late=True, pace_ms=2.0)
+# the same with RCCL's real footprint (280 registers, 19.7 KB LDS per 256-thread channel: one wave per SIMD, needs a whole CU)
+for n_ch in (16, 32):
+    report(f"rccl280-ch{n_ch}/first", kind="cu", n_ch=n_ch, heavy=1)
+    report(f"rccl280-ch{n_ch}/late", kind="cu", n_ch=n_ch, late=True, heavy=1)
+report("rccl280-ch16/first paced 0.4 ms", kind="cu", n_ch=16, pace_ms=0.4, heavy=1)
+report("rccl280-ch16/late paced 0.4 ms", kind="cu", n_ch=16, late=True, pace_ms=0.4, heavy=1)
 for kind in ("d2d", "h2d", "d2h"):
     report(f"{kind}/first", kind=kind)
     report(f"{kind}/late", kind=kind, late=True)
