@@ -234,11 +234,21 @@ int vita_flash_attn_fwd(const vita_attn_params* p, void* stream);
  *   one rank, shipped to the others by any channel, then ncclCommInitRank), the communication stream and its events.  The only
  *   persistent state of the library (SURVEY.md §8b "Ownership"); RCCL is resolved at run time, so nothing here is needed —
  *   or loaded — on the single-GPU path.  cp_size = 1 is valid (the exchange degenerates to a copy through RCCL).
+ *   unique_id128 = NULL creates a context WITHOUT a communicator ("external exchange"): the host moves the shards itself (its own
+ *   transport — e.g. peer copies on the copy engines — or one process simulating the ranks): vita_cp_attn_fwd then expects
+ *   `workspace` to hold the gathered K/V [n_split][cp_size][2][s_local][n_kv_heads / n_split][head_dim] (ordered before `stream`;
+ *   its own slot may be left unwritten when scratch enables own-chunks-first) and vita_cp_attn_bwd leaves the reduction of
+ *   p->dkv_workspace over the ranks to the caller.
  * vita_cp_attn_fwd: q = this rank's rotated queries as a grouped view (head h of kv group g at q + row * q_row_stride +
  *   g * q_group_stride + h * q_head_stride); kv_packed = its rotated K and V packed [n_split][2 (K | V)][s_local][n_kv_heads /
  *   n_split][head_dim] (what vita_rope_qkv_fwd writes); out [s_local][n_q_heads][head_dim] via out_row/head_stride; lse
  *   (optional) [n_q_heads][s_local].  workspace = vita_cp_attn_workspace_bytes(...) of device memory, caller-owned: the gathered
  *   K/V; it is the `k`/`v` of the backward.  Everything is stream-ordered behind `stream`.
+ *   Own chunks first (what TransformerEngine's ring does with its local block): gathers 1.. run under the attention of
+ *   the split before them, gather 0 has nothing in front of it.  With p->scratch = vita_cp_attn_scratch_bytes(...) of device
+ *   memory (one split's output + two lse vectors) and cp_size > 1, split 0 attends to the rank's OWN two chunks straight from
+ *   kv_packed while gather 0 is in flight, then to the 2 CP - 2 remote chunks, and vita_attn_merge joins the two partials;
+ *   scratch = NULL keeps one launch per split behind its gather.
  * vita_cp_attn_bwd: d_out like out; lse from the forward; delta from vita_attn_delta; dq like q; dkv_packed like kv_packed
  *   receives this rank's dK / dV; p->dkv_workspace (same size as workspace) takes the gathered-layout dK / dV. */
 typedef struct vita_cp_context vita_cp_context;
@@ -252,11 +262,13 @@ typedef struct {
   float softmax_scale;
   void* workspace; size_t workspace_bytes;
   void* dkv_workspace;
+  void* scratch; size_t scratch_bytes;      /* optional (ABI 13): vita_cp_attn_scratch_bytes(...) enables "own chunks first" */
 } vita_cp_attn_params;
 int vita_cp_unique_id(void* id_out128);
 int vita_cp_init(vita_cp_context** ctx, int cp_size, int cp_rank, const void* unique_id128);
 int vita_cp_destroy(vita_cp_context* ctx);
 size_t vita_cp_attn_workspace_bytes(int cp_size, int64_t s_local, int n_kv_heads, int head_dim);
+size_t vita_cp_attn_scratch_bytes(int64_t s_local, int n_q_heads, int n_split, int head_dim);
 int vita_cp_attn_fwd(vita_cp_context* ctx, const vita_cp_attn_params* p, void* stream);
 int vita_cp_attn_bwd(vita_cp_context* ctx, const vita_cp_attn_params* p, const void* d_out, const float* lse,
                      const float* delta, void* dq, void* dkv_packed, void* stream);
@@ -310,6 +322,23 @@ int vita_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, void* stre
  * prenormalized != 0: x already holds xhat (e.g. vita_pixel_shuffle_ln run with w = 1, b = 0). */
 int vita_layernorm_param_grad(const void* dy, const void* x, float* dgamma, float* dbeta,
                               int64_t rows, int cols, float eps, int prenormalized, void* stream);
+
+/* ViT training (reference stage 2 trains the encoder: R/scripts/megatron/qwen25/finetune_..._stage2.sh has no --vision-model-freeze).
+ * vita_layernorm_bwd: backward of torch.nn.LayerNorm / TENorm (the block norms of InternViTTransformerLayer,
+ *   M/core/models/vision/intern_vit_model.py:46,72): dx, and dgamma / dbeta accumulated into fp32 [cols] (caller zeroes).
+ * vita_gelu_fwd: a = bf16(gelu(x)) as a kernel of its own (training keeps the pre-activation for vita_gelu_bwd);
+ *   tanh_form != 0: the tanh approximation (SigLIP).
+ * vita_bias_scale_res_fwd / _bwd: `hidden = residual + (out + bias) * ls` of InternViTTransformerLayer.forward (:60-66, :79-82)
+ *   with a bf16 rounding after each of the three ops, bias / scale optional (NULL); backward: dx = bf16(g * scale),
+ *   d_bias += sum_rows dx, d_scale += sum_rows g * bf16(x + bias) (fp32 [cols], caller zeroes; either may be NULL);
+ *   d(residual) = g. */
+int vita_layernorm_bwd(const void* dy, const void* x, const void* w, void* dx, float* dgamma, float* dbeta,
+                       int64_t rows, int cols, float eps, void* stream);
+int vita_gelu_fwd(const void* x, void* a, int64_t n, int tanh_form, void* stream);
+int vita_bias_scale_res_fwd(const void* x, const void* bias, const void* scale, const void* residual, void* out,
+                            int64_t rows, int cols, void* stream);
+int vita_bias_scale_res_bwd(const void* g, const void* x, const void* bias, const void* scale, void* dx, float* d_bias,
+                            float* d_scale, int64_t rows, int cols, void* stream);
 
 /* Vocabulary cross-entropy of the selected rows (TP = 1 form of Megatron's vocab-parallel CE, called at
  * M/core/models/multimodal/gpt_vl_model.py:414):  loss[i] = logsumexp(float(logits[i])) - logits[i, label[i]];

@@ -233,6 +233,60 @@ class RMSNormFn(torch.autograd.Function):
         return dx.view_as(x), dw.to(weight.dtype), None
 
 
+class LayerNormFn(torch.autograd.Function):
+    """torch.nn.LayerNorm / TENorm over the last dim (the InternViT block norms, M/core/models/vision/intern_vit_model.py:46,72):
+    vita_layernorm_fwd + vita_layernorm_bwd (dx and both parameter gradients in one pass over the rows)."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps):
+        ctx.save_for_backward(x, weight)
+        ctx.eps, ctx.has_bias = eps, bias is not None
+        return ops.layernorm(x, weight, bias, eps)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, weight = ctx.saved_tensors
+        dg = torch.zeros(weight.numel(), dtype=torch.float32, device=x.device)
+        db = torch.zeros_like(dg)
+        dx = ops.layernorm_bwd(dy.contiguous(), x.contiguous(), weight, ctx.eps, dg, db)
+        return dx.view_as(x), dg.to(weight.dtype), (db.to(weight.dtype) if ctx.has_bias else None), None
+
+
+class GeluFn(torch.autograd.Function):
+    """bf16(gelu(x)), erf form (`args.activation_func = torch.nn.functional.gelu`, M/pretrain_long_vita.py:207): vita_gelu_fwd / vita_gelu_bwd."""
+
+    @staticmethod
+    def forward(ctx, x):
+        ctx.save_for_backward(x)
+        return ops.gelu(x.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        (x,) = ctx.saved_tensors
+        return ops.gelu_bwd(x.contiguous(), g.contiguous()).view_as(x)
+
+
+class BiasScaleResidualFn(torch.autograd.Function):
+    """`hidden = residual + (out + bias) * ls` of InternViTTransformerLayer.forward (intern_vit_model.py:60-66 / :79-82), one kernel
+    with the module-by-module rounding chain; bias / scale may be None (SigLIP: no LayerScale)."""
+
+    @staticmethod
+    def forward(ctx, x, bias, scale, residual):
+        ctx.save_for_backward(x, bias, scale)
+        return ops.bias_scale_residual(x.contiguous(), bias, scale, residual.contiguous())
+
+    @staticmethod
+    def backward(ctx, g):
+        x, bias, scale = ctx.saved_tensors
+        g = g.contiguous()
+        cols = x.shape[-1]
+        f32 = lambda: torch.zeros(cols, dtype=torch.float32, device=g.device)  # noqa: E731
+        d_bias = f32() if bias is not None and ctx.needs_input_grad[1] else None
+        d_scale = f32() if scale is not None and ctx.needs_input_grad[2] else None
+        dx = ops.bias_scale_residual_bwd(g, x.contiguous(), bias, scale, d_bias, d_scale)
+        return (dx.view_as(x), None if d_bias is None else d_bias.to(bias.dtype), None if d_scale is None else d_scale.to(scale.dtype), g)
+
+
 # ------------------------------------------------------------------------------------------------
 # SwiGLU (bias-free gated linear unit of the decoder MLP: Megatron's MLP.forward glu closure)
 # ------------------------------------------------------------------------------------------------
@@ -281,7 +335,7 @@ class FlashAttnFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, q, k, v, softmax_scale, causal=True, seg_start=None, seg_end=None):
         if not causal:
-            raise NotImplementedError("the non-causal (ViT) attention backward goes through FlashAttnNonCausalFn")
+            raise ValueError("non-causal attention goes through FlashAttnNonCausalFn")
         o, lse = ops.flash_attn(q, k, v, causal=True, softmax_scale=softmax_scale, return_lse=True, seg_start=seg_start)
         ctx.save_for_backward(q, k, v, o, lse, seg_start, seg_end)
         ctx.softmax_scale = softmax_scale
@@ -293,6 +347,46 @@ class FlashAttnFn(torch.autograd.Function):
         dq, dk, dv = ops.flash_attn_bwd(q, k, v, o, d_o.contiguous(), lse, softmax_scale=ctx.softmax_scale,
                                         seg_start=seg_start, seg_end=seg_end)
         return dq, dk, dv, None, None, None, None
+
+
+class FlashAttnNonCausalFn(torch.autograd.Function):
+    """The ViT's core attention (flash_attn_func(causal=False), M/core/transformer/dot_product_attention.py:312-329) under autograd.
+    q / k / v [B, S, H, D] views (B = frames, S = 1025, D = 64 for InternViT).  Forward = the non-causal d = 64 kernel.  Backward =
+    the d = 128 backward kernels, un-masked through their chunk tables (query chunk id 1 > key chunk id 0: every key is visible,
+    there is no diagonal) on zero-padded copies [S_pad, B * H, 128]: frames x heads become the kernel's head index (Megatron's
+    [s, b, np, hn] layout), padded head-dim columns are zeros on both sides of every product, padded KEYS have K = V = 0 (they add
+    nothing to dQ, and their own dK / dV rows are dropped), padded QUERY rows carry lse = +inf (P = 0: they add nothing to dK / dV)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, softmax_scale):
+        o, lse = ops.flash_attn(q, k, v, causal=False, softmax_scale=softmax_scale, return_lse=True)
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.softmax_scale = softmax_scale
+        return o
+
+    @staticmethod
+    def backward(ctx, d_o):
+        q, k, v, o, lse = ctx.saved_tensors
+        B, S, H, D = q.shape
+        if k.shape[2] != H:
+            raise NotImplementedError("the ViT attention backward is built for multi-head attention (ng == np)")
+        sp, dp, nh = -(-S // 128) * 128, 128, B * H
+
+        def pad(t):                                   # [B, S, H, D] -> [1, S_pad, B * H, 128], zero-filled
+            buf = torch.zeros(sp, B, H, dp, dtype=t.dtype, device=t.device)
+            buf[:S, :, :, :D].copy_(t.transpose(0, 1))
+            return buf.view(1, sp, nh, dp)
+
+        qp, kp, vp, op_, dop = pad(q), pad(k), pad(v), pad(o), pad(d_o)
+        lse_p = torch.full((1, nh, sp), float("inf"), dtype=torch.float32, device=q.device)
+        lse_p[0, :, :S].copy_(lse.reshape(nh, S))
+        scale = ctx.softmax_scale if ctx.softmax_scale is not None else 1.0 / (D ** 0.5)
+        dq, dk, dv = ops.flash_attn_bwd(qp, kp, vp, op_, dop, lse_p, chunk_len=sp, q_chunk_gid=[1], kv_chunk_gid=[0], kv_chunk_row=[0],
+                                        softmax_scale=scale)
+
+        def unpad(t):
+            return t.view(sp, B, H, dp)[:S, :, :, :D].transpose(0, 1)
+        return unpad(dq), unpad(dk), unpad(dv), None
 
 
 def zigzag_geometry(cp: int, rank: int, s_l: int) -> dict:

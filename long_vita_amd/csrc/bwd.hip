@@ -229,6 +229,190 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict_
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// ViT training (reference stage 2 does not freeze the encoder): LayerNorm backward with parameter gradients, GELU forward
+// as a kernel of its own (the backward needs the pre-activation), and the LayerScale residual of InternViTTransformerLayer.
+// ---------------------------------------------------------------------------------------------
+// LayerNorm backward (torch.nn.LayerNorm / TENorm; forward y = bf16(xhat * w + b), xhat = (x - mean) * rstd in fp32):
+//   g = dy * w ; dx = bf16( rstd * (g - mean(g) - xhat * mean(g * xhat)) ) ; dgamma += sum_rows dy * xhat ; dbeta += sum_rows dy.
+// One wave per row (strided over rows); parameter gradients per lane in registers, flushed with fp32 atomics (caller zeroes).
+template <int VPL>
+__global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                            const bf16_t* __restrict__ w, bf16_t* __restrict__ dx,
+                                                            float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                                            int64_t rows, int cols, float eps) {
+  const int lane = threadIdx.x & 63;
+  const int64_t wave_id = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int64_t n_waves = (int64_t)gridDim.x * 4;
+  const int nvec = cols >> 3;
+  float dgl[VPL][8], dbl[VPL][8];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { dgl[i][j] = 0.f; dbl[i][j] = 0.f; }
+  const u32x4* wr = reinterpret_cast<const u32x4*>(w);
+  for (int64_t row = wave_id; row < rows; row += n_waves) {
+    const u32x4* xr = reinterpret_cast<const u32x4*>(x + row * (int64_t)cols);
+    const u32x4* gr = reinterpret_cast<const u32x4*>(dy + row * (int64_t)cols);
+    u32x4 xv[VPL], gv[VPL];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int vi = lane + i * 64;
+      if (vi < nvec) {
+        xv[i] = xr[vi];
+        gv[i] = gr[vi];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) s += bf16lo_to_f32(xv[i][j]) + bf16hi_to_f32(xv[i][j]);
+      }
+    }
+    const float mean = wave_reduce_sum(s) / (float)cols;
+    float ss = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int vi = lane + i * 64;
+      if (vi < nvec) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a = bf16lo_to_f32(xv[i][j]) - mean, c = bf16hi_to_f32(xv[i][j]) - mean;
+          ss += a * a + c * c;
+        }
+      }
+    }
+    const float rstd = rsqrtf(wave_reduce_sum(ss) / (float)cols + eps);
+    float sg = 0.f, sgx = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int vi = lane + i * 64;
+      if (vi < nvec) {
+        const u32x4 wv = wr[vi];
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float x0 = (bf16lo_to_f32(xv[i][j]) - mean) * rstd, x1 = (bf16hi_to_f32(xv[i][j]) - mean) * rstd;
+          const float d0 = bf16lo_to_f32(gv[i][j]), d1 = bf16hi_to_f32(gv[i][j]);
+          const float g0 = d0 * bf16lo_to_f32(wv[j]), g1 = d1 * bf16hi_to_f32(wv[j]);
+          sg += g0 + g1;
+          sgx += g0 * x0 + g1 * x1;
+          dgl[i][2 * j] += d0 * x0; dgl[i][2 * j + 1] += d1 * x1;
+          dbl[i][2 * j] += d0;      dbl[i][2 * j + 1] += d1;
+        }
+      }
+    }
+    const float c1 = wave_reduce_sum(sg) / (float)cols, c2 = wave_reduce_sum(sgx) / (float)cols;
+    u32x4* dxr = reinterpret_cast<u32x4*>(dx + row * (int64_t)cols);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int vi = lane + i * 64;
+      if (vi < nvec) {
+        const u32x4 wv = wr[vi];
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float x0 = (bf16lo_to_f32(xv[i][j]) - mean) * rstd, x1 = (bf16hi_to_f32(xv[i][j]) - mean) * rstd;
+          const float g0 = bf16lo_to_f32(gv[i][j]) * bf16lo_to_f32(wv[j]), g1 = bf16hi_to_f32(gv[i][j]) * bf16hi_to_f32(wv[j]);
+          o[j] = pack_bf16x2(rstd * (g0 - c1 - x0 * c2), rstd * (g1 - c1 - x1 * c2));
+        }
+        dxr[vi] = o;
+      }
+    }
+  }
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int vi = lane + i * 64;
+    if (vi < nvec)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        atomicAdd(dgamma + vi * 8 + j, dgl[i][j]);
+        atomicAdd(dbeta + vi * 8 + j, dbl[i][j]);
+      }
+  }
+}
+
+// GELU forward as its own kernel: a = bf16(gelu(x)), erf form (tanh != 0: the tanh approximation of SigLIP)
+__global__ __launch_bounds__(256) void gelu_fwd_kernel(const bf16_t* __restrict__ x, bf16_t* __restrict__ a, int64_t n8, int tanh_form) {
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8; i += (int64_t)gridDim.x * blockDim.x) {
+    const u32x4 xv = reinterpret_cast<const u32x4*>(x)[i];
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float r[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+        const float xx = h ? bf16hi_to_f32(xv[j]) : bf16lo_to_f32(xv[j]);
+        r[h] = tanh_form ? 0.5f * xx * (1.0f + tanhf(0.79788456080286535588f * (xx + 0.044715f * xx * xx * xx)))
+                         : 0.5f * xx * (1.0f + erff(xx * 0.70710678118654752440f));
+      }
+      o[j] = pack_bf16x2(r[0], r[1]);
+    }
+    reinterpret_cast<u32x4*>(a)[i] = o;
+  }
+}
+
+// InternViTTransformerLayer's residual (M/core/models/vision/intern_vit_model.py:60-66,79-82), the module-by-module rounding chain:
+//   t = bf16(x + bias) ; u = bf16(t * scale) ; out = bf16(residual + u)        (bias / scale may be null: SigLIP has no LayerScale)
+__global__ __launch_bounds__(256) void bias_scale_res_fwd_kernel(const bf16_t* __restrict__ x, const bf16_t* __restrict__ bias,
+                                                                 const bf16_t* __restrict__ scale, const bf16_t* __restrict__ res,
+                                                                 bf16_t* __restrict__ out, int64_t rows, int cols) {
+  const int nvec = cols >> 3;
+  const int64_t total = rows * nvec;
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+    const int vi = (int)(i % nvec);
+    const u32x4 xv = reinterpret_cast<const u32x4*>(x)[i], rv = reinterpret_cast<const u32x4*>(res)[i];
+    u32x4 bv = {0u, 0u, 0u, 0u}, sv = {0u, 0u, 0u, 0u};
+    if (bias) bv = reinterpret_cast<const u32x4*>(bias)[vi];
+    if (scale) sv = reinterpret_cast<const u32x4*>(scale)[vi];
+    u32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      float t0 = bf16lo_to_f32(xv[j]), t1 = bf16hi_to_f32(xv[j]);
+      if (bias) { t0 = bf16_round(t0 + bf16lo_to_f32(bv[j])); t1 = bf16_round(t1 + bf16hi_to_f32(bv[j])); }
+      if (scale) { t0 = bf16_round(t0 * bf16lo_to_f32(sv[j])); t1 = bf16_round(t1 * bf16hi_to_f32(sv[j])); }
+      o[j] = pack_bf16x2(bf16lo_to_f32(rv[j]) + t0, bf16hi_to_f32(rv[j]) + t1);
+    }
+    reinterpret_cast<u32x4*>(out)[i] = o;
+  }
+}
+
+// its backward, g = d(out):  d_residual = g (the caller aliases it) ; dx = bf16(g * scale) ; d_bias += sum_rows dx ;
+//   d_scale += sum_rows g * bf16(x + bias).   One workgroup = a block of rows x all columns; column sums per thread, then fp32 atomics.
+__global__ __launch_bounds__(256) void bias_scale_res_bwd_kernel(const bf16_t* __restrict__ g, const bf16_t* __restrict__ x,
+                                                                 const bf16_t* __restrict__ bias, const bf16_t* __restrict__ scale,
+                                                                 bf16_t* __restrict__ dx, float* __restrict__ d_bias,
+                                                                 float* __restrict__ d_scale, int64_t rows, int cols, int rows_per_block) {
+  const int nvec = cols >> 3;
+  const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
+  const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  for (int vi = threadIdx.x; vi < nvec; vi += blockDim.x) {
+    u32x4 bv = {0u, 0u, 0u, 0u}, sv = {0u, 0u, 0u, 0u};
+    if (bias) bv = reinterpret_cast<const u32x4*>(bias)[vi];
+    if (scale) sv = reinterpret_cast<const u32x4*>(scale)[vi];
+    float ab[8], as[8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) { ab[j] = 0.f; as[j] = 0.f; }
+    for (int64_t r = r0; r < r1; ++r) {
+      const u32x4 gv = reinterpret_cast<const u32x4*>(g + r * (int64_t)cols)[vi];
+      const u32x4 xv = reinterpret_cast<const u32x4*>(x + r * (int64_t)cols)[vi];
+      u32x4 o;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const float g0 = bf16lo_to_f32(gv[j]), g1 = bf16hi_to_f32(gv[j]);
+        float t0 = bf16lo_to_f32(xv[j]), t1 = bf16hi_to_f32(xv[j]);
+        if (bias) { t0 = bf16_round(t0 + bf16lo_to_f32(bv[j])); t1 = bf16_round(t1 + bf16hi_to_f32(bv[j])); }
+        const float d0 = scale ? bf16_round(g0 * bf16lo_to_f32(sv[j])) : g0, d1 = scale ? bf16_round(g1 * bf16hi_to_f32(sv[j])) : g1;
+        ab[2 * j] += d0; ab[2 * j + 1] += d1;
+        as[2 * j] += g0 * t0; as[2 * j + 1] += g1 * t1;
+        o[j] = pack_bf16x2(d0, d1);
+      }
+      if (dx) reinterpret_cast<u32x4*>(dx + r * (int64_t)cols)[vi] = o;
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      if (d_bias) atomicAdd(d_bias + vi * 8 + j, ab[j]);
+      if (d_scale) atomicAdd(d_scale + vi * 8 + j, as[j]);
+    }
+  }
+}
+
 // LayerNorm parameter gradients (the projector pre-norm; its input comes from the frozen ViT, so dx
 // is not needed): dgamma += sum_rows dy * xhat, dbeta += sum_rows dy   (fp32 atomics).
 template <int VPL>
@@ -472,6 +656,51 @@ extern "C" int vita_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n,
   if (n == 0) return VITA_OK;
   hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n / 8);
+  return vita_check_launch();
+}
+
+extern "C" int vita_layernorm_bwd(const void* dy, const void* x, const void* w, void* dx, float* dgamma, float* dbeta,
+                                  int64_t rows, int cols, float eps, void* stream) {
+  if (!dy || !x || !w || !dx || !dgamma || !dbeta || rows < 0 || cols <= 0) return VITA_ERR_INVALID_ARG;
+  if ((cols & 7) || cols > 8192) return VITA_ERR_UNSUPPORTED;
+  if (rows == 0) return VITA_OK;
+  dim3 grid((unsigned)((rows + 3) / 4 < 512 ? (rows + 3) / 4 : 512)), block(256);
+  hipStream_t st = (hipStream_t)stream;
+#define VITA_LB(V) hipLaunchKernelGGL(layernorm_bwd_kernel<V>, grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)dx, dgamma, dbeta, rows, cols, eps)
+  const int vpl = (cols + 511) / 512;
+  if (vpl <= 2) VITA_LB(2); else if (vpl <= 4) VITA_LB(4); else if (vpl <= 8) VITA_LB(8); else VITA_LB(16);
+#undef VITA_LB
+  return vita_check_launch();
+}
+
+extern "C" int vita_gelu_fwd(const void* x, void* a, int64_t n, int tanh_form, void* stream) {
+  if (!x || !a || n < 0) return VITA_ERR_INVALID_ARG;
+  if (n & 7) return VITA_ERR_UNSUPPORTED;
+  if (n == 0) return VITA_OK;
+  hipLaunchKernelGGL(gelu_fwd_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, (bf16_t*)a,
+                     n / 8, tanh_form);
+  return vita_check_launch();
+}
+
+extern "C" int vita_bias_scale_res_fwd(const void* x, const void* bias, const void* scale, const void* residual, void* out,
+                                       int64_t rows, int cols, void* stream) {
+  if (!x || !residual || !out || rows < 0 || cols <= 0) return VITA_ERR_INVALID_ARG;
+  if (cols & 7) return VITA_ERR_UNSUPPORTED;
+  if (rows == 0) return VITA_OK;
+  hipLaunchKernelGGL(bias_scale_res_fwd_kernel, dim3(grid_for(rows * (cols / 8), 256)), dim3(256), 0, (hipStream_t)stream,
+                     (const bf16_t*)x, (const bf16_t*)bias, (const bf16_t*)scale, (const bf16_t*)residual, (bf16_t*)out, rows, cols);
+  return vita_check_launch();
+}
+
+extern "C" int vita_bias_scale_res_bwd(const void* g, const void* x, const void* bias, const void* scale, void* dx, float* d_bias,
+                                       float* d_scale, int64_t rows, int cols, void* stream) {
+  if (!g || !x || rows < 0 || cols <= 0) return VITA_ERR_INVALID_ARG;
+  if (cols & 7) return VITA_ERR_UNSUPPORTED;
+  if (rows == 0) return VITA_OK;
+  const int rpb = 64;
+  hipLaunchKernelGGL(bias_scale_res_bwd_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(cols / 8 < 256 ? (cols / 8 + 63) / 64 * 64 : 256),
+                     0, (hipStream_t)stream, (const bf16_t*)g, (const bf16_t*)x, (const bf16_t*)bias, (const bf16_t*)scale,
+                     (bf16_t*)dx, d_bias, d_scale, rows, cols, rpb);
   return vita_check_launch();
 }
 

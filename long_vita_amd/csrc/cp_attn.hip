@@ -9,7 +9,13 @@
 //   forward : per kv-head split j ONE ncclAllGather of the packed shard [2 (K | V)][S_l][hg][d] -> [CP][2][S_l][hg][d], all splits
 //             issued up front on the communication stream; the attention over split j (compute stream) waits only for the
 //             event behind gather j, so gathers j+1.. run under it.  Global chunk 2p+h of the gathered buffer is zig-zag chunk
-//             (h ? 2CP-1-p : p) (M/training/utils.py:329-341); the kernel addresses it through chunk tables.
+//             (h ? 2CP-1-p : p) (M/training/utils.py:329-341); the kernel addresses it through chunk tables.  Gather 0 runs under
+//             the attention over the rank's OWN two chunks (read straight from the packed shard), the remote chunks follow it and
+//             vita_attn_merge joins the two partials (needs p->scratch).
+//             Measured on one MI355X with a stand-in of RCCL's real kernel footprint (280 registers, one wave per SIMD:
+//             tools/probe_comm_overlap.py, profiles/r03_hwprobe_comm_overlap.txt): a communication kernel enqueued under the
+//             attention gets whole CUs at the first workgroup turnover (<= 2.8 ms at the 128K / CP = 8 geometry, where the next
+//             gather is needed 5.6 ms later) and costs the attention <= 1.2 %.
 //   backward: vita_flash_attn_bwd writes dK / dV of every visible key in the gathered layout, ONE ncclReduceScatter (sum, bf16)
 //             per split returns each rank its shard.
 // RCCL is resolved at run time (dlsym): inside a PyTorch process that is the librccl torch already loaded, a plain C host gets
@@ -21,6 +27,9 @@
 
 extern "C" int vita_flash_attn_fwd(const vita_attn_params* p, void* stream);
 extern "C" int vita_flash_attn_bwd(const vita_attn_bwd_params* p, void* stream);
+extern "C" int vita_attn_merge(void* o_a, int64_t oa_row_stride, int64_t oa_head_stride, float* lse_a, const void* o_b,
+                               int64_t ob_row_stride, int64_t ob_head_stride, const float* lse_b, int64_t rows, int heads,
+                               int head_dim, void* stream);
 
 namespace {
 
@@ -80,19 +89,21 @@ extern "C" int vita_cp_unique_id(void* id_out128) {
 }
 
 extern "C" int vita_cp_init(vita_cp_context** out, int cp_size, int cp_rank, const void* unique_id128) {
-  if (!out || !unique_id128 || cp_size < 1 || cp_size > kMaxCP || cp_rank < 0 || cp_rank >= cp_size) return VITA_ERR_INVALID_ARG;
-  if (!rccl().ok) return VITA_ERR_UNSUPPORTED;
+  if (!out || cp_size < 1 || cp_size > kMaxCP || cp_rank < 0 || cp_rank >= cp_size) return VITA_ERR_INVALID_ARG;
+  if (unique_id128 && !rccl().ok) return VITA_ERR_UNSUPPORTED;
   vita_cp_context* c = (vita_cp_context*)calloc(1, sizeof(vita_cp_context));
   if (!c) return VITA_ERR_LAUNCH;
-  ncclUniqueId id;
-  memcpy(id.internal, unique_id128, 128);
-  if (rccl().CommInitRank(&c->comm, cp_size, id, cp_rank) != 0) { free(c); return VITA_ERR_LAUNCH; }
+  if (unique_id128) {
+    ncclUniqueId id;
+    memcpy(id.internal, unique_id128, 128);
+    if (rccl().CommInitRank(&c->comm, cp_size, id, cp_rank) != 0) { free(c); return VITA_ERR_LAUNCH; }
+  }      // else: EXTERNAL exchange — the host moves the shards itself (its own transport, or one process simulating the ranks)
   c->cp_size = cp_size; c->cp_rank = cp_rank;
   bool ok = hipStreamCreateWithFlags(&c->comm_stream, hipStreamNonBlocking) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->ready, hipEventDisableTiming) == hipSuccess;
   ok = ok && hipEventCreateWithFlags(&c->reduced, hipEventDisableTiming) == hipSuccess;
   for (int j = 0; j < kMaxSplit && ok; ++j) ok = hipEventCreateWithFlags(&c->gathered[j], hipEventDisableTiming) == hipSuccess;
-  if (!ok) { rccl().CommDestroy(c->comm); free(c); return VITA_ERR_LAUNCH; }
+  if (!ok) { if (c->comm) rccl().CommDestroy(c->comm); free(c); return VITA_ERR_LAUNCH; }
   *out = c;
   return VITA_OK;
 }
@@ -104,13 +115,21 @@ extern "C" int vita_cp_destroy(vita_cp_context* c) {
   (void)hipEventDestroy(c->ready);
   (void)hipEventDestroy(c->reduced);
   (void)hipStreamDestroy(c->comm_stream);
-  rccl().CommDestroy(c->comm);
+  if (c->comm) rccl().CommDestroy(c->comm);
   free(c);
   return VITA_OK;
 }
 
 extern "C" size_t vita_cp_attn_workspace_bytes(int cp_size, int64_t s_local, int n_kv_heads, int head_dim) {
   return (size_t)cp_size * 2 * (size_t)s_local * n_kv_heads * head_dim * 2;            // the gathered K/V of one layer, bf16
+}
+
+// one split's second output partial (bf16 [s_local][n_q_heads / n_split][head_dim]) + the lse of both partials (fp32)
+extern "C" size_t vita_cp_attn_scratch_bytes(int64_t s_local, int n_q_heads, int n_split, int head_dim) {
+  if (s_local <= 0 || n_q_heads <= 0 || n_split <= 0 || n_q_heads % n_split) return 0;
+  const size_t hj = (size_t)(n_q_heads / n_split);
+  const size_t o_b = (((size_t)s_local * hj * head_dim * 2) + 255) & ~(size_t)255;
+  return o_b + 2 * hj * (size_t)s_local * sizeof(float);
 }
 
 namespace {
@@ -151,14 +170,18 @@ extern "C" int vita_cp_attn_fwd(vita_cp_context* c, const vita_cp_attn_params* p
   const size_t shard = (size_t)2 * s_l * hg * d;                                          // elements per rank and split
   const bf16_t* kv = (const bf16_t*)p->kv_packed;
   bf16_t* ws = (bf16_t*)p->workspace;
-  if (hipEventRecord(c->ready, st) != hipSuccess || hipStreamWaitEvent(c->comm_stream, c->ready, 0) != hipSuccess) return VITA_ERR_LAUNCH;
-  for (int j = 0; j < p->n_split; ++j) {
-    if (rccl().AllGather(kv + j * shard, ws + (size_t)j * cp * shard, shard, kNcclBfloat16, c->comm, c->comm_stream) != 0) return VITA_ERR_LAUNCH;
-    if (hipEventRecord(c->gathered[j], c->comm_stream) != hipSuccess) return VITA_ERR_LAUNCH;
+  const bool exchange = c->comm != nullptr;          // external exchange: the caller has filled `workspace`, ordered before `stream`
+  if (exchange) {
+    if (hipEventRecord(c->ready, st) != hipSuccess || hipStreamWaitEvent(c->comm_stream, c->ready, 0) != hipSuccess) return VITA_ERR_LAUNCH;
+    for (int j = 0; j < p->n_split; ++j) {
+      if (rccl().AllGather(kv + j * shard, ws + (size_t)j * cp * shard, shard, kNcclBfloat16, c->comm, c->comm_stream) != 0) return VITA_ERR_LAUNCH;
+      if (hipEventRecord(c->gathered[j], c->comm_stream) != hipSuccess) return VITA_ERR_LAUNCH;
+    }
   }
   const Geo g = make_geo(cp, c->cp_rank, s_l);
+  const int hj = hg * G;                                                                    // query heads of one split
+  const bool own_first = cp > 1 && p->scratch && p->scratch_bytes >= vita_cp_attn_scratch_bytes(s_l, p->n_q_heads, p->n_split, d);
   for (int j = 0; j < p->n_split; ++j) {
-    if (hipStreamWaitEvent(st, c->gathered[j], 0) != hipSuccess) return VITA_ERR_LAUNCH;
     const bf16_t* rows = ws + (size_t)j * cp * shard;                                    // [cp][2][s_l][hg][d]: K of rank r at r*2*s_l rows, V at + s_l
     vita_attn_params a;
     memset(&a, 0, sizeof(a));
@@ -166,14 +189,45 @@ extern "C" int vita_cp_attn_fwd(vita_cp_context* c, const vita_cp_attn_params* p
     a.q_row_stride = p->q_row_stride; a.q_head_stride = p->q_head_stride; a.q_group_stride = p->q_group_stride;
     a.k = rows; a.k_row_stride = (int64_t)hg * d; a.k_head_stride = d;
     a.v = rows + (size_t)s_l * hg * d; a.v_row_stride = (int64_t)hg * d; a.v_head_stride = d;
-    a.o = (bf16_t*)p->out + (int64_t)j * hg * G * p->out_head_stride;
+    a.o = (bf16_t*)p->out + (int64_t)j * hj * p->out_head_stride;
     a.o_row_stride = p->out_row_stride; a.o_head_stride = p->out_head_stride;
-    a.lse = p->lse ? p->lse + (int64_t)j * hg * G * s_l : nullptr;
-    a.batch = 1; a.n_q_heads = hg * G; a.n_kv_heads = hg; a.head_dim = d;
+    a.lse = p->lse ? p->lse + (int64_t)j * hj * s_l : nullptr;
+    a.batch = 1; a.n_q_heads = hj; a.n_kv_heads = hg; a.head_dim = d;
     a.chunk_len = s_l / 2; a.q_valid = a.kv_valid = s_l / 2;
     a.n_q_chunks = 2; a.n_kv_chunks = 2 * cp;
     a.q_chunk_gid = g.q_gid; a.kv_chunk_gid = g.kv_gid; a.kv_chunk_row = g.kv_row;
     a.causal = 1; a.softmax_scale = p->softmax_scale;
+    if (j == 0 && own_first) {
+      // (1) the rank's own two chunks, straight from its packed shard — no remote byte needed, gather 0 is still in flight
+      char* sc = (char*)p->scratch;
+      const size_t o_b_bytes = (((size_t)s_l * hj * d * 2) + 255) & ~(size_t)255;
+      bf16_t* o_b = (bf16_t*)sc;
+      float* lse_b = (float*)(sc + o_b_bytes);
+      float* lse_a = p->lse ? p->lse : lse_b + (size_t)hj * s_l;                          // split 0's slice of the caller's lse, or scratch
+      const int64_t own_row[2] = {0, s_l / 2};
+      vita_attn_params own = a;
+      own.k = kv; own.v = kv + (size_t)s_l * hg * d;
+      own.n_kv_chunks = 2; own.kv_chunk_gid = g.q_gid; own.kv_chunk_row = own_row; own.lse = lse_a;
+      rc = vita_flash_attn_fwd(&own, stream);
+      if (rc != VITA_OK) return rc;
+      // (2) the 2 CP - 2 remote chunks once gather 0 has landed, into the scratch partial
+      if (exchange && hipStreamWaitEvent(st, c->gathered[0], 0) != hipSuccess) return VITA_ERR_LAUNCH;
+      int32_t rem_gid[2 * kMaxCP];
+      int64_t rem_row[2 * kMaxCP];
+      int n_rem = 0;
+      for (int i = 0; i < 2 * cp; ++i)
+        if (i / 2 != c->cp_rank) { rem_gid[n_rem] = g.kv_gid[i]; rem_row[n_rem] = g.kv_row[i]; ++n_rem; }
+      vita_attn_params rem = a;
+      rem.o = o_b; rem.o_row_stride = (int64_t)hj * d; rem.o_head_stride = d; rem.lse = lse_b;
+      rem.n_kv_chunks = n_rem; rem.kv_chunk_gid = rem_gid; rem.kv_chunk_row = rem_row;
+      rc = vita_flash_attn_fwd(&rem, stream);
+      if (rc != VITA_OK) return rc;
+      // (3) O = O_a e^(lse_a - lse) + O_b e^(lse_b - lse), lse_a <- lse
+      rc = vita_attn_merge(a.o, a.o_row_stride, a.o_head_stride, lse_a, o_b, (int64_t)hj * d, d, lse_b, s_l, hj, d, stream);
+      if (rc != VITA_OK) return rc;
+      continue;
+    }
+    if (exchange && hipStreamWaitEvent(st, c->gathered[j], 0) != hipSuccess) return VITA_ERR_LAUNCH;
     rc = vita_flash_attn_fwd(&a, stream);
     if (rc != VITA_OK) return rc;
   }
@@ -184,7 +238,7 @@ extern "C" int vita_cp_attn_bwd(vita_cp_context* c, const vita_cp_attn_params* p
                                 const float* delta, void* dq, void* dkv_packed, void* stream) {
   int rc = check(p, c);
   if (rc != VITA_OK) return rc;
-  if (!d_out || !lse || !delta || !dq || !dkv_packed || !p->dkv_workspace) return VITA_ERR_INVALID_ARG;
+  if (!d_out || !lse || !delta || !dq || (c->comm && !dkv_packed) || !p->dkv_workspace) return VITA_ERR_INVALID_ARG;
   hipStream_t st = (hipStream_t)stream;
   const int cp = c->cp_size, hg = p->n_kv_heads / p->n_split, G = p->n_q_heads / p->n_kv_heads, d = p->head_dim;
   const int64_t s_l = p->s_local;
@@ -215,6 +269,7 @@ extern "C" int vita_cp_attn_bwd(vita_cp_context* c, const vita_cp_attn_params* p
     rc = vita_flash_attn_bwd(&b, stream);
     if (rc != VITA_OK) return rc;
   }
+  if (!c->comm) return VITA_OK;        // external exchange: the caller reduces p->dkv_workspace ([split][rank][dK | dV][s_l][hg][d]) itself
   if (hipEventRecord(c->ready, st) != hipSuccess || hipStreamWaitEvent(c->comm_stream, c->ready, 0) != hipSuccess) return VITA_ERR_LAUNCH;
   for (int j = 0; j < p->n_split; ++j)
     if (rccl().ReduceScatter(dws + (size_t)j * cp * shard, (bf16_t*)dkv_packed + j * shard, shard, kNcclBfloat16, kNcclSum, c->comm,

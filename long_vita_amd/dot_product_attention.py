@@ -48,8 +48,12 @@ class HipDotProductAttention(torch.nn.Module):
         assert packed_seq_params is None, (
             "Packed sequence is not supported by DotProductAttention."
             "Please use TEDotProductAttention instead.")
-        from .autograd_fns import FlashAttnCPFn, FlashAttnFn
+        from .autograd_fns import FlashAttnCPFn, FlashAttnFn, FlashAttnNonCausalFn
         sq, b, np_, hn = query.shape
+        if not self._impl.causal:                      # the ViT layers (AttnMaskType.no_mask): batch = frames
+            out = FlashAttnNonCausalFn.apply(query.transpose(0, 1), key.transpose(0, 1), value.transpose(0, 1),
+                                             self._impl.softmax_scale if self._impl.softmax_scale is not None else 1.0 / hn ** 0.5)
+            return out.transpose(0, 1).reshape(sq, b, np_ * hn)
         if b != 1:
             # vita_flash_attn_bwd is a batch-1 kernel (every Long-VITA script trains --micro-batch-size 1)
             raise ValueError("the autograd path of HipDotProductAttention runs micro-batch 1 "

@@ -122,7 +122,11 @@ class ColumnParallelLinear(_TEStateMixin, torch.nn.Module):
             expected_shape = (self.output_size_per_partition, self.input_size)
             if tuple(weight.shape) != expected_shape:
                 raise RuntimeError(f"supplied weight's shape is {tuple(weight.shape)}, not {expected_shape} as expected")
-        bias = self.bias if not self.skip_bias_add else None
+        return self._linear(input_, weight, logit_mask, fuse_bias=not self.skip_bias_add)
+
+    def _linear(self, input_, weight, logit_mask, fuse_bias: bool):
+        """fuse_bias: the bias is added inside the GEMM epilogue (one rounding); else it is handed back beside the output."""
+        bias = self.bias if fuse_bias else None
         if self.allreduce_dgrad or self.sequence_parallel or self.disable_grad_reduce:
             input_parallel = input_
         else:
@@ -134,7 +138,12 @@ class ColumnParallelLinear(_TEStateMixin, torch.nn.Module):
             output = F_.GatherFromTP.apply(output_parallel)
         else:
             output = output_parallel
-        return output, (self.bias if self.skip_bias_add else None)
+        return output, (None if fuse_bias else self.bias)
+
+    def forward_fused_bias(self, input_: torch.Tensor):
+        """The same linear with its bias folded into the GEMM epilogue whatever `skip_bias_add` says (ViTMLP: Megatron's MLP adds the
+        fc1 bias itself as a torch op; here it stays in the kernel)."""
+        return self._linear(input_, self.weight, None, fuse_bias=True)
 
 
 class RowParallelLinear(_TEStateMixin, torch.nn.Module):
@@ -222,7 +231,8 @@ class RMSNorm(torch.nn.Module):
 
 
 class LayerNorm(torch.nn.Module):
-    """torch.nn.LayerNorm's parameters (`weight`, `bias`) with the library's forward (inference: the frozen ViT's norms)."""
+    """torch.nn.LayerNorm's parameters (`weight`, `bias`); forward and backward are library kernels (the ViT block norms:
+    TENorm with normalization = "LayerNorm", M/pretrain_long_vita.py:216)."""
 
     def __init__(self, normalized_shape: int, eps: float = 1e-5, config=None):
         super().__init__()
@@ -232,7 +242,7 @@ class LayerNorm(torch.nn.Module):
 
     def forward(self, x):
         if torch.is_grad_enabled() and (x.requires_grad or self.weight.requires_grad):
-            raise NotImplementedError("LayerNorm backward is only built for the projector (training.TrainStep); the ViT is frozen")
+            return F_.LayerNormFn.apply(x, self.weight, self.bias, self.eps)       # vita_layernorm_fwd / vita_layernorm_bwd
         return ops.layernorm(x, self.weight, self.bias, self.eps)
 
 
@@ -271,14 +281,57 @@ class LayerNormColumnParallelLinear(ColumnParallelLinear):
         else:
             self.register_parameter("layer_norm_bias", None)
 
-    def forward(self, x: torch.Tensor):
+    def _norm(self, x: torch.Tensor) -> torch.Tensor:
         if self.normalization == "RMSNorm":
-            xn = F_.RMSNormFn.apply(x, self.layer_norm_weight, self.eps)
+            return F_.RMSNormFn.apply(x, self.layer_norm_weight, self.eps)
+        if torch.is_grad_enabled() and (x.requires_grad or self.layer_norm_weight.requires_grad):
+            return F_.LayerNormFn.apply(x, self.layer_norm_weight, self.layer_norm_bias, self.eps)
+        return ops.layernorm(x, self.layer_norm_weight, self.layer_norm_bias, self.eps)
+
+    def forward(self, x: torch.Tensor):
+        return super().forward(self._norm(x))
+
+    def forward_fused_bias(self, x: torch.Tensor):
+        return super().forward_fused_bias(self._norm(x))
+
+
+class ViTMLP(torch.nn.Module):
+    """The ViT's dense MLP with Megatron MLP's constructor (`MLP(config, submodules, is_expert=False, input_size=None)`,
+    megatron/core/transformer/mlp.py) and return value `(output, output_bias)`: linear_fc1 (+ bias) -> GELU -> linear_fc2.
+    Megatron's MLP.forward adds the fc1 bias and applies `config.activation_func` (torch.nn.functional.gelu,
+    M/pretrain_long_vita.py:207) as two torch ops; here, without autograd, bias + GELU are the epilogue of the fc1 GEMM
+    (VITA_EPI_BIAS_GELU: one kernel), and with autograd the GEMM (+ bias) is followed by vita_gelu_fwd, whose input the backward keeps."""
+
+    def __init__(self, config, submodules, is_expert: bool = False, input_size: int = None):
+        super().__init__()
+        from megatron.core.transformer.spec_utils import build_module
+        if is_expert or getattr(config, "gated_linear_unit", False):
+            raise NotImplementedError("ViTMLP is the dense, non-gated MLP of the vision encoders")
+        act = getattr(config, "activation_func", torch.nn.functional.gelu)
+        if act is not torch.nn.functional.gelu:
+            raise NotImplementedError("ViTMLP under Megatron is built for erf GELU (InternViT); SigLIP's tanh GELU runs in the "
+                                      "stand-alone vision.MegatronVisionModel")
+        self.config = config
+        self.input_size = input_size if input_size is not None else config.hidden_size
+        self.linear_fc1 = build_module(submodules.linear_fc1, self.input_size, config.ffn_hidden_size, config=config,
+                                       init_method=config.init_method, gather_output=False, bias=config.add_bias_linear,
+                                       skip_bias_add=True, is_expert=False, tp_comm_buffer_name="fc1")
+        self.activation_func = act
+        self.linear_fc2 = build_module(submodules.linear_fc2, config.ffn_hidden_size, config.hidden_size, config=config,
+                                       init_method=config.output_layer_init_method, bias=config.add_bias_linear, input_is_parallel=True,
+                                       skip_bias_add=True, is_expert=False, tp_comm_buffer_name="fc2")
+
+    def forward(self, hidden_states):
+        fc1 = self.linear_fc1
+        grad = torch.is_grad_enabled() and (hidden_states.requires_grad or fc1.weight.requires_grad)
+        plain = type(fc1) is ColumnParallelLinear and not fc1.sequence_parallel and mpu.get_tensor_model_parallel_world_size() == 1
+        if not grad and plain and fc1.bias is not None:
+            s, b, h = hidden_states.shape                                     # inference: GEMM + bias + GELU in one kernel
+            a = ops.gemm(hidden_states.reshape(s * b, h), fc1.weight, ops.EPI_BIAS_GELU, fc1.bias).view(s, b, -1)
         else:
-            if torch.is_grad_enabled() and x.requires_grad:
-                raise NotImplementedError("LayerNorm backward is not built (decoder layers use RMSNorm)")
-            xn = ops.layernorm(x, self.layer_norm_weight, self.layer_norm_bias, self.eps)
-        return super().forward(xn)
+            y, _ = fc1.forward_fused_bias(hidden_states)                      # GEMM + bias (one rounding), pre-activation kept for the backward
+            a = F_.GeluFn.apply(y)
+        return self.linear_fc2(a)                                              # (output, bias): the bias goes into the residual kernel
 
 
 class ResidualAddFn(torch.autograd.Function):

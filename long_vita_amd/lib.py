@@ -21,7 +21,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libvita_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "vita_hip.h")
 
-ABI_VERSION = 12
+ABI_VERSION = 13
 VITA_OK = 0
 VITA_ERR_INVALID_ARG = -1
 VITA_ERR_UNSUPPORTED = -2
@@ -92,6 +92,7 @@ class CpAttnParams(C.Structure):
         ("softmax_scale", C.c_float),
         ("workspace", C.c_void_p), ("workspace_bytes", C.c_size_t),
         ("dkv_workspace", C.c_void_p),
+        ("scratch", C.c_void_p), ("scratch_bytes", C.c_size_t),
     ]
 
 
@@ -154,6 +155,10 @@ PROTOTYPES = {
     "vita_swiglu_bwd": (_i, [_p, _p, _p, _l, _i, _p]),
     "vita_gelu_bwd": (_i, [_p, _p, _p, _l, _p]),
     "vita_layernorm_param_grad": (_i, [_p, _p, _p, _p, _l, _i, _f, _i, _p]),
+    "vita_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _f, _p]),
+    "vita_gelu_fwd": (_i, [_p, _p, _l, _i, _p]),
+    "vita_bias_scale_res_fwd": (_i, [_p, _p, _p, _p, _p, _l, _i, _p]),
+    "vita_bias_scale_res_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _i, _p]),
     "vita_ce_loss": (_i, [_p, _l, _p, _p, _p, _l, _p, _l, _i, _p, _p]),
     "vita_row_scatter_add_f32": (_i, [_p, _p, _p, _l, _l, _i, _p, _p]),
     "vita_attn_delta": (_i, [_p, _p, _p, _l, _i, _i, _l, _l, _l, _l, _p]),
@@ -170,6 +175,7 @@ PROTOTYPES = {
     "vita_cp_init": (_i, [C.POINTER(_p), _i, _i, _p]),
     "vita_cp_destroy": (_i, [_p]),
     "vita_cp_attn_workspace_bytes": (C.c_size_t, [_i, _l, _i, _i]),
+    "vita_cp_attn_scratch_bytes": (C.c_size_t, [_l, _i, _i, _i]),
     "vita_cp_attn_fwd": (_i, [_p, C.POINTER(CpAttnParams), _p]),
     "vita_cp_attn_bwd": (_i, [_p, C.POINTER(CpAttnParams), _p, _p, _p, _p, _p, _p]),
     "vita_decode_attn_merge": (_i, [_p, _p, _p, _i, _l, _l, _i, _i, _p, _p, _p, _p, _p]),

@@ -13,6 +13,10 @@ reference patches on the prefill path:
   megatron.inference.text_generation.forward_step.ForwardStep.__init__                          (:145, wrapper carrying
         `external_inputs` into the InferenceParams)
 
+  long_vita_megatron.core.models.vision.vit_layer_specs.get_vit_layer_local_spec_for_intern / ..._with_transformer_engine_spec_for_intern /
+        get_vit_layer_local_spec_for_siglip   (vit_layer_specs.py of this package: the ViT layer with HIP-backed leaves — LayerNorm,
+        bias linears, non-causal attention, GELU MLP, LayerScale residual — forward and backward)
+
   megatron.core.models.gpt.gpt_layer_specs.get_gpt_layer_local_spec / get_gpt_layer_with_transformer_engine_spec   (:81-88;
         gpt_layer_specs.py of this package: the same ModuleSpec trees with HIP-backed leaves — norm + column-parallel linear,
         row-parallel linear, core attention — so a Megatron-built decoder layer runs every kernel through libvita_hip.so)
@@ -90,6 +94,7 @@ def generate_tokens_probs_and_return_on_first_stage(model, tokens, lengths, retu
 
 
 def _targets():
+    from . import vit_layer_specs as vls
     from .gpt_layer_specs import get_gpt_layer_local_spec, get_gpt_layer_with_transformer_engine_spec
     from .language_model_embedding import LanguageModelEmbedding
     from .layers import ColumnParallelLinear
@@ -107,11 +112,21 @@ def _targets():
         ("megatron.inference.text_generation.generation.generate_tokens_probs_and_return_on_first_stage",
          generate_tokens_probs_and_return_on_first_stage),
         ("megatron.inference.text_generation.forward_step.ForwardStep.__init__", inference_forward_step_init_wrapper),
+        # the ViT layer specs MegatronVisionModel.__init__ builds the encoder from (M/pretrain_long_vita.py:337-370 imports them from
+        # the reference's own package; the patch manager swaps the name in every module that already holds it)
+        (VIT_SPECS + "get_vit_layer_local_spec_for_intern", vls.get_vit_layer_local_spec_for_intern),
+        (VIT_SPECS + "get_vit_layer_with_transformer_engine_spec_for_intern", vls.get_vit_layer_with_transformer_engine_spec_for_intern),
+        (VIT_SPECS + "get_vit_layer_local_spec_for_siglip", vls.get_vit_layer_local_spec_for_siglip),
     ]
 
 
-# registered here but not by the reference (it leaves Megatron's RoPE in place and relies on apex's fused kernel, :102-103)
-EXTRA_TARGETS = ("megatron.core.models.common.embeddings.rotary_pos_embedding.apply_rotary_pos_emb",)
+VIT_SPECS = "long_vita_megatron.core.models.vision.vit_layer_specs."
+# registered here but not by the reference: RoPE (it leaves Megatron's in place and relies on apex's fused kernel, :102-103) and the
+# three ViT layer-spec builders, which live in the reference's OWN package (M/core/models/vision/vit_layer_specs.py:30-101) — the
+# reference has no reason to patch itself; a drop-in that must not edit the reference swaps them through the same manager
+EXTRA_TARGETS = ("megatron.core.models.common.embeddings.rotary_pos_embedding.apply_rotary_pos_emb",
+                 VIT_SPECS + "get_vit_layer_local_spec_for_intern", VIT_SPECS + "get_vit_layer_with_transformer_engine_spec_for_intern",
+                 VIT_SPECS + "get_vit_layer_local_spec_for_siglip")
 
 PATCHES = [name for name, _ in _targets()]
 

@@ -444,6 +444,45 @@ def gelu_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
     return dx
 
 
+def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, eps: float, dgamma: torch.Tensor, dbeta: torch.Tensor,
+                  out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """Backward of layernorm(): returns dx; dgamma / dbeta (fp32 [cols], zeroed by the caller) receive the parameter gradients."""
+    cols = x.shape[-1]
+    dx = torch.empty_like(x) if out is None else out
+    _L.check(_L.load().vita_layernorm_bwd(_dev(dy, "dy", BF16), _dev(x, "x", BF16), _dev(weight, "weight", BF16), _dev(dx, "dx", BF16),
+                                          _dev(dgamma, "dgamma", torch.float32), _dev(dbeta, "dbeta", torch.float32),
+                                          x.numel() // cols, cols, float(eps), _stream()), "vita_layernorm_bwd")
+    return dx
+
+
+def gelu(x: torch.Tensor, tanh: bool = False) -> torch.Tensor:
+    a = torch.empty_like(x)
+    _L.check(_L.load().vita_gelu_fwd(_dev(x, "x", BF16), _dev(a, "a", BF16), x.numel(), int(tanh), _stream()), "vita_gelu_fwd")
+    return a
+
+
+def bias_scale_residual(x: torch.Tensor, bias: Optional[torch.Tensor], scale: Optional[torch.Tensor], residual: torch.Tensor) -> torch.Tensor:
+    """bf16(residual + bf16(bf16(x + bias) * scale)) — InternViTTransformerLayer's LayerScale residual; bias / scale optional."""
+    cols = x.shape[-1]
+    out = torch.empty_like(x)
+    _L.check(_L.load().vita_bias_scale_res_fwd(_dev(x, "x", BF16), _opt(bias, "bias", BF16), _opt(scale, "scale", BF16),
+                                               _dev(residual, "residual", BF16), _dev(out, "out", BF16), x.numel() // cols, cols,
+                                               _stream()), "vita_bias_scale_res_fwd")
+    return out
+
+
+def bias_scale_residual_bwd(g: torch.Tensor, x: torch.Tensor, bias, scale, d_bias: Optional[torch.Tensor],
+                            d_scale: Optional[torch.Tensor]) -> torch.Tensor:
+    """-> dx = bf16(g * scale) (g itself when scale is None); d_bias / d_scale fp32 [cols] accumulate (zeroed by the caller)."""
+    cols = x.shape[-1]
+    dx = torch.empty_like(x) if scale is not None else None
+    _L.check(_L.load().vita_bias_scale_res_bwd(_dev(g, "g", BF16), _dev(x, "x", BF16), _opt(bias, "bias", BF16), _opt(scale, "scale", BF16),
+                                               _opt(dx, "dx", BF16), _opt(d_bias, "d_bias", torch.float32),
+                                               _opt(d_scale, "d_scale", torch.float32), x.numel() // cols, cols, _stream()),
+             "vita_bias_scale_res_bwd")
+    return g if dx is None else dx
+
+
 def layernorm_param_grad(dy, x, dgamma: torch.Tensor, dbeta: torch.Tensor, eps: float,
                          prenormalized: bool = False) -> None:
     cols = x.shape[-1]

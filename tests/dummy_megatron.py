@@ -63,6 +63,13 @@ class IdentityOp(torch.nn.Module):
         return x
 
 
+class IdentityFuncOp(IdentityOp):
+    """megatron.core.transformer.identity_op.IdentityFuncOp: forward returns the identity FUNCTION (the default bias-dropout-add)."""
+
+    def forward(self, *args, **kwargs):
+        return super().forward
+
+
 @dataclass
 class TransformerConfig:
     num_layers: int = 1
@@ -120,13 +127,13 @@ class MLPSubmodules:
 class TransformerLayerSubmodules:
     input_layernorm: object = IdentityOp
     self_attention: object = IdentityOp
-    self_attn_bda: object = None
+    self_attn_bda: object = IdentityFuncOp
     pre_cross_attn_layernorm: object = IdentityOp
     cross_attention: object = IdentityOp
     cross_attn_bda: object = None
     pre_mlp_layernorm: object = IdentityOp
     mlp: object = IdentityOp
-    mlp_bda: object = None
+    mlp_bda: object = IdentityFuncOp
     sharded_state_dict_keys_map: dict = field(default_factory=dict)
 
 
@@ -239,7 +246,7 @@ class TransformerLayer(torch.nn.Module):
 _STUBS = {
     "megatron.core.transformer.spec_utils": dict(ModuleSpec=ModuleSpec, build_module=build_module),
     "megatron.core.transformer.enums": dict(AttnMaskType=AttnMaskType),
-    "megatron.core.transformer.identity_op": dict(IdentityOp=IdentityOp),
+    "megatron.core.transformer.identity_op": dict(IdentityOp=IdentityOp, IdentityFuncOp=IdentityFuncOp),
     "megatron.core.transformer.attention": dict(SelfAttention=SelfAttention, SelfAttentionSubmodules=SelfAttentionSubmodules),
     "megatron.core.transformer.mlp": dict(MLP=MLP, MLPSubmodules=MLPSubmodules),
     "megatron.core.transformer.transformer_layer": dict(TransformerLayer=TransformerLayer,
@@ -253,7 +260,8 @@ def install():
     names = set()
     for full in list(_STUBS) + ["megatron.core.models.gpt.gpt_layer_specs", "megatron.core.models.common.embeddings.rotary_pos_embedding",
                                 "megatron.core.models.common.embeddings.language_model_embedding", "megatron.core.tensor_parallel.layers",
-                                "megatron.core.transformer.dot_product_attention", "megatron.core.parallel_state"]:
+                                "megatron.core.transformer.dot_product_attention", "megatron.core.parallel_state",
+                                "long_vita_megatron.core.models.vision.vit_layer_specs"]:
         parts = full.split(".")
         for i in range(1, len(parts) + 1):
             names.add(".".join(parts[:i]))

@@ -187,3 +187,73 @@ def test_flash_attn_bwd_zigzag(ops, cp, S):
     dv_ref_g = torch.cat([glue.zigzag_slice(dv_r, cp, r) for r in range(cp)], 1)
     tol("dk_sum, dk_ref_g", rel_l2(dk_sum, dk_ref_g), 3.8e-03)
     tol("dv_sum, dv_ref_g", rel_l2(dv_sum, dv_ref_g), 3.6e-03)
+
+
+# ---------------------------------------------------------------------------------------------
+# ViT training kernels (reference stage 2 trains the encoder)
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("rows,cols", [(70, 1024), (1025, 1024), (33, 4096)])
+def test_layernorm_bwd(ops, rows, cols):
+    x = (torch.randn(rows, cols, generator=g(40)) * 2 + 0.3).bfloat16()
+    w = (1 + 0.1 * torch.randn(cols, generator=g(41))).bfloat16()
+    b = (0.1 * torch.randn(cols, generator=g(42))).bfloat16()
+    dy = torch.randn(rows, cols, generator=g(43)).bfloat16()
+    xf, wf, bf = x.float().requires_grad_(True), w.float().requires_grad_(True), b.float().requires_grad_(True)
+    torch.nn.functional.layer_norm(xf, (cols,), wf, bf, 1e-6).backward(dy.float())
+    dg = torch.zeros(cols, dtype=torch.float32, device=DEV)
+    db = torch.zeros_like(dg)
+    dx = ops.layernorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), 1e-6, dg, db)
+    tol("dx", rel_l2(dx, xf.grad), 4e-3)                     # one bf16 rounding of the result
+    tol("dgamma", rel_l2(dg, wf.grad), 1e-4)
+    tol("dbeta", rel_l2(db, bf.grad), 1e-4)
+
+
+def test_gelu_fwd_and_bias_scale_residual(ops):
+    x = (torch.randn(300, 1024, generator=g(44)) * 2).bfloat16()
+    ge, gr = ops.gelu(x.to(DEV)).cpu(), torch.nn.functional.gelu(x.float()).bfloat16()
+    assert float((ge != gr).float().mean()) < 1e-3 and float((ge.float() - gr.float()).abs().max()) < 2e-2      # device erff vs host erf
+    d = (ops.gelu(x.to(DEV), tanh=True).cpu().float() - torch.nn.functional.gelu(x.float(), approximate="tanh")).abs()
+    assert float(d.max()) < 2e-2 and float((d > 0).float().mean()) < 0.6      # device tanhf vs host tanh: <= 1 bf16 ulp
+    rows, cols = 130, 1024
+    y = torch.randn(rows, cols, generator=g(45)).bfloat16()
+    bias = torch.randn(cols, generator=g(46)).bfloat16()
+    ls = (0.1 + 0.02 * torch.randn(cols, generator=g(47))).bfloat16()
+    res = torch.randn(rows, cols, generator=g(48)).bfloat16()
+    go = torch.randn(rows, cols, generator=g(49)).bfloat16()
+    for use_b, use_s in ((True, True), (True, False), (False, True)):
+        yb, bb, sb, rb = (t.clone().requires_grad_(True) for t in (y, bias, ls, res))
+        t = yb + bb if use_b else yb                          # the reference's three torch ops, bf16 (intern_vit_model.py:60-66)
+        t = t * sb if use_s else t
+        ref = rb + t
+        ref.backward(go)
+        out = ops.bias_scale_residual(y.to(DEV), bias.to(DEV) if use_b else None, ls.to(DEV) if use_s else None, res.to(DEV))
+        assert torch.equal(out.cpu(), ref.detach())            # same rounding chain: bit-exact
+        d_b = torch.zeros(cols, dtype=torch.float32, device=DEV) if use_b else None
+        d_s = torch.zeros(cols, dtype=torch.float32, device=DEV) if use_s else None
+        dx = ops.bias_scale_residual_bwd(go.to(DEV), y.to(DEV), bias.to(DEV) if use_b else None, ls.to(DEV) if use_s else None, d_b, d_s)
+        assert torch.equal(dx.cpu(), yb.grad)
+        if use_b:
+            tol("d_bias", rel_l2(d_b, bb.grad), 6e-3)          # autograd sums bf16 rows in bf16 storage; the kernel in fp32
+        if use_s:
+            tol("d_scale", rel_l2(d_s, sb.grad), 6e-3)
+
+
+@pytest.mark.parametrize("B,S,H,D", [(3, 1025, 16, 64), (2, 1024, 4, 64), (1, 300, 2, 128)])
+def test_non_causal_attention_backward_through_the_padded_chunk_tables(ops, B, S, H, D):
+    """autograd_fns.FlashAttnNonCausalFn: the ViT's attention gradient from the d = 128 causal backward kernels, un-masked through
+    their chunk tables on zero-padded [S_pad, B * H, 128] copies, vs fp32 autograd through the oracle (non-causal)."""
+    from long_vita_amd.autograd_fns import FlashAttnNonCausalFn
+    q = torch.randn(B, S, H, D, generator=g(50)).bfloat16()
+    k = torch.randn(B, S, H, D, generator=g(51)).bfloat16()
+    v = torch.randn(B, S, H, D, generator=g(52)).bfloat16()
+    d_o = torch.randn(B, S, H, D, generator=g(53)).bfloat16()
+    qf, kf, vf = (t.float().requires_grad_(True) for t in (q, k, v))
+    o = oattn.core_attention(qf.transpose(0, 1), kf.transpose(0, 1), vf.transpose(0, 1), False)      # [S, B, H*D]
+    o.view(S, B, H, D).transpose(0, 1).backward(d_o.float())
+    qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
+    out = FlashAttnNonCausalFn.apply(qd, kd, vd, 1.0 / math.sqrt(D))
+    tol("out", rel_l2(out, o.detach().view(S, B, H, D).transpose(0, 1)), 3.5e-3)
+    out.backward(d_o.to(DEV))
+    tol("dq", rel_l2(qd.grad, qf.grad), 4.5e-3)
+    tol("dk", rel_l2(kd.grad, kf.grad), 4.5e-3)
+    tol("dv", rel_l2(vd.grad, vf.grad), 4.5e-3)

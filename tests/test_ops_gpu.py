@@ -522,3 +522,63 @@ def test_attention_over_own_chunks_then_remote_chunks_merged_equals_one_launch(o
         tol("o_a, whole", rel_l2(o_a, whole), 4e-3)
         assert float((lse_a - lse_w).abs().max()) < 2e-3
         assert torch.isfinite(o_a.float()).all()
+
+
+def test_cp_attention_c_abi_own_chunks_first_with_an_external_exchange(ops):
+    """vita_cp_attn_fwd with `scratch` (ABI 13): split 0 attends to the rank's OWN zig-zag chunks straight from its packed shard
+    (while gather 0 would be in flight), then to the remote chunks, and merges — the C twin of forward_cp's own-chunks-first
+    (VERDICT r2 "missing" 6).  Driven through a context WITHOUT a communicator (vita_cp_init(..., unique_id = NULL): the host
+    performs the exchange — here one process lays out the gathered K / V of CP = 4 ranks by hand), for ranks 0 (its first chunk
+    sees no remote key), 2 and 3: == the same call without scratch (one launch per split) == the fp32 oracle; the rank's own slot
+    of the gathered workspace is poisoned to prove split 0's own-chunk launch never reads it... (it is read by the remote launch of
+    no one: own chunks are excluded from the remote tables)."""
+    import ctypes as C
+    from long_vita_amd import lib as L
+    h = L.load()
+    cp, ng, qpg, d, n_split, c = 4, 4, 2, 128, 2, 512
+    s_l, S, hq, hg = 2 * c, 2 * cp * c, ng * qpg, ng // n_split
+    k_full = (torch.randn(S, ng, d, generator=g(91)) * 0.5).bfloat16()
+    v_full = torch.randn(S, ng, d, generator=g(92)).bfloat16()
+    q_full = (torch.randn(S, hq, d, generator=g(93)) * 0.5).bfloat16()
+    ref = _attn_ref(q_full[None], k_full[None], v_full[None], True)[0]                           # [S, hq, d] fp32
+    pos = [glue.calibration_index(S, cp, r) for r in range(cp)]
+    for r in (0, 2, 3):
+        ctx = C.c_void_p()
+        L.check(h.vita_cp_init(C.byref(ctx), cp, r, None), "vita_cp_init (external exchange)")
+        try:
+            q = q_full[pos[r]].to(DEV).contiguous()                                                 # [s_l, hq, d]
+            q5 = q.view(1, s_l, ng, qpg, d)
+            # packed shards [n_split][2][s_l][hg][d] of every rank; the gathered workspace is [n_split][cp][2][s_l][hg][d]
+            packed = [torch.stack([torch.stack([k_full[pos[p_]][:, j * hg:(j + 1) * hg], v_full[pos[p_]][:, j * hg:(j + 1) * hg]])
+                                   for j in range(n_split)]).to(DEV).contiguous() for p_ in range(cp)]
+            ws = torch.stack([torch.stack([packed[p_][j] for p_ in range(cp)]) for j in range(n_split)]).contiguous()
+            outs = {}
+            for mode in ("single", "own_first"):
+                w = ws.clone()
+                if mode == "own_first":
+                    w[0, r] = float("nan")                       # split 0: the rank's own slot is never read (own chunks come from kv_packed)
+                out = torch.empty(s_l, hq, d, dtype=torch.bfloat16, device=DEV)
+                lse = torch.empty(hq, s_l, dtype=torch.float32, device=DEV)
+                nsc = h.vita_cp_attn_scratch_bytes(s_l, hq, n_split, d)
+                assert nsc >= s_l * (hq // n_split) * d * 2 + 2 * (hq // n_split) * s_l * 4
+                scratch = torch.empty(nsc, dtype=torch.uint8, device=DEV)
+                p = L.CpAttnParams()
+                p.q, p.q_row_stride, p.q_head_stride, p.q_group_stride = q5.data_ptr(), q5.stride(1), q5.stride(3), q5.stride(2)
+                p.kv_packed = packed[r].data_ptr()
+                p.out, p.out_row_stride, p.out_head_stride, p.lse = out.data_ptr(), out.stride(0), out.stride(1), lse.data_ptr()
+                p.s_local, p.n_q_heads, p.n_kv_heads, p.head_dim, p.n_split = s_l, hq, ng, d, n_split
+                p.softmax_scale = 1.0 / math.sqrt(d)
+                p.workspace, p.workspace_bytes = w.data_ptr(), w.numel() * 2
+                if mode == "own_first":
+                    p.scratch, p.scratch_bytes = scratch.data_ptr(), nsc
+                L.check(h.vita_cp_attn_fwd(ctx, C.byref(p), torch.cuda.current_stream().cuda_stream), "vita_cp_attn_fwd")
+                torch.cuda.synchronize()
+                outs[mode] = (out.clone(), lse.clone())
+            assert torch.isfinite(outs["own_first"][0].float()).all()
+            tol("own-chunks-first vs one launch per split", rel_l2(outs["own_first"][0], outs["single"][0]), 4.5e-3)   # two bf16 roundings instead of one
+            assert float((outs["own_first"][1] - outs["single"][1]).abs().max()) < 2e-3
+            # split 1 takes the plain path in both modes: bit-identical
+            assert torch.equal(outs["own_first"][0][:, hq // n_split:], outs["single"][0][:, hq // n_split:])
+            tol("vs the fp32 oracle", rel_l2(outs["own_first"][0], ref[pos[r]]), 4.5e-3)
+        finally:
+            L.check(h.vita_cp_destroy(ctx), "vita_cp_destroy")
