@@ -40,6 +40,16 @@ LIMITS = {
     "attn_bwd_S16384_dq": (3.6e-3, 1.3e-2),
     "attn_bwd_S16384_dk": (3.6e-3, 2.4e-2),
     "attn_bwd_S16384_dv": (3.6e-3, 4.0e-2),
+    # r03: against the reference's own bf16 dtype chain (Megatron's unfused attention run in bf16, oracle chain=True) and, for scale,
+    # that chain against fp32 math.  Measured: forward HIP-vs-chain 2.08e-3 / 2.18e-3 (16K / 128K) where chain-vs-exact is 1.77e-3 /
+    # 1.83e-3 and HIP-vs-exact 1.19e-3 — the reference's chain is FURTHER from fp32 math than this kernel is; backward HIP-vs-chain
+    # 5.2e-3 / 5.5e-3 / 4.8e-3 (dq / dk / dv), chain-vs-exact 4.6e-3 / 5.0e-3 / 4.3e-3, HIP-vs-exact 2.4e-3.
+    "attn_fwd_S16384_vs_chain": (3.3e-3, 2.4e-2), "attn_fwd_S131072_vs_chain": (3.3e-3, 2.4e-2),
+    "attn_fwd_S16384_chain_vs_exact": (2.8e-3, 2.2e-2), "attn_fwd_S131072_chain_vs_exact": (2.8e-3, 2.2e-2),
+    "attn_bwd_S16384_dq_vs_chain": (7.9e-3, 2.4e-2), "attn_bwd_S16384_dk_vs_chain": (8.3e-3, 4.7e-2),
+    "attn_bwd_S16384_dv_vs_chain": (7.2e-3, 9.4e-2),
+    "attn_bwd_S16384_dq_chain_vs_exact": (7.0e-3, 2.1e-2), "attn_bwd_S16384_dk_chain_vs_exact": (7.5e-3, 3.1e-2),
+    "attn_bwd_S16384_dv_chain_vs_exact": (6.4e-3, 5.5e-2),
 }
 
 
@@ -244,7 +254,9 @@ def test_prefill_48_layers_full_width_16k(ops, std):
            note="48-layer full-width text prefill, 64 sampled logit rows; exact = fp32 activations over the same bf16 weights, "
                 "chain = the reference's bf16 rounding chain (oracle functions as torch ops on the GPU)")
     assert e_hip < 1.25 * e_chain + 1e-3, (e_hip, e_chain)
-    assert e_pair < 2.5 * e_chain + 1e-3, (e_pair, e_chain)
+    # measured (profiles/r03_parity.json): std 0.02: HIP 9.7e-2, chain 1.32e-1 from exact, 1.18e-1 from each other (top-1 agreement with
+    # exact: HIP 83 %, chain 73 %); std 0.01 (the reference's init): HIP 1.93e-2, chain 1.93e-2, pair 2.2e-2 (top-1 95 % / 95 %)
+    assert e_pair < 1.5 * e_chain + 1e-3, (e_pair, e_chain)
 
 
 def _group_attn(ocfg, S, chain):
@@ -305,7 +317,11 @@ def test_full_width_decoder_layer_forward_and_every_gradient_at_16k(ops):
         assert r["hip_vs_chain"] < LAYER_LIMITS.get(k, 3e-2), (k, r)
 
 
-LAYER_LIMITS = {}
+# HIP vs the reference's bf16 chain, per tensor, 1.5 x the values measured on the MI355X (profiles/r03_parity.json): out 6.8e-3,
+# dx 8.8e-3, qkv_w 1.30e-2, qkv_b 7.6e-3, o_w 1.27e-2, fc1_w 6.5e-3, fc2_w 6.7e-3, ln1 1.31e-2, ln2 6.9e-3 (the chain itself is
+# 7.5e-3 .. 1.8e-2 from fp32 math on the same tensors, the HIP path 6.8e-3 .. 1.5e-2)
+LAYER_LIMITS = {"out": 1.02e-2, "dx": 1.32e-2, "qkv_w": 1.95e-2, "qkv_b": 1.15e-2, "o_w": 1.91e-2, "fc1_w": 9.8e-3, "fc2_w": 1.01e-2,
+                "ln1": 1.97e-2, "ln2": 1.03e-2}
 
 
 def test_vit_scatter_layer0_at_128k_with_506_frames(ops):
@@ -374,4 +390,6 @@ def test_vit_scatter_layer0_at_128k_with_506_frames(ops):
         assert r["hip_vs_chain"] < HEADLINE_LIMITS.get(k_, 5e-2), (k_, r)
 
 
-HEADLINE_LIMITS = {}
+# measured: feats 8.30e-3, embed 8.29e-3, layer0 1.05e-2 (HIP vs chain); chain vs exact 1.28e-2 / 1.28e-2 / 1.30e-2, HIP vs exact
+# 1.29e-2 / 1.27e-2 / 1.26e-2: 24 ViT layers + projector + one decoder layer in bf16 sit 1.3e-2 from fp32 math whoever computes them
+HEADLINE_LIMITS = {"feats": 1.25e-2, "embed": 1.25e-2, "layer0": 1.6e-2}
