@@ -387,7 +387,7 @@ def test_vit_layer_built_by_megatron_matches_the_oracle_forward_and_backward(meg
     xh = x.transpose(0, 1).contiguous().to(DEV).requires_grad_(True)                  # Megatron's [s, b, h]
     out, _ = layer(xh, attention_mask=None)
     assert out.shape == (S, n, H) and out.dtype == torch.bfloat16
-    tol("forward", rel_l2(out.transpose(0, 1), ref), 1e-2)
+    tol("forward", rel_l2(out.transpose(0, 1), ref), 1.4e-3)                   # measured 9.0e-4
     out.backward(go.transpose(0, 1).contiguous().to(DEV))
     params = dict(layer.named_parameters())
     errs = {"dx": rel_l2(xh.grad.transpose(0, 1), xo.grad)}
@@ -395,7 +395,7 @@ def test_vit_layer_built_by_megatron_matches_the_oracle_forward_and_backward(meg
         assert params[nme].grad is not None, nme
         errs[k] = rel_l2(params[nme].grad, lpo[k].grad)
     _record("vit_layer_" + spec, errs)
-    tol("worst gradient", max(errs.values()), 3e-2)
+    tol("worst gradient", max(errs.values()), 6.6e-3)                          # measured 4.4e-3 (ls2)
     with torch.no_grad():                                                             # inference: fc1 + bias + GELU in one GEMM epilogue
         out2, _ = layer(x.transpose(0, 1).contiguous().to(DEV), attention_mask=None)
-    tol("no-grad path vs autograd path", rel_l2(out2, out), 5e-3)
+    tol("no-grad path vs autograd path", rel_l2(out2, out), 1e-5)              # measured 0: the same rounding chain

@@ -203,7 +203,7 @@ def test_layernorm_bwd(ops, rows, cols):
     dg = torch.zeros(cols, dtype=torch.float32, device=DEV)
     db = torch.zeros_like(dg)
     dx = ops.layernorm_bwd(dy.to(DEV), x.to(DEV), w.to(DEV), 1e-6, dg, db)
-    tol("dx", rel_l2(dx, xf.grad), 4e-3)                     # one bf16 rounding of the result
+    tol("dx", rel_l2(dx, xf.grad), 2.5e-3)                     # one bf16 rounding of the result
     tol("dgamma", rel_l2(dg, wf.grad), 1e-4)
     tol("dbeta", rel_l2(db, bf.grad), 1e-4)
 
@@ -211,9 +211,10 @@ def test_layernorm_bwd(ops, rows, cols):
 def test_gelu_fwd_and_bias_scale_residual(ops):
     x = (torch.randn(300, 1024, generator=g(44)) * 2).bfloat16()
     ge, gr = ops.gelu(x.to(DEV)).cpu(), torch.nn.functional.gelu(x.float()).bfloat16()
-    # device erff vs host erf: 1 + erf(x / sqrt 2) cancels for negative x, so ~1 % of the results land one bf16 ulp apart
-    ai, bi = ge.view(torch.int16).int(), gr.view(torch.int16).int()
-    assert float((ge != gr).float().mean()) < 5e-2 and int((ai - bi).abs().max()) <= 2
+    # device erff vs host erf: 1 + erf(x / sqrt 2) cancels for negative x — ~1 % of the results differ, by one bf16 ulp where the
+    # value is O(1) and by ~1e-8 absolute in the far negative tail (|gelu| ~ 1e-6), where fp32 cancellation leaves few digits
+    dgl = (ge.float() - gr.float()).abs()
+    assert float((ge != gr).float().mean()) < 5e-2 and bool((dgl <= 8e-3 * gr.float().abs() + 1e-6).all())
     d = (ops.gelu(x.to(DEV), tanh=True).cpu().float() - torch.nn.functional.gelu(x.float(), approximate="tanh")).abs()
     assert float(d.max()) < 2e-2 and float((d > 0).float().mean()) < 0.6      # device tanhf vs host tanh: <= 1 bf16 ulp
     rows, cols = 130, 1024
@@ -254,8 +255,8 @@ def test_non_causal_attention_backward_through_the_padded_chunk_tables(ops, B, S
     o.view(S, B, H, D).transpose(0, 1).backward(d_o.float())
     qd, kd, vd = (t.to(DEV).requires_grad_(True) for t in (q, k, v))
     out = FlashAttnNonCausalFn.apply(qd, kd, vd, 1.0 / math.sqrt(D))
-    tol("out", rel_l2(out, o.detach().view(S, B, H, D).transpose(0, 1)), 3.5e-3)
+    tol("out", rel_l2(out, o.detach().view(S, B, H, D).transpose(0, 1)), 3.4e-3)
     out.backward(d_o.to(DEV))
-    tol("dq", rel_l2(qd.grad, qf.grad), 4.5e-3)
-    tol("dk", rel_l2(kd.grad, kf.grad), 4.5e-3)
-    tol("dv", rel_l2(vd.grad, vf.grad), 4.5e-3)
+    tol("dq", rel_l2(qd.grad, qf.grad), 3.7e-3)
+    tol("dk", rel_l2(kd.grad, kf.grad), 3.7e-3)
+    tol("dv", rel_l2(vd.grad, vf.grad), 3.7e-3)

@@ -575,10 +575,10 @@ def test_cp_attention_c_abi_own_chunks_first_with_an_external_exchange(ops):
                 torch.cuda.synchronize()
                 outs[mode] = (out.clone(), lse.clone())
             assert torch.isfinite(outs["own_first"][0].float()).all()
-            tol("own-chunks-first vs one launch per split", rel_l2(outs["own_first"][0], outs["single"][0]), 4.5e-3)   # two bf16 roundings instead of one
+            tol("own-chunks-first vs one launch per split", rel_l2(outs["own_first"][0], outs["single"][0]), 3.3e-3)   # two bf16 roundings instead of one
             assert float((outs["own_first"][1] - outs["single"][1]).abs().max()) < 2e-3
             # split 1 takes the plain path in both modes: bit-identical
             assert torch.equal(outs["own_first"][0][:, hq // n_split:], outs["single"][0][:, hq // n_split:])
-            tol("vs the fp32 oracle", rel_l2(outs["own_first"][0], ref[pos[r]]), 4.5e-3)
+            tol("vs the fp32 oracle", rel_l2(outs["own_first"][0], ref[pos[r]]), 4.1e-3)
         finally:
             L.check(h.vita_cp_destroy(ctx), "vita_cp_destroy")
