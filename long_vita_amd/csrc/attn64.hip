@@ -31,7 +31,7 @@
 namespace {
 
 constexpr int D = 128, KVT = 64, QTILE = 256, ROWB = D * 2, TILEB = KVT * ROWB;     // 16 KiB per K (or V) tile
-constexpr int LDS_K = 0, LDS_V = 2 * TILEB, LDS_BYTES = 4 * TILEB;                   // K ring [2] | V ring [2]
+constexpr int LDS_K = 0;                                                             // K ring [NSLOT] | V ring [NSLOT]
 constexpr int NF2 = 3;                                                               // P fragments of tile t+1 done in phase 2
 constexpr int THR = 8;                                                               // lazy running maximum, log2 units
 
@@ -85,7 +85,11 @@ struct TileIt {
   const char* vp;
 };
 
+// NSLOT = 2: one barrier per tile (rings of two slots).  NSLOT = 4 (r03 experiment, VITA_ATTN64_RING=4): rings of four slots,
+// TWO tiles between barriers — the DMAs of tiles t+2 .. t+4 are issued at the start of a pair and have two tiles to land.
+template <int NSLOT>
 __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
+  constexpr int LDS_V = NSLOT * TILEB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
   const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
@@ -367,41 +371,90 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
   enter_chunk(cur);
   TileIt nx1 = cur;
   advance(nx1);
-  dma_k(cur, 0); dma_v(cur, 0);
-  dma_k(nx1, 1);                                     // n_tiles >= 4
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
-  qk_phase(0, lds0 + LDS_K, false, 0);
-  __syncthreads();                                  // every wave has read K(0): its ring slot may be refilled
-  if (needs_mask(cur)) mask_tile(0, cur.j * KVT);
-#pragma unroll
-  for (int u = 0; u < 34 + 8 * NF2; ++u) {
-    if (u < 34) max_unit(0, u);
-    else exp_half(0, u - 34);
-  }
-  // (O is zero: no rescale for tile 0)
-
-  // ---- main loop: two tiles per trip (the S / P buffer parity is a compile-time constant); n_tiles is a multiple of 4 ----------
-  // full(par): `cur` sits in buffer par; K(t+2) -> K ring slot par, V(t+1) -> V ring slot par ^ 1; S(t+1) -> buffer par ^ 1
-  auto full = [&](int par, bool more_k) __attribute__((always_inline)) {
-    TileIt nx2 = nx1;
-    if (more_k) { advance(nx2); dma_k(nx2, par); }  // K(t) in that slot was last read before the previous barrier
-    dma_v(nx1, par ^ 1);
-    qk_phase(par ^ 1, lds0 + LDS_K + (par ^ 1) * TILEB, true, par);
-    if (needs_mask(nx1)) mask_tile(par ^ 1, nx1.j * KVT);
-    pv_phase(par, lds0 + LDS_V + par * TILEB, true);
-    rescale_o();
+  if constexpr (NSLOT == 2) {
+    dma_k(cur, 0); dma_v(cur, 0);
+    dma_k(nx1, 1);                                     // n_tiles >= 4
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
-    nx1 = nx2;
-  };
-  for (int t = 0; t + 2 < n_tiles; t += 2) {
-    full(0, true);
-    full(1, true);
+    qk_phase(0, lds0 + LDS_K, false, 0);
+    __syncthreads();                                  // every wave has read K(0): its ring slot may be refilled
+    if (needs_mask(cur)) mask_tile(0, cur.j * KVT);
+#pragma unroll
+    for (int u = 0; u < 34 + 8 * NF2; ++u) {
+      if (u < 34) max_unit(0, u);
+      else exp_half(0, u - 34);
+    }
+    // (O is zero: no rescale for tile 0)
+
+    // ---- main loop: two tiles per trip (the S / P buffer parity is a compile-time constant); n_tiles is a multiple of 4 ----------
+    // full(par): `cur` sits in buffer par; K(t+2) -> K ring slot par, V(t+1) -> V ring slot par ^ 1; S(t+1) -> buffer par ^ 1
+    auto full = [&](int par, bool more_k) __attribute__((always_inline)) {
+      TileIt nx2 = nx1;
+      if (more_k) { advance(nx2); dma_k(nx2, par); }  // K(t) in that slot was last read before the previous barrier
+      dma_v(nx1, par ^ 1);
+      qk_phase(par ^ 1, lds0 + LDS_K + (par ^ 1) * TILEB, true, par);
+      if (needs_mask(nx1)) mask_tile(par ^ 1, nx1.j * KVT);
+      pv_phase(par, lds0 + LDS_V + par * TILEB, true);
+      rescale_o();
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+      nx1 = nx2;
+    };
+    for (int t = 0; t + 2 < n_tiles; t += 2) {
+      full(0, true);
+      full(1, true);
+    }
+    full(0, false);
+    finish_sm(1);                                      // last tile: the rest of its softmax, then P V
+    pv_phase(1, lds0 + LDS_V + TILEB, false);
+  } else {
+    // ---- NSLOT = 4: tile t lives in ring slot t & 3 (K and V); call c (tile c in S / P buffer c & 1) reads K(c+1) and V(c);
+    //      a PAIR of calls (c, c+1), c even, sits between two barriers and starts by fetching K(c+3), K(c+4), V(c+2), V(c+3) -------
+    TileIt t2 = nx1;
+    advance(t2);
+    dma_k(cur, 0); dma_v(cur, 0);
+    dma_k(nx1, 1); dma_v(nx1, 1);
+    dma_k(t2, 2);                                      // n_tiles >= 4
+    TileIt it_v = t2, it_k = t2;                      // next V / K tile to fetch: 2 / 3
+    advance(it_k);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    qk_phase(0, lds0 + LDS_K, false, 0);
+    __syncthreads();                                  // every wave has read K(0): slot 0 is refilled by the first pair
+    if (needs_mask(cur)) mask_tile(0, cur.j * KVT);
+#pragma unroll
+    for (int u = 0; u < 34 + 8 * NF2; ++u) {
+      if (u < 34) max_unit(0, u);
+      else exp_half(0, u - 34);
+    }
+    // one call: tile c in buffer par, K(c+1) in k_slot, V(c) in v_slot
+    auto call = [&](int par, int k_slot, int v_slot) __attribute__((always_inline)) {
+      qk_phase(par ^ 1, lds0 + LDS_K + k_slot * TILEB, true, par);
+      if (needs_mask(nx1)) mask_tile(par ^ 1, nx1.j * KVT);
+      pv_phase(par, lds0 + LDS_V + v_slot * TILEB, true);
+      rescale_o();
+      advance(nx1);
+    };
+    // pair with c = 4i + 2 b: fetches K(c+3), K(c+4) -> slots (3 + 2b) & 3, (4 + 2b) & 3 and V(c+2), V(c+3) -> slots (2 + 2b) & 3, (3 + 2b) & 3
+    auto pair = [&](int b, bool k4) __attribute__((always_inline)) {
+      dma_k(it_k, (3 + 2 * b) & 3); advance(it_k);
+      if (k4) { dma_k(it_k, (4 + 2 * b) & 3); advance(it_k); }
+      dma_v(it_v, (2 + 2 * b) & 3); advance(it_v);
+      dma_v(it_v, (3 + 2 * b) & 3); advance(it_v);
+      call(0, (1 + 2 * b) & 3, (2 * b) & 3);
+      call(1, (2 + 2 * b) & 3, (1 + 2 * b) & 3);
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();
+    };
+    for (int t = 0; t + 4 < n_tiles; t += 4) {        // (n_tiles / 4 - 1) x [pair A, pair B]
+      pair(0, true);
+      pair(1, true);
+    }
+    pair(0, false);                                    // the last pair: K(n_tiles) does not exist
+    call(0, 3, 2);                                     // tile n_tiles - 2: K(n_tiles - 1) in slot 3, V(n_tiles - 2) in slot 2
+    finish_sm(1);
+    pv_phase(1, lds0 + LDS_V + 3 * TILEB, false);
   }
-  full(0, false);
-  finish_sm(1);                                      // last tile: the rest of its softmax, then P V
-  pv_phase(1, lds0 + LDS_V + TILEB, false);
 
   // ---- epilogue: O[row][head][d] = O^T / l, lse ------------------------------------------------------------------------------
   asm volatile("s_nop 15\n\ts_nop 15" : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[0][2]), "+a"(o[0][3]), "+a"(o[1][0]), "+a"(o[1][1]), "+a"(o[1][2]), "+a"(o[1][3]));
@@ -442,8 +495,13 @@ bool vita_attn64_eligible(const AttnArgs& a, int head_dim, bool causal) {
 int vita_attn64_launch(const AttnArgs& a, int64_t nblocks, hipStream_t st) {
   static std::atomic<unsigned long long> attr_set{0};
   vita_device_once(attr_set, [&] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd64_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILEB);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd64_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILEB);
   });
-  hipLaunchKernelGGL(flash_fwd64_kernel, dim3((unsigned)nblocks), dim3(256), LDS_BYTES, st, a);
+  const char* e = vita_dev_getenv("VITA_ATTN64_RING");           // developer A/B switch: 4 = four-slot rings, a barrier every two tiles
+  if (e && e[0] == '4')
+    hipLaunchKernelGGL(flash_fwd64_kernel<4>, dim3((unsigned)nblocks), dim3(256), 8 * TILEB, st, a);
+  else
+    hipLaunchKernelGGL(flash_fwd64_kernel<2>, dim3((unsigned)nblocks), dim3(256), 4 * TILEB, st, a);
   return vita_check_launch();
 }
