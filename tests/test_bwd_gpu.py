@@ -215,8 +215,9 @@ def test_gelu_fwd_and_bias_scale_residual(ops):
     # value is O(1) and by ~1e-8 absolute in the far negative tail (|gelu| ~ 1e-6), where fp32 cancellation leaves few digits
     dgl = (ge.float() - gr.float()).abs()
     assert float((ge != gr).float().mean()) < 5e-2 and bool((dgl <= 8e-3 * gr.float().abs() + 1e-6).all())
-    d = (ops.gelu(x.to(DEV), tanh=True).cpu().float() - torch.nn.functional.gelu(x.float(), approximate="tanh")).abs()
-    assert float(d.max()) < 2e-2 and float((d > 0).float().mean()) < 0.6      # device tanhf vs host tanh: <= 1 bf16 ulp
+    gt, gtr = ops.gelu(x.to(DEV), tanh=True).cpu(), torch.nn.functional.gelu(x.float(), approximate="tanh").bfloat16()
+    dgt = (gt.float() - gtr.float()).abs()                                     # device tanhf vs host tanh
+    assert float((gt != gtr).float().mean()) < 5e-2 and bool((dgt <= 8e-3 * gtr.float().abs() + 1e-6).all())
     rows, cols = 130, 1024
     y = torch.randn(rows, cols, generator=g(45)).bfloat16()
     bias = torch.randn(cols, generator=g(46)).bfloat16()
