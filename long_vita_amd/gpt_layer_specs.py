@@ -6,6 +6,7 @@ The reference returns `ModuleSpec(module=TransformerLayer, submodules=...)` whos
 modules; here the leaves are the HIP-backed modules of this package, so that under a real Megatron the decoder's norms, the
 four linears and the core attention — every kernel of the layer — run through libvita_hip.so:
 
+  both specs           mlp = layers.GatedMLP (Megatron MLP's constructor; SwiGLU as the fc1 GEMM epilogue / vita_swiglu_fwd,bwd)
   TE spec   (:26-55)   linear_qkv = LayerNormColumnParallelLinear   (vita_rmsnorm_fwd -> vita_gemm_bf16, + bias)
                        core_attention = HipDotProductAttention      (vita_flash_attn_fwd / _bwd)
                        linear_proj = RowParallelLinear, mlp.linear_fc1 = LayerNormColumnParallelLinear, mlp.linear_fc2 = RowParallelLinear
@@ -18,7 +19,7 @@ leaves together); they are imported when the builder is called, so this module i
 from __future__ import annotations
 
 from .dot_product_attention import HipDotProductAttention
-from .layers import (ColumnParallelLinear, LayerNormColumnParallelLinear, Norm, RowParallelLinear, get_bias_dropout_add)
+from .layers import (ColumnParallelLinear, GatedMLP, LayerNormColumnParallelLinear, Norm, RowParallelLinear, get_bias_dropout_add)
 
 
 def _megatron():
@@ -38,7 +39,9 @@ def _get_mlp_module_spec(use_te: bool = True, num_experts: int = None, moe_group
     if num_experts is not None:
         raise NotImplementedError("mixture-of-experts layers are not on the Long-VITA path")
     m = _megatron()
-    return m["ModuleSpec"](module=m["MLP"], submodules=m["MLPSubmodules"](
+    # module = GatedMLP (Megatron MLP's constructor and return value): the gated activation stays on the library — the fc1 GEMM's
+    # epilogue without autograd, vita_swiglu_fwd / _bwd with it — instead of Megatron's three torch ops on the 2 ffn-wide product
+    return m["ModuleSpec"](module=GatedMLP, submodules=m["MLPSubmodules"](
         linear_fc1=LayerNormColumnParallelLinear if use_te else ColumnParallelLinear, linear_fc2=RowParallelLinear))
 
 

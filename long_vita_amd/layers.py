@@ -206,10 +206,8 @@ class BiasAddFn(torch.autograd.Function):
 
     @staticmethod
     def forward(ctx, x, bias):
-        y = x.contiguous().clone()
-        rows = y.numel() // y.shape[-1]
-        ops.add_(y.view(rows, -1), bias.expand(rows, -1).contiguous())
-        return y
+        rows = x.numel() // x.shape[-1]
+        return ops.add(x.contiguous().view(rows, -1), bias.expand(rows, -1).contiguous()).view_as(x)      # one pass, x is not copied
 
     @staticmethod
     def backward(ctx, g):
@@ -334,12 +332,50 @@ class ViTMLP(torch.nn.Module):
         return self.linear_fc2(a)                                              # (output, bias): the bias goes into the residual kernel
 
 
+class GatedMLP(torch.nn.Module):
+    """The decoder's SwiGLU MLP with Megatron MLP's constructor and `(output, output_bias)` return (megatron/core/transformer/mlp.py;
+    stage-3 flags `--swiglu --disable-bias-linear`).  Megatron's MLP.forward runs linear_fc1, then `silu(gate) * up` as torch ops on
+    the [s, b, 2 ffn] product; here, without autograd, the gated activation is the EPILOGUE of the fc1 GEMM (VITA_EPI_SWIGLU: the
+    2 ffn-wide product never reaches HBM — what GPTVLModel.decoder_layer does), and with autograd fc1 is followed by vita_swiglu_fwd
+    (SwiGLUFn keeps the product for the backward).  fc1's weight rows are cat[gate, up] (R/tools/hf2mcore_long_vita.py:612)."""
+
+    def __init__(self, config, submodules, is_expert: bool = False, input_size: int = None):
+        super().__init__()
+        from megatron.core.transformer.spec_utils import build_module
+        if is_expert or not getattr(config, "gated_linear_unit", False) or getattr(config, "add_bias_linear", False):
+            raise NotImplementedError("GatedMLP is the dense bias-free SwiGLU MLP of the Long-VITA decoder")
+        if getattr(config, "activation_func", torch.nn.functional.silu) is not torch.nn.functional.silu:
+            raise NotImplementedError("GatedMLP: activation_func must be silu (--swiglu)")
+        self.config = config
+        self.input_size = input_size if input_size is not None else config.hidden_size
+        self.linear_fc1 = build_module(submodules.linear_fc1, self.input_size, 2 * config.ffn_hidden_size, config=config,
+                                       init_method=config.init_method, gather_output=False, bias=False, skip_bias_add=True,
+                                       is_expert=False, tp_comm_buffer_name="fc1")
+        self.activation_func = config.activation_func
+        self.linear_fc2 = build_module(submodules.linear_fc2, config.ffn_hidden_size, config.hidden_size, config=config,
+                                       init_method=config.output_layer_init_method, bias=False, input_is_parallel=True,
+                                       skip_bias_add=True, is_expert=False, tp_comm_buffer_name="fc2")
+
+    def forward(self, hidden_states):
+        fc1 = self.linear_fc1
+        grad = torch.is_grad_enabled() and (hidden_states.requires_grad or fc1.weight.requires_grad)
+        fusable = not grad and not fc1.sequence_parallel and mpu.get_tensor_model_parallel_world_size() == 1
+        if fusable:
+            x = fc1._norm(hidden_states) if isinstance(fc1, LayerNormColumnParallelLinear) else hidden_states
+            s, b, h = x.shape
+            a = ops.gemm(x.reshape(s * b, h), fc1.weight, ops.EPI_SWIGLU).view(s, b, -1)
+        else:
+            y, _ = fc1(hidden_states)
+            a = F_.SwiGLUFn.apply(y)
+        return self.linear_fc2(a)
+
+
 class ResidualAddFn(torch.autograd.Function):
     """residual + x as one library kernel (vita_add_bf16); the gradient passes to both unchanged."""
 
     @staticmethod
     def forward(ctx, x, residual):
-        return ops.add_(x.contiguous().clone(), residual.contiguous())
+        return ops.add(x.contiguous(), residual.contiguous())            # out = bf16(x + residual): one pass, nothing is cloned
 
     @staticmethod
     def backward(ctx, g):
@@ -353,6 +389,8 @@ def get_bias_dropout_add(training: bool, fused: bool):
     def _bda(x_with_bias, residual, prob):
         x, bias = x_with_bias
         if bias is None and (prob == 0.0 or not training):
+            if not (torch.is_grad_enabled() and (x.requires_grad or residual.requires_grad)) and x.is_contiguous():
+                return ops.add(x, residual.contiguous(), out=x)          # inference: into the linear's own (temporary) output
             return ResidualAddFn.apply(x, residual)
         if bias is not None:
             x = x + bias

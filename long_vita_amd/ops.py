@@ -694,6 +694,15 @@ def logit_postprocess_bwd_(y: torch.Tensor, grad: torch.Tensor, multiplier_scale
     return grad
 
 
+def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out = bf16(a + b) (out may alias a): one pass, no copy of either operand."""
+    if a.shape != b.shape or not a.is_contiguous() or not b.is_contiguous():
+        raise ValueError("add: contiguous tensors of equal shape")
+    y = torch.empty_like(a) if out is None else out
+    _L.check(_L.load().vita_add_bf16(_dev(a, "a", BF16), _dev(b, "b", BF16), _dev(y, "out", BF16), a.numel(), _stream()), "vita_add_bf16")
+    return y
+
+
 def add_(a: torch.Tensor, b: torch.Tensor) -> torch.Tensor:
     """a = bf16(a + b) in place (residual add behind a tensor-parallel all-reduce)."""
     if a.shape != b.shape or not a.is_contiguous() or not b.is_contiguous():
