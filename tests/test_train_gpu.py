@@ -446,3 +446,41 @@ def test_train_step_selective_recompute_equals_full_recompute(amd, monkeypatch, 
         for k in lf:
             worst = max(worst, rel_l2(ls[k], lf[k]))
     assert worst < 2.5e-2, worst          # measured 0.6e-2 .. 1.0e-2 (bf16 noise of the two forward variants; CP: + the gathers' order)
+
+
+def test_config5_shaped_training_step_tp2_cp4_at_128k(amd, monkeypatch):
+    """BASELINE config 5 at its REAL sizes on what one GPU can hold: the 14B decoder's width (hidden 5120, 40 : 8 heads, FFN 13824,
+    vocabulary 152064), S = 131072, 512 answer tokens, TP = 2 x CP = 4 on eight simulated ranks (every rank: S_l = 32768 rows of two
+    zig-zag chunks, 20 : 4 heads, a K/V all-gather to 131072 keys per layer, the dK / dV reduce-scatter, bf16 TP all-reduces, the
+    vocab-parallel head) — two layers deep, stage-3's block recompute with one layer kept.  Reference: the SAME weights through the
+    unsharded TP = CP = 1 step of this library at 128K (pinned against torch autograd over the oracle at small sizes by the tests
+    above): equal loss, every gradient within bf16 noise of the unsharded step."""
+    from long_vita_amd import tensor_parallel as tpar
+    tp, cp, S = 2, 4, 131072
+    G = amd["gpt"]
+    full_cfg = G.GPTConfig(num_layers=2)
+    base = G.GPTVLModel.random_init(full_cfg, seed=55, device=DEV)
+    gen = torch.Generator().manual_seed(56)
+    tokens = torch.randint(0, 151643, (1, S), generator=gen)
+    labels = torch.roll(tokens, -1, 1)
+    loss_mask = torch.zeros(1, S)
+    loss_mask[0, S - 512:] = 1
+    tok, lab, lm = tokens.to(DEV), labels.to(DEV), loss_mask.to(DEV)
+    loss_ref, g_ref = amd["train"].TrainStep(base, recompute_num_layers=1).forward_backward(tok, lab, lm)
+    base._ws = {}
+    torch.cuda.empty_cache()
+    p_cpu = {"embed": base.p["embed"], "final_ln": base.p["final_ln"], "lm_head": base.p["lm_head"], "layers": base.p["layers"]}
+
+    def rank_fn(ci, ti):
+        shard, cfg_l = tpar.shard_llm_params(p_cpu, full_cfg, tp, ti)
+        m = G.GPTVLModel(cfg_l, shard)
+        loss, g = amd["train"].TrainStep(m, recompute_num_layers=1).forward_backward(tok, lab, lm)
+        amd["train"].allreduce_grads(g)                       # over the CP group
+        return loss, g
+
+    outs = _run_grid(tp, cp, rank_fn, amd, monkeypatch)
+    losses = {float(v[0]) for v in outs.values()}
+    assert len(losses) == 1
+    tol("loss, TP2 x CP4 vs unsharded (relative)", abs(losses.pop() - float(loss_ref)) / abs(float(loss_ref)), 2e-3)
+    full = tpar.unshard_llm_grads([outs[(0, ti)][1] for ti in range(tp)], full_cfg, tp)
+    _check_grads(full, g_ref, 2.5e-2)
