@@ -169,6 +169,13 @@ int vita_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void*
                    int64_t M, int64_t N, int64_t K, int epilogue, const void* bias,
                    const void* scale, const void* R, int64_t ldr, void* stream);
 
+/* The weight-gradient GEMM without transposes (r03): C[M, N] = A_t^T W_t, BOTH operands contraction-major — A_t [K, M] (row stride
+ * lda), W_t [K, N] (ldw).  grad_weight = grad_output.t().matmul(total_input) (M/core/tensor_parallel/layers.py:522-523) is exactly this
+ * with A_t = grad_output [tokens, out], W_t = total_input [tokens, in] as the forward left them: no vita_transpose_bf16 pass over
+ * either.  M, N multiples of 256, K of 64 (VITA_ERR_UNSUPPORTED otherwise: the caller falls back to vita_transpose_bf16 + vita_gemm_bf16). */
+int vita_gemm_bf16_tn(const void* At, int64_t lda, const void* Wt, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N,
+                      int64_t K, void* stream);
+
 /* Skinny-M GEMM for the logits-masked LM head (n_sel rows, M <= 16):
  *   logits[M, N] fp32-accumulated, stored bf16 (out_f32 == 0) or fp32 (out_f32 != 0).
  * Replaces torch.matmul on the masked rows, M/core/tensor_parallel/layers.py:402-409. */

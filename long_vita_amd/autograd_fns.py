@@ -102,11 +102,19 @@ class LinearFn(torch.autograd.Function):
             grad_input = sub
         grad_weight = grad_bias = None
         if ctx.needs_input_grad[1] or ctx.use_bias:
-            go_t = transpose(pad_rows(go))
-            if ctx.needs_input_grad[1]:
-                grad_weight = wgrad(go_t, pad_rows(x.contiguous()))                               # :522-523
-            if ctx.use_bias:
-                grad_bias = bias_grad(go_t)                                                       # :524
+            go_p, x_p = pad_rows(go), pad_rows(x.contiguous())
+            if ops.gemm_tn_ok(go_p, x_p):                # both operands contraction-major as they are: no transposed copies
+                if ctx.needs_input_grad[1]:
+                    grad_weight = ops.gemm_tn(go_p, x_p)                                          # :522-523
+                if ctx.use_bias:
+                    ones = torch.ones(go_p.shape[0], 256, dtype=go_p.dtype, device=go_p.device)
+                    grad_bias = ops.gemm_tn(go_p, ones)[:, 0].contiguous()                        # :524
+            else:
+                go_t = transpose(go_p)
+                if ctx.needs_input_grad[1]:
+                    grad_weight = wgrad(go_t, x_p)
+                if ctx.use_bias:
+                    grad_bias = bias_grad(go_t)
         return grad_input, grad_weight, grad_bias, None, None, None
 
 

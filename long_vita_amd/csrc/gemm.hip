@@ -554,9 +554,19 @@ constexpr int LINE = 1040, HALF = 16 * LINE, OPB = 2 * HALF, STAGE = 2 * OPB, LD
 // INTERIOR = every tile of the problem is whole (M % 256 == 0, N % tile width == 0): chosen at launch, so that each instantiation has
 // ONE straight-line epilogue (two epilogue paths behind a run-time branch made hipcc shuffle the pinned accumulators between AGPRs
 // and produced wrong blocks).
-template <int EPI, bool INTERIOR>
+//
+// TN = true (r03, vita_gemm_bf16_tn): BOTH operands are stored contraction-major — A_t [K][M] and W_t [K][N], C = A_t^T W_t — which is
+// what a weight gradient is (dW [N, K_in] = dY^T X with dY [tokens, N] and X [tokens, K_in] as the forward left them), so wgrad needs
+// no vita_transpose_bf16 passes.  Same MFMA order, barriers, DMA slots and epilogue; what changes is the LDS image and the fragment
+// reads: a K tile of an operand is 64 contraction rows x 256 columns = 64 rows of 512 B (DMA piece = two whole rows), the 16 x 32
+// fragment (lane -> column lane % 16, contraction rows 8 (lane / 16) .. + 7) comes from TWO ds_read_b64_tr_b16 (rows .. + 0..3 and
+// .. + 4..7; the hardware transposes 4 x 16 blocks inside 16-lane groups), and the eight rows a 32-lane half reads (r and r + 8,
+// r = 0..3) are spread over the 64 banks by XOR-ing the 32-byte chunk index with key(row) = (row & 3) | ((row >> 3) & 1) << 2 — on
+// the DMA's SOURCE address and on the read address.
+template <int EPI, bool INTERIOR, bool TN = false>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   using namespace w4;
+  constexpr int STG = TN ? 65536 : STAGE, OPBS = TN ? 32768 : OPB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -584,10 +594,19 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   // ---- DMA geometry: wave w fills lines (h = w >> 1, r16 = (w & 1) * 8 + i), i = 0..7, of both operands; per-lane byte offsets of
   // the eight pieces relative to the tile's first row (clamped rows for ragged edges; SwiGLU: 16-row blocks alternate gate / up) ------
   const int h = wave >> 1, r0 = (wave & 1) * 8;
-  const unsigned d_line0 = (unsigned)(h * HALF + r0 * LINE);
+  const unsigned d_line0 = TN ? (unsigned)(wave * 8 * 1024) : (unsigned)(h * HALF + r0 * LINE);
+  constexpr int PIECE = TN ? 1024 : LINE;
   unsigned voff_a[8], voff_w[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
+    if (TN) {       // piece 8 wave + i = contraction rows 16 wave + 2 i + {0, 1}; lane -> (row lane / 32, 16-byte chunk lane % 32)
+      const int krow = 16 * wave + 2 * i + (lane >> 5), c16 = lane & 31;
+      const int key = (krow & 3) | (((krow >> 3) & 1) << 2);       // the 8 rows one 32-lane half reads (r, r + 8; r = 0..3 [+ 4]) get 8 keys
+      const int col = ((((c16 >> 1) ^ key) << 1) | (c16 & 1)) * 8;                          // source-side swizzle (32-byte chunks)
+      voff_a[i] = (unsigned)((krow * p.lda + col) * 2);
+      voff_w[i] = (unsigned)((krow * p.ldw + col) * 2);
+      continue;
+    }
     const int lr = 128 * h + 16 * (lane >> 3) + r0 + i;
     int64_t g = m0 + lr;
     g = g < p.M ? g : p.M - 1;
@@ -609,23 +628,50 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (const char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
   };
-  const char* const ap = uniform_ptr(p.A + m0 * p.lda);
-  const char* const wp = uniform_ptr(p.W + n0 * p.ldw);
-  int koff = 0;                                                                             // byte offset of the K tile fetched next
+  const char* const ap = uniform_ptr(TN ? p.A + m0 : p.A + m0 * p.lda);
+  const char* const wp = uniform_ptr(TN ? p.W + n0 : p.W + n0 * p.ldw);
+  int64_t koff_a = 0, koff_w = 0;                                                           // byte offsets of the K tile fetched next
+  const int64_t kstep_a = TN ? (int64_t)BK * p.lda * 2 : BK * 2, kstep_w = TN ? (int64_t)BK * p.ldw * 2 : BK * 2;
   auto dma_piece = [&](unsigned stage, int j) __attribute__((always_inline)) {              // j = 0..7: A lines, 8..15: W lines
-    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)((j < 8 ? ap : wp) + koff), 0, 0x7fffffff, 0x00020000);
+    const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(j < 8 ? ap + koff_a : wp + koff_w), 0, 0x7fffffff, 0x00020000);
     const int i = j & 7;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(uintptr_t)(stage + (j < 8 ? 0 : OPB) + d_line0 + i * LINE), 16,
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(uintptr_t)(stage + (j < 8 ? 0 : OPBS) + d_line0 + i * PIECE), 16,
                                              j < 8 ? voff_a[i] : voff_w[i], 0, 0, 0);
   };
-  auto next_tile = [&]() __attribute__((always_inline)) { koff += BK * 2; };
+  auto next_tile = [&]() __attribute__((always_inline)) { koff_a += kstep_a; koff_w += kstep_w; };
 
   // ---- fragment reads: lane -> (row lane % 16) * LINE + (k chunk lane / 16) * 16, + row block * 128 + k half * 64 ------------------
   const unsigned rd_a = (unsigned)(wm * HALF + (lane & 15) * LINE + (lane >> 4) * 16);
   const unsigned rd_w = (unsigned)(OPB + wn * HALF + (lane & 15) * LINE + (lane >> 4) * 16);
   bf16x8 af[2][8], wf[2][8];
+  // TN: lane -> (16-lane group g = contraction rows 8 g .., row inside the 4 x 16 block (lane % 16) / 4, 4-column chunk lane % 4);
+  // block x of an operand sits in 32-byte chunk (8 wm + x) ^ (row & 7) of each 512-byte row
+  u32x2 tlo[16], thi[16];                                                  // the two halves of a fragment until its wait has passed
+  unsigned toff_a[8], toff_w[8];
+  if (TN) {
+    const int i16 = lane & 15, sw = (i16 >> 2) | (((lane >> 4) & 1) << 2);          // = key(row) of both reads of this lane
+    const unsigned lane_base = (unsigned)((lane >> 4) * 8 * 512 + (i16 >> 2) * 512 + (i16 & 3) * 8);
+#pragma unroll
+    for (int x = 0; x < 8; ++x) {
+      toff_a[x] = lane_base + (unsigned)((wm * 8 + (x ^ sw)) * 32);
+      toff_w[x] = (unsigned)OPBS + lane_base + (unsigned)((wn * 8 + (x ^ sw)) * 32);
+    }
+  }
   // read q (0..15) of k half ks: W block 0 first, then the eight A blocks, then W blocks 1..7 (the order the MFMAs need them)
   auto frag_read = [&](unsigned stage, int ks, int q) __attribute__((always_inline)) {
+    if (TN) {
+      const bool is_w = q == 0 || q > 8;
+      const int x = is_w ? (q == 0 ? 0 : q - 8) : q - 1;
+      const unsigned a1 = stage + (is_w ? toff_w[x] : toff_a[x]);
+      if (ks == 0) {                                                       // rows 32 ks + 8 g + {0..3}, then + {4..7} (same key)
+        asm volatile("ds_read_b64_tr_b16 %0, %1" : "=v"(tlo[q]) : "v"(a1));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:2048" : "=v"(thi[q]) : "v"(a1));
+      } else {
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:16384" : "=v"(tlo[q]) : "v"(a1));
+        asm volatile("ds_read_b64_tr_b16 %0, %1 offset:18432" : "=v"(thi[q]) : "v"(a1));
+      }
+      return;
+    }
     if (q == 0 || q > 8) {
       const int nb = q == 0 ? 0 : q - 8;
       const unsigned ad = stage + rd_w + nb * 128 + ks * 64;
@@ -634,6 +680,18 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
       const int mb = q - 1;
       const unsigned ad = stage + rd_a + mb * 128 + ks * 64;
       asm volatile("ds_read_b128 %0, %1" : "=v"(af[ks][mb]) : "v"(ad));
+    }
+  };
+  // TN: after the s_waitcnt that covers them, the 16 fragments of k half ks are assembled from their halves (the empty asm makes the
+  // halves opaque HERE, so no compiler-placed copy of them can sit above the wait)
+  auto frag_commit = [&](int ks) __attribute__((always_inline)) {
+    if (!TN) return;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) {
+      asm volatile("" : "+v"(tlo[q]), "+v"(thi[q]));
+      const u32x4 f = {tlo[q][0], tlo[q][1], thi[q][0], thi[q][1]};
+      if (q == 0 || q > 8) wf[ks][q == 0 ? 0 : q - 8] = __builtin_bit_cast(bf16x8, f);
+      else af[ks][q - 1] = __builtin_bit_cast(bf16x8, f);
     }
   };
 
@@ -649,7 +707,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   next_tile();
   if (nk > 1) {
 #pragma unroll
-    for (int j = 0; j < 16; ++j) dma_piece(lds0 + STAGE, j);
+    for (int j = 0; j < 16; ++j) dma_piece(lds0 + STG, j);
     next_tile();
     asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
   } else {
@@ -658,11 +716,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
 #pragma unroll
   for (int q = 0; q < 16; ++q) frag_read(lds0, 0, q);
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  frag_commit(0);
 
   // one K tile: DMA = tile t+2 exists (goes into `cur`), NEXT = tile t+1 exists (its first-half fragments come from `nxt`)
   auto tile = [&](const bool DMA, const bool NEXT, unsigned cur, unsigned nxt) __attribute__((always_inline)) {
-#pragma unroll
-    for (int s = 0; s < 128; ++s) {
+    auto slot = [&](const int s) __attribute__((always_inline)) {
       const int ks = s >> 6, nb = (s >> 3) & 7, mb = s & 7;
       asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[nb][mb]) : "v"(wf[ks][nb]), "v"(af[ks][mb]));
       if (s <= 30 && (s & 1) == 0) frag_read(cur, 1, s >> 1);
@@ -674,18 +732,28 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
       }
       if (NEXT && s >= 104 && s < 120) frag_read(nxt, 0, s - 104);
       __builtin_amdgcn_sched_barrier(0);
-    }
+    };
+    // (two loops: the TN fragment assembly sits between them, outside either body — with it inside, the fully unrolled 128-slot
+    // loop exceeded the optimizer's pragma-unroll size limit, stayed a loop, and the accumulators went to scratch)
+#pragma unroll
+    for (int s = 0; s <= 36; ++s) slot(s);
+    frag_commit(1);
+#pragma unroll
+    for (int s = 37; s < 128; ++s) slot(s);
     if (DMA) next_tile();
-    if (NEXT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (NEXT) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      frag_commit(0);
+    }
   };
 
   int t = 0;
-  for (; t + 2 < nk; ++t) tile(true, true, lds0 + (t & 1) * STAGE, lds0 + ((t + 1) & 1) * STAGE);
+  for (; t + 2 < nk; ++t) tile(true, true, lds0 + (t & 1) * STG, lds0 + ((t + 1) & 1) * STG);
   if (t + 1 < nk) {
-    tile(false, true, lds0 + (t & 1) * STAGE, lds0 + ((t + 1) & 1) * STAGE);
+    tile(false, true, lds0 + (t & 1) * STG, lds0 + ((t + 1) & 1) * STG);
     ++t;
   }
-  tile(false, false, lds0 + (t & 1) * STAGE, 0u);
+  tile(false, false, lds0 + (t & 1) * STG, 0u);
 
   // ---- epilogue.  The inline-asm MFMAs are invisible to the compiler's hazard tracking: one wait for the matrix pipe, then every row
   // block's accumulators pass through an (empty) asm statement of their own right before they are read — asm volatile statements
@@ -970,6 +1038,28 @@ extern "C" int vita_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
       return launch_gemm<VITA_EPI_BIAS2_RES>(a, st);
     default: return VITA_ERR_INVALID_ARG;
   }
+}
+
+// C[M, N] = A_t^T W_t with both operands contraction-major (A_t [K, M], W_t [K, N]): the weight-gradient GEMM without transposes
+extern "C" int vita_gemm_bf16_tn(const void* At, int64_t lda, const void* Wt, int64_t ldw, void* C, int64_t ldc, int64_t M,
+                                 int64_t N, int64_t K, void* stream) {
+  if (!At || !Wt || !C || M <= 0 || N <= 0 || K <= 0) return VITA_ERR_INVALID_ARG;
+  if ((M % 256) || (N % 256) || (K % BK) || (lda & 7) || (ldw & 7) || (ldc & 3)) return VITA_ERR_UNSUPPORTED;
+  if (BK * lda * 2 + 512 >= 0x7fff0000LL || BK * ldw * 2 + 512 >= 0x7fff0000LL) return VITA_ERR_UNSUPPORTED;
+  GemmArgs a;
+  a.A = (const bf16_t*)At; a.lda = lda; a.W = (const bf16_t*)Wt; a.ldw = ldw;
+  a.C = (bf16_t*)C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+  a.bias = nullptr; a.scale = nullptr; a.R = nullptr; a.ldr = 0; a.stagger = 0;
+  const int64_t tm = M / 256, tn = N / 256;
+  if (tm * tn > 0x7fffffff) return VITA_ERR_UNSUPPORTED;
+  a.tiles_m = (int)tm; a.tiles_n = (int)tn;
+  static std::atomic<unsigned long long> attr_set{0};
+  vita_device_once(attr_set, [&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<VITA_EPI_NONE, true, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, w4::LDS_BYTES);
+  });
+  hipLaunchKernelGGL((gemm_w4_kernel<VITA_EPI_NONE, true, true>), dim3((unsigned)(tm * tn)), dim3(256), w4::LDS_BYTES, (hipStream_t)stream, a);
+  return vita_check_launch();
 }
 
 extern "C" int vita_gemm_skinny_bf16(const void* A, int64_t lda, const void* W, int64_t ldw,

@@ -257,6 +257,24 @@ def gemm(a: torch.Tensor, w: torch.Tensor, epilogue: int = EPI_NONE, bias: Optio
     return y
 
 
+def gemm_tn_ok(a_t: torch.Tensor, w_t: torch.Tensor) -> bool:
+    """Shapes vita_gemm_bf16_tn takes: out dims multiples of 256, contraction a multiple of 64, 16-byte aligned rows."""
+    return (a_t.dim() == 2 and w_t.dim() == 2 and a_t.shape[0] == w_t.shape[0] and a_t.stride(1) == 1 and w_t.stride(1) == 1
+            and a_t.shape[1] % 256 == 0 and w_t.shape[1] % 256 == 0 and a_t.shape[0] % 64 == 0 and a_t.stride(0) % 8 == 0
+            and w_t.stride(0) % 8 == 0 and a_t.shape[0] > 0)
+
+
+def gemm_tn(a_t: torch.Tensor, w_t: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M, N] = a_t[K, M]^T @ w_t[K, N] — both operands contraction-major (the wgrad GEMM: a_t = grad_output [tokens, out],
+    w_t = total_input [tokens, in]; M/core/tensor_parallel/layers.py:522-523) with no transposed copies."""
+    K, M = a_t.shape
+    N = w_t.shape[1]
+    y = torch.empty((M, N), dtype=BF16, device=a_t.device) if out is None else out
+    _L.check(_L.load().vita_gemm_bf16_tn(_dev(a_t, "a_t", BF16), a_t.stride(0), _dev(w_t, "w_t", BF16), w_t.stride(0),
+                                         _dev(y, "out", BF16), y.stride(0), M, N, K, _stream()), "vita_gemm_bf16_tn")
+    return y
+
+
 def gemm_skinny(a: torch.Tensor, w: torch.Tensor, out_f32: bool = False) -> torch.Tensor:
     """Logits-masked head GEMM for <= 16 selected rows."""
     M, K = a.shape

@@ -8,7 +8,8 @@ explicit reverse sweep over the same expressions, every arithmetic step a libvit
 
   forward   the inference fast path (fused epilogues), keeping only each layer's input `h_l`;
   backward  per layer, recompute the layer from `h_l` with its intermediates, then
-            dgrad = gemm(dY, W^T), wgrad = gemm(dY^T, X^T)  (vita_transpose_bf16 feeds the one NT GEMM),
+            dgrad = gemm(dY, W^T) (vita_transpose_bf16 of the weight feeds the NT GEMM), wgrad = gemm_tn(dY, X) (r03:
+            vita_gemm_bf16_tn takes both operands contraction-major, no transposed copies of the activations),
             vita_swiglu_bwd, vita_rmsnorm_bwd (+ residual), vita_flash_attn_bwd, vita_rope_qkv_bwd;
   context parallelism: K/V all-gather in forward (and recompute), ONE reduce-scatter of the
             gathered-layout dK/dV per layer in backward (what TE's ring does in CP-1 P2P steps);
@@ -45,6 +46,25 @@ def _dgrad(dy: torch.Tensor, w: torch.Tensor, out=None, epilogue=ops.EPI_NONE, r
 def _wgrad(dy_t: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     """grad_weight = grad_output.t().matmul(total_input)  (layers.py:522-523): dy_t [N, M], x [M, K] -> [N, K]."""
     return ops.gemm(dy_t, _t(x))
+
+
+def _wgrad_tn(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
+    """grad_weight = grad_output.t().matmul(total_input) (layers.py:522-523) from the operands AS THE FORWARD LEFT THEM:
+    dy [M, N], x [M, K] -> [N, K] through vita_gemm_bf16_tn (both operands contraction-major, no transposed copies);
+    shapes the kernel does not tile (out dims not multiples of 256) take the two vita_transpose_bf16 passes + the NT GEMM."""
+    if ops.gemm_tn_ok(dy, x):
+        return ops.gemm_tn(dy, x)
+    return ops.gemm(_t(dy), _t(x))
+
+
+def _colsum(dy: torch.Tensor) -> torch.Tensor:
+    """grad_bias = grad_output.sum(dim=0) (layers.py:524) as a GEMM against a block of ones: dy [M, N] -> [N]."""
+    m = dy.shape[0]
+    if dy.shape[1] % 256 == 0 and m % 64 == 0 and dy.stride(1) == 1 and dy.stride(0) % 8 == 0:
+        ones = torch.ones(m, 256, dtype=dy.dtype, device=dy.device)
+        return ops.gemm_tn(dy, ones)[:, 0].contiguous()
+    ones = torch.ones(4, m, dtype=dy.dtype, device=dy.device)
+    return ops.gemm(_t(dy), ones)[:, 0].contiguous()
 
 
 def _tp_sum(t: torch.Tensor) -> torch.Tensor:
@@ -163,21 +183,19 @@ class TrainStep:
         a = self._layer_recompute(h, lp, cos, sin) if keep is None else self._rebuild(h, lp, keep)
         f32 = lambda n: torch.zeros(n, dtype=torch.float32, device=h.device)  # noqa: E731
         # ---- MLP: out = h_mid + fc2(swiglu(fc1(norm2(h_mid)))) ------------------------------------
-        dh_t = _t(dh)
-        g["fc2_w"] = _wgrad(dh_t, a["act"])
+        g["fc2_w"] = _wgrad_tn(dh, a["act"])
         d_act = _dgrad(dh, lp["fc2_w"])
         dy = ops.swiglu_bwd(a["y"], d_act)
         del d_act
-        dy_t = _t(dy)
-        g["fc1_w"] = _wgrad(dy_t, a["x2"])
+        g["fc1_w"] = _wgrad_tn(dy, a["x2"])
         dx2 = _tp_sum(_dgrad(dy, lp["fc1_w"]))
-        del dy, dy_t
+        del dy
         dln2 = f32(c.hidden)
         dh_mid = ops.rmsnorm_bwd(dx2, a["h_mid"], lp["ln2"], c.eps, dln2, residual=dh)
         g["ln2"] = dln2
         del dx2
         # ---- attention: h_mid = h + proj(attn(rope(qkv(norm1(h))))) -------------------------------
-        g["o_w"] = _wgrad(_t(dh_mid), a["ctx"].view(s, -1))
+        g["o_w"] = _wgrad_tn(dh_mid, a["ctx"].view(s, -1))
         d_ctx = _dgrad(dh_mid, lp["o_w"]).view(1, s, c.heads, c.head_dim)
         d_mixed = torch.empty_like(a["qkv"])
         dm5 = d_mixed.view(1, s, c.kv_groups, c.qpg + 2, c.head_dim)
@@ -197,11 +215,8 @@ class TrainStep:
                                dk=dm5[:, :, :, c.qpg], dv=dm5[:, :, :, c.qpg + 1],
                                seg_start=None if seg is None else seg[0], seg_end=None if seg is None else seg[1])
         ops.rope_qkv_bwd_(d_mixed, c.kv_groups, c.qpg, c.head_dim, cos, sin)
-        dm_t = _t(d_mixed)
-        g["qkv_w"] = _wgrad(dm_t, a["x1"])
-        # grad_bias = grad_output.sum(dim=0) (layers.py:524) as a GEMM against a block of ones
-        ones = torch.ones(4, s, dtype=h.dtype, device=h.device)
-        g["qkv_b"] = ops.gemm(dm_t, ones)[:, 0].contiguous()
+        g["qkv_w"] = _wgrad_tn(d_mixed, a["x1"])
+        g["qkv_b"] = _colsum(d_mixed)                       # grad_bias = grad_output.sum(dim=0) (layers.py:524)
         dx1 = _tp_sum(_dgrad(d_mixed, lp["qkv_w"]))
         dln1 = f32(c.hidden)
         dh_in = ops.rmsnorm_bwd(dx1, h, lp["ln1"], c.eps, dln1, residual=dh_mid)
@@ -308,7 +323,7 @@ class TrainStep:
         if tp > 1:      # this rank's vocabulary slice of dlogits
             v_l = logits_local.shape[1]
             dlogits = dlogits[:, tp_rank * v_l: (tp_rank + 1) * v_l].contiguous()
-        grads["lm_head"] = ops.gemm(_t(dlogits), _t(hn_p))              # [V / TP, hidden]
+        grads["lm_head"] = _wgrad_tn(dlogits, hn_p)                      # [V / TP, hidden]
         d_hn = _tp_sum(_dgrad(dlogits, m.p["lm_head"]))[:n_sel]
         dfl = torch.zeros(c.hidden, dtype=torch.float32, device=h.device)
         d_rows = ops.rmsnorm_bwd(d_hn.contiguous(), rows, m.p["final_ln"], c.eps, dfl)

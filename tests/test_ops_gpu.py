@@ -582,3 +582,31 @@ def test_cp_attention_c_abi_own_chunks_first_with_an_external_exchange(ops):
             tol("vs the fp32 oracle", rel_l2(outs["own_first"][0], ref[pos[r]]), 4.1e-3)
         finally:
             L.check(h.vita_cp_destroy(ctx), "vita_cp_destroy")
+
+
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 256, 128), (512, 768, 1024), (1536, 1024, 2112), (7168, 5120, 4096)])
+def test_gemm_tn_both_operands_contraction_major(ops, M, N, K):
+    """vita_gemm_bf16_tn: C[M, N] = A_t[K, M]^T W_t[K, N] (the wgrad GEMM, grad_output.t().matmul(total_input),
+    M/core/tensor_parallel/layers.py:522-523, without transposed copies) vs fp32 math, vs the NT kernel fed with vita_transpose_bf16
+    copies (same MFMA order along the contraction: bit-identical), and an asymmetric-identity case that catches swapped roles."""
+    a_t = (torch.randn(K, M, generator=g(100)) * 0.5).bfloat16()
+    w_t = (torch.randn(K, N, generator=g(101)) * (1.0 / math.sqrt(K))).bfloat16()
+    ref = (a_t.float().t() @ w_t.float()).bfloat16()
+    ad, wd = a_t.to(DEV), w_t.to(DEV)
+    assert ops.gemm_tn_ok(ad, wd)
+    out = ops.gemm_tn(ad, wd)
+    tol("vs fp32 math", rel_l2(out, ref), 2e-3)
+    nt = ops.gemm(ops.transpose(ad), ops.transpose(wd))
+    assert torch.equal(out, nt)
+    # strided operands (a column slice of a wider activation), as the backward hands them over
+    big_a = torch.zeros(K, M + 64, dtype=torch.bfloat16, device=DEV)
+    big_a[:, 32:32 + M] = ad
+    big_w = torch.zeros(K, N + 512, dtype=torch.bfloat16, device=DEV)
+    big_w[:, 256:256 + N] = wd
+    assert torch.equal(ops.gemm_tn(big_a[:, 32:32 + M], big_w[:, 256:256 + N]), out)
+    if K >= 256 and M == 256:
+        eye_t = torch.zeros(K, M, dtype=torch.bfloat16)
+        eye_t[:M] = torch.eye(M)                                       # A_t^T = [I | 0]: C = the first M rows of W_t
+        wa = (torch.arange(K * N).reshape(K, N) % 251 - 125).float().bfloat16()
+        assert torch.equal(ops.gemm_tn(eye_t.to(DEV), wa.to(DEV)).cpu(), wa[:M])
+    assert not ops.gemm_tn_ok(ad[:, :M - 8], wd) and not ops.gemm_tn_ok(ad[:K - 8], wd[:K - 8])

@@ -83,6 +83,26 @@ def bench_attn_bwd(S, Hq=40, Hkv=8, D=128, tag=""):
              algorithmic_tflops=(5 * unit / med / 1e9) if not only else None)
 
 
+def bench_gemm_tn():
+    """wgrad GEMMs: vita_gemm_bf16_tn on the operands as the forward left them vs two vita_transpose_bf16 passes + the NT GEMM (r02's path),
+    at the 16K single-GPU shapes and BASELINE config 5's per-rank shapes (tokens = 32768, TP = 2 widths)."""
+    for (T, N, K, tag) in [(16384, 7168, 5120, "S16K/qkv"), (16384, 5120, 5120, "S16K/proj"), (16384, 27648, 5120, "S16K/fc1"),
+                           (16384, 5120, 13824, "S16K/fc2"), (32768, 3584, 5120, "cfg5/qkv"), (32768, 5120, 2560, "cfg5/proj"),
+                           (32768, 13824, 5120, "cfg5/fc1"), (32768, 5120, 6912, "cfg5/fc2"), (131072, 7168, 5120, "S128K/qkv")]:
+        dy = torch.randn(T, N, device=DEV).bfloat16()
+        x = (torch.randn(T, K, device=DEV) * 0.5).bfloat16()
+        out = torch.empty(N, K, dtype=torch.bfloat16, device=DEV)
+        med, best = timeit(lambda: ops.gemm_tn(dy, x, out=out))
+        ref = ops.gemm(ops.transpose(dy), ops.transpose(x))
+        same = bool(torch.equal(ref, out))
+        med2, best2 = timeit(lambda: ops.gemm(ops.transpose(dy), ops.transpose(x)))
+        med3, _ = timeit(lambda: (ops.transpose(dy), ops.transpose(x)))
+        fl = 2.0 * T * N * K
+        emit(kind="gemm_tn", tag=tag, tokens=T, N=N, K=K, tn_ms=med, tn_tflops=fl / med / 1e9, transposes_plus_nt_ms=med2,
+             transposes_ms=med3, nt_alone_tflops=fl / max(med2 - med3, 1e-6) / 1e9, speedup=med2 / med, bit_identical=same)
+        del dy, x, out, ref
+
+
 def bench_hbm():
     rows, cols = 131072, 5120
     x = torch.randn(rows, cols, device=DEV).bfloat16()
@@ -196,6 +216,8 @@ if __name__ == "__main__":
         bench_gemm_variants()
     if "peaks" in which:
         bench_peaks()
+    if "gemm_tn" in which:
+        bench_gemm_tn()
     if "gemm" in which:
         for (M, tag) in [(16384, "S16K"), (131072, "S128K")]:
             bench_gemm(M, 7168, 5120, 1, tag + "/qkv")
