@@ -97,10 +97,10 @@ def bench_rank(rank=1):
         wt = ops.transpose(w)                                   # dgrad: dy [M, N] @ w [N, K] = gemm(dy, w^T [K, N])
         dx = torch.empty(M, K, dtype=torch.bfloat16, device=DEV)
         t_d = timeit(lambda: ops.gemm(dy, ops.transpose(w), out=dx))
-        t_w = timeit(lambda: ops.gemm(ops.transpose(dy), ops.transpose(a)))      # wgrad: dy^T [N, M] @ a [M, K]
+        t_w = timeit(lambda: training._wgrad_tn(dy, a))                          # wgrad: dy^T [N, M] @ a [M, K] (vita_gemm_bf16_tn, r03)
         fl = 2.0 * M * N * K
         emit(kind="cfg5_gemm", name=name, M=M, N=N, K=K, fwd_ms=t, dgrad_ms=t_d, wgrad_ms=t_w, fwd_tflops=fl / t / 1e9,
-             dgrad_tflops=fl / t_d / 1e9, wgrad_tflops=fl / t_w / 1e9, note="dgrad / wgrad include the operand transposes they need today")
+             dgrad_tflops=fl / t_d / 1e9, wgrad_tflops=fl / t_w / 1e9, note="dgrad includes the weight transpose it needs; wgrad = vita_gemm_bf16_tn on the operands as they are")
         tot["fwd"] += t; tot["dgrad"] += t_d; tot["wgrad"] += t_w
         del a, w, out, dy, wt, dx
     # ---- HBM-bound kernels at M rows (norms run on the rank's S_l / TP rows under sequence parallelism: count M / TP rows)
