@@ -101,7 +101,12 @@ class LinearFn(torch.autograd.Function):
             dist.reduce_scatter_tensor(sub, grad_input.contiguous(), group=group)
             grad_input = sub
         grad_weight = grad_bias = None
-        if ctx.needs_input_grad[1] or ctx.use_bias:
+        if go.shape[0] == 0:                    # an empty logit-mask selection on this rank: zero parameter gradients
+            if ctx.needs_input_grad[1]:
+                grad_weight = torch.zeros_like(weight)
+            if ctx.use_bias:
+                grad_bias = torch.zeros(weight.shape[0], dtype=weight.dtype, device=weight.device)
+        elif ctx.needs_input_grad[1] or ctx.use_bias:
             go_p, x_p = pad_rows(go), pad_rows(x.contiguous())
             if ops.gemm_tn_ok(go_p, x_p):                # both operands contraction-major as they are: no transposed copies
                 if ctx.needs_input_grad[1]:

@@ -45,6 +45,8 @@ def rmsnorm(x: torch.Tensor, weight: torch.Tensor, eps: float = 1e-6, out: Optio
     xc = x if x.is_contiguous() else x.contiguous()
     rows = xc.numel() // cols
     y = torch.empty_like(xc) if out is None else out
+    if rows == 0:
+        return y
     _L.check(_L.load().vita_rmsnorm_fwd(_dev(xc, "x", BF16), _dev(weight, "weight", BF16), _dev(y, "out", BF16),
                                         _opt(rstd, "rstd", torch.float32), rows, cols, float(eps), _stream()),
              "vita_rmsnorm_fwd")
@@ -246,6 +248,8 @@ def gemm(a: torch.Tensor, w: torch.Tensor, epilogue: int = EPI_NONE, bias: Optio
     y = torch.empty((M, N), dtype=BF16, device=a.device) if out is None else out
     if y.shape != (M, N) or y.stride(1) != 1:
         raise ValueError("out has wrong shape")
+    if M == 0:                                  # an empty selection (a logit mask with no True on this rank): nothing to launch
+        return y
     r_ptr, ldr = None, 0
     if residual is not None:
         if residual.shape != (M, N) or residual.stride(1) != 1:
@@ -282,6 +286,8 @@ def gemm_skinny(a: torch.Tensor, w: torch.Tensor, out_f32: bool = False) -> torc
     if w.shape[1] != K:
         raise RuntimeError(f"supplied weight's shape is {tuple(w.shape)}, K = {K} expected")
     y = torch.empty((M, N), dtype=torch.float32 if out_f32 else BF16, device=a.device)
+    if M == 0:
+        return y
     _L.check(_L.load().vita_gemm_skinny_bf16(_dev(a, "a", BF16), a.stride(0), _dev(w, "w", BF16), w.stride(0),
                                              _dev(y, "out"), y.stride(0), M, N, K, int(out_f32), _stream()),
              "vita_gemm_skinny_bf16")
@@ -433,6 +439,8 @@ def rmsnorm_bwd(dy, x, weight, eps: float, dw_acc: Optional[torch.Tensor] = None
     cols = x.shape[-1]
     rows = x.numel() // cols
     dx = torch.empty_like(x) if out is None else out
+    if rows == 0:
+        return dx
     _L.check(_L.load().vita_rmsnorm_bwd(_dev(dy, "dy", BF16), _dev(x, "x", BF16), _dev(weight, "weight", BF16),
                                         _opt(residual, "residual", BF16), _dev(dx, "dx", BF16), _opt(dw_acc, "dw_acc", torch.float32), rows, cols,
                                         float(eps), _stream()), "vita_rmsnorm_bwd")

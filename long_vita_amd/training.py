@@ -289,20 +289,25 @@ class TrainStep:
                 kept.append(keep)
         idx = ops.mask_to_index(logit_mask.transpose(0, 1).reshape(-1))
         n_sel = idx.numel()
-        rows = ops.row_gather(h, idx)
-        hn = ops.rmsnorm(rows, m.p["final_ln"], c.eps)
-        hn_p = _pad_rows(hn)
         tp, tp_rank = mpu.get_tensor_model_parallel_world_size(), mpu.get_tensor_model_parallel_rank()
-        logits_local = ops.gemm(hn_p, m.p["lm_head"])                # [n_sel (padded), V / TP]
-        logits = m._gather_vocab_parallel(logits_local).contiguous() # [n_sel (padded), V]
-        ops.logit_postprocess_(logits, c.output_multiplier_scale, c.output_logit_softcapping)     # gpt_vl_model.py:349-355
-        # labels of the selected rows (masked_select, gpt_vl_model.py:380-382); 16-byte rows for the gather
-        lab_sel = ops.row_gather(lab.reshape(-1, 1).repeat(1, 2).contiguous(), idx)[:, 0]
         # instruction shift (gpt_vl_model.py:389-391): logits[:-1] vs labels[1:]
         shift = 1 if self.is_instruction else 0
         n_loss = max(n_sel - shift, 0)
         stats = torch.zeros(2, dtype=torch.float32, device=h.device)
-        dlogits = torch.zeros_like(logits)
+        # A context-parallel rank whose two zig-zag chunks hold no answer token selects nothing (config 5: the 512 answer tokens at
+        # the end of a 128K row all sit in the last chunk, i.e. on CP rank 0): its head sees an empty [0, 1, hidden] input, contributes
+        # zero loss and zero head gradients, and still takes part in every CP collective below.  (All TP ranks of a CP rank hold the
+        # same tokens, so the TP collectives inside this block are entered by all of them or none.)
+        if n_sel > 0:
+            rows = ops.row_gather(h, idx)
+            hn = ops.rmsnorm(rows, m.p["final_ln"], c.eps)
+            hn_p = _pad_rows(hn)
+            logits_local = ops.gemm(hn_p, m.p["lm_head"])                # [n_sel (padded), V / TP]
+            logits = m._gather_vocab_parallel(logits_local).contiguous() # [n_sel (padded), V]
+            ops.logit_postprocess_(logits, c.output_multiplier_scale, c.output_logit_softcapping)     # gpt_vl_model.py:349-355
+            # labels of the selected rows (masked_select, gpt_vl_model.py:380-382); 16-byte rows for the gather
+            lab_sel = ops.row_gather(lab.reshape(-1, 1).repeat(1, 2).contiguous(), idx)[:, 0]
+            dlogits = torch.zeros_like(logits)
         if n_loss > 0:
             total = torch.tensor([float(n_loss)], dtype=torch.float32, device=h.device)
             if cp > 1:
@@ -319,17 +324,21 @@ class TrainStep:
 
         # ---- backward ------------------------------------------------------------------------------
         grads = {"layers": [dict() for _ in m.p["layers"]]}
-        ops.logit_postprocess_bwd_(logits, dlogits, c.output_multiplier_scale, c.output_logit_softcapping)
-        if tp > 1:      # this rank's vocabulary slice of dlogits
-            v_l = logits_local.shape[1]
-            dlogits = dlogits[:, tp_rank * v_l: (tp_rank + 1) * v_l].contiguous()
-        grads["lm_head"] = _wgrad_tn(dlogits, hn_p)                      # [V / TP, hidden]
-        d_hn = _tp_sum(_dgrad(dlogits, m.p["lm_head"]))[:n_sel]
-        dfl = torch.zeros(c.hidden, dtype=torch.float32, device=h.device)
-        d_rows = ops.rmsnorm_bwd(d_hn.contiguous(), rows, m.p["final_ln"], c.eps, dfl)
-        grads["final_ln"] = dfl
         dh = torch.zeros(s, c.hidden, dtype=h.dtype, device=h.device)
-        ops.row_scatter_(dh, idx, d_rows)                                # zeros.masked_scatter (layers.py:451)
+        if n_sel > 0:
+            ops.logit_postprocess_bwd_(logits, dlogits, c.output_multiplier_scale, c.output_logit_softcapping)
+            if tp > 1:      # this rank's vocabulary slice of dlogits
+                v_l = logits_local.shape[1]
+                dlogits = dlogits[:, tp_rank * v_l: (tp_rank + 1) * v_l].contiguous()
+            grads["lm_head"] = _wgrad_tn(dlogits, hn_p)                      # [V / TP, hidden]
+            d_hn = _tp_sum(_dgrad(dlogits, m.p["lm_head"]))[:n_sel]
+            dfl = torch.zeros(c.hidden, dtype=torch.float32, device=h.device)
+            d_rows = ops.rmsnorm_bwd(d_hn.contiguous(), rows, m.p["final_ln"], c.eps, dfl)
+            grads["final_ln"] = dfl
+            ops.row_scatter_(dh, idx, d_rows)                                # zeros.masked_scatter (layers.py:451)
+        else:
+            grads["lm_head"] = torch.zeros_like(m.p["lm_head"])
+            grads["final_ln"] = torch.zeros(c.hidden, dtype=torch.float32, device=h.device)
         for li in range(len(m.p["layers"]) - 1, -1, -1):
             dh = self._layer_backward(dh, saved[li], m.p["layers"][li], cos, sin, grads["layers"][li], kept[li])
             saved[li] = None
