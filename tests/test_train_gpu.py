@@ -481,6 +481,6 @@ def test_config5_shaped_training_step_tp2_cp4_at_128k(amd, monkeypatch):
     outs = _run_grid(tp, cp, rank_fn, amd, monkeypatch)
     losses = {float(v[0]) for v in outs.values()}
     assert len(losses) == 1
-    tol("loss, TP2 x CP4 vs unsharded (relative)", abs(losses.pop() - float(loss_ref)) / abs(float(loss_ref)), 2e-3)
+    tol("loss, TP2 x CP4 vs unsharded (relative)", abs(losses.pop() - float(loss_ref)) / abs(float(loss_ref)), 1e-4)    # measured 1.9e-5
     full = tpar.unshard_llm_grads([outs[(0, ti)][1] for ti in range(tp)], full_cfg, tp)
-    _check_grads(full, g_ref, 2.5e-2)
+    _check_grads(full, g_ref, 2.2e-2)                      # measured 1.48e-2 (layers.1.ln1): two bf16 evaluations of the same step
