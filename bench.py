@@ -222,9 +222,9 @@ def main():
     # rocprofv3 --pmc measurement of the same launch shape is committed under profiles/, report it
     traffic, traffic_src = None, None
     try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r02_attn128k_pmc.json")))
+        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_attn128k_pmc.json")))
         if pmc["seq"] == seq and pmc["n_gpus"] == world:
-            traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/r02_attn128k_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, offline)"
+            traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/r03_attn128k_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, offline)"
     except (OSError, KeyError, ValueError):
         pass
 
