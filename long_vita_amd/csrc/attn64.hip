@@ -87,7 +87,11 @@ struct TileIt {
 
 // NSLOT = 2: one barrier per tile (rings of two slots).  NSLOT = 4 (r03 experiment, VITA_ATTN64_RING=4): rings of four slots,
 // TWO tiles between barriers — the DMAs of tiles t+2 .. t+4 are issued at the start of a pair and have two tiles to land.
-template <int NSLOT>
+// PACKED (r03): packed samples (p.seg_start: first key row of each query row's segment, non-decreasing; one chunk).  The workgroup
+// starts at the (even) tile of its first row's segment, and a tile that begins before the segment of the wave's LAST row gets a
+// second arithmetic mask (key >= seg_start[row]); rows whose segment starts later see such tiles as all-masked: P = 0, the running
+// maximum stays at its initial -1e30 and the first visible tile rescales the (zero) state by exp2(-1e30 - m) = 0.
+template <int NSLOT, bool PACKED>
 __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
   constexpr int LDS_V = NSLOT * TILEB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -110,6 +114,14 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
   const int q_off_wg = qti * QTILE;                 // offset of this workgroup inside its chunk
   const int q_off = q_off_wg + wave * 64;           // this wave's first row inside the chunk
   const float scale_log2e = p.scale_log2e;
+  // packed samples: first tile to visit, the per-lane segment starts of the wave's rows, and the largest of them (wave-uniform)
+  int seg_j0 = 0, seg_lo[2] = {0, 0}, seg_lo_max = 0;
+  if constexpr (PACKED) {
+    const int* ss = p.seg_start + (int64_t)qc * p.chunk_len;
+    seg_j0 = (ss[q_off_wg] / KVT) & ~1;                          // even: the pipeline consumes tiles in pairs
+    seg_lo[0] = ss[q_off + l31]; seg_lo[1] = ss[q_off + 32 + l31];
+    seg_lo_max = __builtin_amdgcn_readfirstlane(ss[q_off + 63]);
+  }
 
   // ---- Q fragments (B operand of S^T = K Q^T): block qb, k-step ds: row q_off + 32 qb + l31, d = 16 ds + 8 hi .. + 7 ----------
   bf16x8 qf[2][8];
@@ -179,10 +191,10 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
       t.diag = gk == gq;
       t.n = gk < gq ? tiles_per_chunk : (gk > gq ? 0 : q_off_wg / KVT + 4);
       if (t.n > 0) {
-        const int64_t crow = p.kv_row[t.c];
+        const int64_t crow = p.kv_row[t.c] + (PACKED ? seg_j0 * KVT : 0);
         t.kp = kbase + crow * p.k_rs * 2;
         t.vp = vbase + crow * p.v_rs * 2;
-        t.j = 0;
+        t.j = PACKED ? seg_j0 : 0;                   // (t.n stays the absolute end: tiles seg_j0 .. t.n - 1)
         return;
       }
       ++t.c;
@@ -198,6 +210,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
     const int gk = p.kv_gid[c];
     n_tiles += gk < gq ? tiles_per_chunk : (gk > gq ? 0 : q_off_wg / KVT + 4);
   }
+  if constexpr (PACKED) n_tiles -= seg_j0;           // even, >= 4: seg_start[row] <= row
   if (n_tiles == 0) {
     // a launch over REMOTE chunks only (context parallelism: the rank's own chunks are attended to before the gather lands,
     // dot_product_attention.forward_cp): these rows see none of them -> O = 0, lse = -inf, the merge ignores this part
@@ -347,6 +360,21 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
         }
     }
   };
+  // packed samples: keys before a row's segment start (key >= seg_lo visible), same arithmetic
+  auto seg_mask_tile = [&](int par, int kv_off) __attribute__((always_inline)) {
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int base = kv_off + 4 * hi - seg_lo[qb];
+#pragma unroll
+      for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          const int kc = 32 * kb + (r & 3) + 8 * (r >> 2);
+          const float pen = fminf((float)(base + kc), 0.0f);
+          sb[par][qb][kb][r] = fmaf(pen, 3.0e38f, sb[par][qb][kb][r]);
+        }
+    }
+  };
   // O *= alpha (rare: only when a running maximum moved); every P V MFMA that precedes it has been issued
   auto rescale_o = [&]() __attribute__((always_inline)) {
     if (!__all(alpha[0] == 1.0f && alpha[1] == 1.0f)) {
@@ -364,6 +392,12 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
     }
   };
   auto needs_mask = [&](const TileIt& t) __attribute__((always_inline)) { return t.diag && t.j * KVT + KVT - 1 > q_off_wg; };
+  auto masks = [&](const TileIt& t, int par) __attribute__((always_inline)) {          // wave-uniform conditions
+    if (needs_mask(t)) mask_tile(par, t.j * KVT);
+    if constexpr (PACKED) {
+      if (t.j * KVT < seg_lo_max) seg_mask_tile(par, t.j * KVT);
+    }
+  };
 
   // ---- prologue: K(0), V(0), K(1) -> LDS; S(0); the start of its softmax -----------------------------------------------------
   TileIt cur;
@@ -378,7 +412,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
     __syncthreads();
     qk_phase(0, lds0 + LDS_K, false, 0);
     __syncthreads();                                  // every wave has read K(0): its ring slot may be refilled
-    if (needs_mask(cur)) mask_tile(0, cur.j * KVT);
+    masks(cur, 0);
 #pragma unroll
     for (int u = 0; u < 34 + 8 * NF2; ++u) {
       if (u < 34) max_unit(0, u);
@@ -393,7 +427,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
       if (more_k) { advance(nx2); dma_k(nx2, par); }  // K(t) in that slot was last read before the previous barrier
       dma_v(nx1, par ^ 1);
       qk_phase(par ^ 1, lds0 + LDS_K + (par ^ 1) * TILEB, true, par);
-      if (needs_mask(nx1)) mask_tile(par ^ 1, nx1.j * KVT);
+      masks(nx1, par ^ 1);
       pv_phase(par, lds0 + LDS_V + par * TILEB, true);
       rescale_o();
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
@@ -421,7 +455,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
     __syncthreads();
     qk_phase(0, lds0 + LDS_K, false, 0);
     __syncthreads();                                  // every wave has read K(0): slot 0 is refilled by the first pair
-    if (needs_mask(cur)) mask_tile(0, cur.j * KVT);
+    masks(cur, 0);
 #pragma unroll
     for (int u = 0; u < 34 + 8 * NF2; ++u) {
       if (u < 34) max_unit(0, u);
@@ -430,7 +464,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
     // one call: tile c in buffer par, K(c+1) in k_slot, V(c) in v_slot
     auto call = [&](int par, int k_slot, int v_slot) __attribute__((always_inline)) {
       qk_phase(par ^ 1, lds0 + LDS_K + k_slot * TILEB, true, par);
-      if (needs_mask(nx1)) mask_tile(par ^ 1, nx1.j * KVT);
+      masks(nx1, par ^ 1);
       pv_phase(par, lds0 + LDS_V + v_slot * TILEB, true);
       rescale_o();
       advance(nx1);
@@ -483,7 +517,8 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
 }  // namespace
 
 bool vita_attn64_eligible(const AttnArgs& a, int head_dim, bool causal) {
-  if (head_dim != 128 || !causal || a.seg_start) return false;
+  if (head_dim != 128 || !causal) return false;
+  if (a.seg_start && (a.n_q_chunks != 1 || a.n_kv_chunks != 1 || a.batch != 1)) return false;     // packed samples: one chunk (CP = 1)
   if (a.chunk_len % QTILE || a.q_valid != a.chunk_len || a.kv_valid != a.chunk_len) return false;
   // a tile's 64 rows x row stride must fit the 32-bit lane offset of the DMA
   if (a.k_rs * 2 * KVT >= (1ll << 31) || a.v_rs * 2 * KVT >= (1ll << 31)) return false;
@@ -495,13 +530,18 @@ bool vita_attn64_eligible(const AttnArgs& a, int head_dim, bool causal) {
 int vita_attn64_launch(const AttnArgs& a, int64_t nblocks, hipStream_t st) {
   static std::atomic<unsigned long long> attr_set{0};
   vita_device_once(attr_set, [&] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd64_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILEB);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd64_kernel<4>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILEB);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd64_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILEB);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd64_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILEB);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd64_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILEB);
   });
+  if (a.seg_start) {
+    hipLaunchKernelGGL((flash_fwd64_kernel<2, true>), dim3((unsigned)nblocks), dim3(256), 4 * TILEB, st, a);
+    return vita_check_launch();
+  }
   const char* e = vita_dev_getenv("VITA_ATTN64_RING");           // developer A/B switch: 4 = four-slot rings, a barrier every two tiles
   if (e && e[0] == '4')
-    hipLaunchKernelGGL(flash_fwd64_kernel<4>, dim3((unsigned)nblocks), dim3(256), 8 * TILEB, st, a);
+    hipLaunchKernelGGL((flash_fwd64_kernel<4, false>), dim3((unsigned)nblocks), dim3(256), 8 * TILEB, st, a);
   else
-    hipLaunchKernelGGL(flash_fwd64_kernel<2>, dim3((unsigned)nblocks), dim3(256), 4 * TILEB, st, a);
+    hipLaunchKernelGGL((flash_fwd64_kernel<2, false>), dim3((unsigned)nblocks), dim3(256), 4 * TILEB, st, a);
   return vita_check_launch();
 }

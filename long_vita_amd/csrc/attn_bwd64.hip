@@ -1,5 +1,5 @@
 // Flash attention backward, dQ, d = 128, causal, whole tiles: 4 waves x 64 query rows, one wave per SIMD (gfx950 / MI355X).
-// The fast path of vita_flash_attn_bwd's dQ pass; attn_bwd.hip keeps every other geometry (packed samples, ragged chunks).
+// The fast path of vita_flash_attn_bwd's dQ pass; attn_bwd.hip keeps every other geometry (ragged chunks, packed samples of ragged length).
 //
 // Same recipe as the forward's attn64.hip, for the three GEMMs of the dQ pass:
 //     S^T = K Q^T,   dP^T = V dO^T,   P^T = exp2(S^T c - lse),   dS^T = P^T o (dP^T - delta) scale,   dQ^T += K^T dS^T
@@ -36,6 +36,9 @@ struct TileIt {
   const char* vp;
 };
 
+// PACKED (r03): packed samples (p.seg_start, one chunk) — the workgroup starts at the tile of its first row's segment; halves that begin
+// before the segment of the wave's last row get a second arithmetic mask (key >= seg_start[row]), as in attn64.hip.
+template <bool PACKED>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(BwdArgs p) {
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
@@ -56,6 +59,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(BwdArgs p) {
   const int q_off_wg = qti * QTILE;
   const int q_off = q_off_wg + wave * 64;
   const float scale_log2e = p.scale_log2e, scale = p.scale;
+  int seg_j0 = 0, seg_lo[2] = {0, 0}, seg_lo_max = 0;
+  if constexpr (PACKED) {
+    const int* ss = p.seg_start + (int64_t)qc * p.chunk_len;
+    seg_j0 = ss[q_off_wg] / KVT;
+    seg_lo[0] = ss[q_off + l31]; seg_lo[1] = ss[q_off + 32 + l31];
+    seg_lo_max = __builtin_amdgcn_readfirstlane(ss[q_off + 63]);
+  }
 
   // ---- the wave's own rows: Q and dO fragments (MFMA B operands: row q_off + 32 qb + l31, d = 16 ds + 8 hi .. + 7), lse, delta ------
   bf16x8 qf[2][8], dof[2][8];
@@ -136,10 +146,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(BwdArgs p) {
       t.diag = gk == gq;
       t.n = gk < gq ? kv_tiles_per_chunk : (gk > gq ? 0 : q_off_wg / KVT + 4);
       if (t.n > 0) {
-        const int64_t crow = p.kv_row[t.c];
+        const int64_t crow = p.kv_row[t.c] + (PACKED ? seg_j0 * KVT : 0);
         t.kp = kbase + crow * p.k_rs * 2;
         t.vp = vbase + crow * p.v_rs * 2;
-        t.j = 0;
+        t.j = PACKED ? seg_j0 : 0;                   // (t.n stays the absolute end)
         return;
       }
       ++t.c;
@@ -155,6 +165,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(BwdArgs p) {
     const int gk = p.kv_gid[c];
     n_tiles += gk < gq ? kv_tiles_per_chunk : (gk > gq ? 0 : q_off_wg / KVT + 4);
   }
+  if constexpr (PACKED) n_tiles -= seg_j0;           // >= 4: seg_start[row] <= row
 
   // ---- state ---------------------------------------------------------------------------------------------------------------------
   f32x16 o[2][4];                                    // dQ^T[qb][db] (AGPRs)
@@ -207,6 +218,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(BwdArgs p) {
       }
     }
   };
+  auto seg_mask_half = [&](int par, int kv_off) __attribute__((always_inline)) {       // packed samples: key >= seg_lo is visible
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      const int base = kv_off + 4 * hi - seg_lo[qb];
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int kc = (r & 3) + 8 * (r >> 2);
+        const float pen = fminf((float)(base + kc), 0.0f);
+        sb[par][qb][r] = fmaf(pen, 3.0e38f, sb[par][qb][r]);
+      }
+    }
+  };
   // slots 0..15: S^T of the next half (kb_n of the tile at kf) into buffer par ^ 1; FILL: dS(par) behind them
   auto s_group = [&](int par, unsigned kf, int kb_n, bool fill) __attribute__((always_inline)) {
     bf16x8 fr[4];
@@ -250,6 +273,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(BwdArgs p) {
   auto sp_group = [&](int par, unsigned kf, unsigned vf, int kb_n, bool fill, bool masked, int mask_off) __attribute__((always_inline)) {
     s_group(par, kf, kb_n, fill);
     if (masked) mask_half(par ^ 1, mask_off);          // wave-uniform, diagonal tiles only; between the groups, not inside one
+    if constexpr (PACKED) {
+      if (mask_off < seg_lo_max) seg_mask_half(par ^ 1, mask_off);
+    }
     p_group(par, vf, kb_n, fill);
   };
   // slots 32..47: dQ^T += K^T(half kb of the tile at kt) dS^T(par); FILL: pairs 8..15 of P(par ^ 1)
@@ -341,7 +367,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(BwdArgs p) {
 }  // namespace
 
 bool vita_attn_bwd_dq64_eligible(const BwdArgs& a) {
-  if (a.seg_start || a.chunk_len % QTILE) return false;
+  if (a.chunk_len % QTILE) return false;
+  if (a.seg_start && (a.n_q_chunks != 1 || a.n_kv_chunks != 1)) return false;      // packed samples: one chunk
   for (int i = 0; i < a.n_q_chunks; ++i) {           // every query chunk meets its own keys (the diagonal) in this launch
     bool found = false;
     for (int j = 0; j < a.n_kv_chunks; ++j) found = found || a.kv_gid[j] == a.q_gid[i];
@@ -355,10 +382,12 @@ bool vita_attn_bwd_dq64_eligible(const BwdArgs& a) {
 int vita_attn_bwd_dq64_launch(const BwdArgs& a, hipStream_t st) {
   static std::atomic<unsigned long long> attr_set{0};
   vita_device_once(attr_set, [&] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq64_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq64_kernel<false>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq64_kernel<true>), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES);
   });
   const int64_t n = (int64_t)a.n_q_heads * a.n_q_chunks * (a.chunk_len / QTILE);
   if (n > 0x7fffffff) return VITA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(attn_bwd_dq64_kernel, dim3((unsigned)n), dim3(256), LDS_BYTES, st, a);
+  if (a.seg_start) hipLaunchKernelGGL(attn_bwd_dq64_kernel<true>, dim3((unsigned)n), dim3(256), LDS_BYTES, st, a);
+  else hipLaunchKernelGGL(attn_bwd_dq64_kernel<false>, dim3((unsigned)n), dim3(256), LDS_BYTES, st, a);
   return vita_check_launch();
 }

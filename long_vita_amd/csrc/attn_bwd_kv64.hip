@@ -37,7 +37,10 @@ struct QTileIt {
   const char* dlp;
 };
 
-template <bool IS_DK>
+// PACKED (r03): packed samples (p.seg_end: one past the last row of each KEY's segment, non-decreasing; one chunk) — the walk over the
+// query tiles ends with the segment of the workgroup's last key; halves that reach past the segment end of the wave's FIRST key get a
+// second arithmetic mask (row < seg_end[key] is visible).
+template <bool IS_DK, bool PACKED>
 __global__ __launch_bounds__(256, 1) void attn_bwd_kv64_kernel(BwdArgs p) {
   // LDS: fragment-layout ring A [3] (Q) | fragment-layout ring B [3] (dO, IS_DK only) | transposed ring [2] (Q^T or dO^T) | stats [3] x 512 B
   constexpr int LDS_FA = 0, LDS_FB = 3 * TILEB, LDS_TR = IS_DK ? 6 * TILEB : 3 * TILEB, LDS_ST = LDS_TR + 2 * TILEB;
@@ -57,6 +60,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv64_kernel(BwdArgs p) {
   const int k_off = k_off_wg + wave * 64;               // this wave's first key inside the chunk
   const int64_t k_row0 = p.kv_row[kc] + k_off;          // its row in the K / V buffers
   const float scale_log2e = p.scale_log2e, scale = p.scale;
+  int seg_jend = 0, seg_hi[2] = {0, 0}, seg_hi_min = 0;
+  if constexpr (PACKED) {
+    const int* se = p.seg_end + p.kv_row[kc];
+    seg_jend = (se[k_off_wg + KTILE - 1] + QT - 1) / QT;         // >= k_off_wg / QT + 4: seg_end[key] > key
+    seg_hi[0] = se[k_off + l31]; seg_hi[1] = se[k_off + 32 + l31];
+    seg_hi_min = __builtin_amdgcn_readfirstlane(se[k_off]);
+  }
 
   // ---- the wave's own keys: K (and V) fragments as MFMA B operands (key k_off + 32 kb + l31, d = 16 ds + 8 hi .. + 7) ------------------
   bf16x8 kf[2][8], vf[2][8];
@@ -139,7 +149,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv64_kernel(BwdArgs p) {
         if (gq >= gk) {
           t.diag = gq == gk;
           t.j = t.diag ? j0 : 0;
-          t.jend = q_tiles_per_chunk;
+          t.jend = PACKED ? seg_jend : q_tiles_per_chunk;
           const int64_t row = (int64_t)t.c * p.chunk_len + (int64_t)t.j * QT;
           const int head = kvh * G + t.hq;
           t.qp = qbase + ((int64_t)t.hq * p.q_hs + row * p.q_rs) * 2;
@@ -161,7 +171,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv64_kernel(BwdArgs p) {
   int n_tiles = 0;                                       // >= 4 G: the own chunk contributes at least four tiles
   for (int c = 0; c < p.n_q_chunks; ++c) {
     const int gq = p.q_gid[c];
-    n_tiles += gq > gk ? q_tiles_per_chunk : (gq == gk ? q_tiles_per_chunk - j0 : 0);
+    n_tiles += gq > gk ? q_tiles_per_chunk : (gq == gk ? (PACKED ? seg_jend : q_tiles_per_chunk) - j0 : 0);
   }
   n_tiles *= G;
   if (n_tiles == 0) {                                    // context parallelism: a key chunk none of the local queries can see
@@ -247,6 +257,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv64_kernel(BwdArgs p) {
       }
     }
   };
+  auto seg_mask_half = [&](int par, int q_off_h) __attribute__((always_inline)) {       // packed samples: row < seg_hi[key] is visible
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      const int base = seg_hi[kb] - 1 - q_off_h - 4 * hi;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        const int rc = (r & 3) + 8 * (r >> 2);
+        const float pen = fminf((float)(base - rc), 0.0f);
+        sb[par][kb][r] = fmaf(pen, 3.0e38f, sb[par][kb][r]);
+      }
+    }
+  };
   // 16 slots: S of the next half (rows qh_n of the tile at fa) into buffer par ^ 1; FILL: dS / pack of half `par` behind them
   auto s_group = [&](int par, unsigned fa, int qh_n, bool fill) __attribute__((always_inline)) {
     bf16x8 fr[4];
@@ -312,6 +334,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv64_kernel(BwdArgs p) {
     if (fill && IS_DK) load_delta(lds0 + LDS_ST + slot_cur * 512, qh_cur);
     s_group(par, lds0 + LDS_FA + slot3 * TILEB, qh_n, fill);
     if (needs_mask(tn)) mask_half(par ^ 1, tn.j * QT + 32 * qh_n);       // wave-uniform, diagonal tiles only
+    if constexpr (PACKED) {
+      if (tn.j * QT + 32 * qh_n + 31 >= seg_hi_min) seg_mask_half(par ^ 1, tn.j * QT + 32 * qh_n);
+    }
     load_lse(lds0 + LDS_ST + slot3 * 512, qh_n);
     if (IS_DK) p_group(par, lds0 + LDS_FB + slot3 * TILEB, qh_n, fill);
   };
@@ -385,29 +410,34 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv64_kernel(BwdArgs p) {
   }
 }
 
-template <bool IS_DK>
+template <bool IS_DK, bool PACKED>
 int launch_kv64(const BwdArgs& a, hipStream_t st) {
   constexpr int lds = (IS_DK ? 8 : 5) * TILEB + 3 * 512;
   static std::atomic<unsigned long long> attr_set{0};
   vita_device_once(attr_set, [&] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kv64_kernel<IS_DK>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kv64_kernel<IS_DK, PACKED>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
   });
   const int64_t n = (int64_t)a.n_kv_heads * a.n_kv_chunks * (a.chunk_len / KTILE);
   if (n > 0x7fffffff) return VITA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(attn_bwd_kv64_kernel<IS_DK>, dim3((unsigned)n), dim3(256), lds, st, a);
+  hipLaunchKernelGGL((attn_bwd_kv64_kernel<IS_DK, PACKED>), dim3((unsigned)n), dim3(256), lds, st, a);
   return vita_check_launch();
 }
 
 }  // namespace
 
 bool vita_attn_bwd_kv64_eligible(const BwdArgs& a) {
-  if (a.seg_start || a.chunk_len % KTILE) return false;     // (a key chunk sees whole chunks, its own from the diagonal on, or nothing)
+  if (a.chunk_len % KTILE) return false;                    // (a key chunk sees whole chunks, its own from the diagonal on, or nothing)
+  if (a.seg_start && (a.n_q_chunks != 1 || a.n_kv_chunks != 1)) return false;      // packed samples: one chunk
   if ((int64_t)QT * a.q_rs * 2 > 0x7fffffffLL || (int64_t)QT * a.do_rs * 2 > 0x7fffffffLL) return false;
   const char* e = vita_dev_getenv("VITA_ATTN_BWD64");
   return !(e && e[0] == '0');
 }
 
 int vita_attn_bwd_kv64_launch(const BwdArgs& a, hipStream_t st) {
-  const int rc = launch_kv64<true>(a, st);
-  return rc != VITA_OK ? rc : launch_kv64<false>(a, st);
+  if (a.seg_start) {
+    const int rc = launch_kv64<true, true>(a, st);
+    return rc != VITA_OK ? rc : launch_kv64<false, true>(a, st);
+  }
+  const int rc = launch_kv64<true, false>(a, st);
+  return rc != VITA_OK ? rc : launch_kv64<false, false>(a, st);
 }

@@ -952,7 +952,14 @@ def test_adaptor_stacks_on_top_of_the_references_adaptor():
                           ("megatron.core.models.common.embeddings.language_model_embedding.LanguageModelEmbedding", RefEmbedding),
                           ("megatron.core.tensor_parallel.layers.ColumnParallelLinear", RefColumnParallelLinear)]:
             ref_mgr.register_patch(name, obj, create_dummy=True)
-        ref_mgr.apply_patches()
+        # the reference's manager probes EVERY loaded module with hasattr(module, name) (M/patch_utils.py:67-70); a lazily-importing
+        # package an earlier test loaded (transformers: its stubs import torchvision on first touch) answers that with an
+        # ImportError, which has nothing to do with Megatron — keep such packages out of its sight while it runs
+        lazy = {k: sys.modules.pop(k) for k in list(sys.modules) if k.split(".")[0] in ("transformers", "datasets", "accelerate")}
+        try:
+            ref_mgr.apply_patches()
+        finally:
+            sys.modules.update(lazy)
         specs = sys.modules["megatron.core.models.gpt.gpt_layer_specs"]
         assert specs.get_gpt_layer_local_spec() == "reference local spec"
         # a module of the host framework that imported the reference's replacements by name (pretrain_long_vita.py does)

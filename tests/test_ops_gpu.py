@@ -360,8 +360,10 @@ def test_vit_front_back_kernels(ops):
 # ---------------------------------------------------------------------------------------------
 # packed sequences: block-diagonal causal attention, forward and backward
 # ---------------------------------------------------------------------------------------------
+# S % 256 == 0: the 64-row kernels' packed variants (attn64.hip / attn_bwd64.hip / attn_bwd_kv64.hip, r03); otherwise attn.hip / attn_bwd.hip
 @pytest.mark.parametrize("S,cu", [(1024, [0, 300, 301, 777, 1024]), (2048, [0, 2048]), (1536, [0, 64, 128, 900]),
-                                  (512, [0, 255, 256, 257, 512])])
+                                  (512, [0, 255, 256, 257, 512]), (4096, [0, 1, 70, 1400, 1408, 3333]), (896, [0, 100, 640]),
+                                  (2048, [0, 256, 512, 1024, 1280])])
 def test_flash_attn_packed_sequences_fwd_bwd(ops, S, cu):
     from oracle import attention as oattn
     Hq, Hkv, D = 10, 2, 128
