@@ -43,11 +43,114 @@ __global__ __launch_bounds__(256) void transpose_kernel(const bf16_t* __restrict
 // RMSNorm backward.  forward (transformer_engine.py:74-79):  n = x_f * rstd (fp32) ;
 //   o = bf16(n) ; y = bf16(o * w).      autograd:  do = bf16(dy * w) ; dn = float(do) ;
 //   dx = bf16( rstd * (dn - n * mean(dn * n)) ) ;  dw = sum_rows bf16(dy * o).
-// One wave per row (strided over rows); dw accumulated per lane in registers, flushed with fp32
-// atomics into dw_acc[cols] (caller zeroes it).
+// r03 kernel (cols <= 6144): a WORKGROUP per row (strided over rows), 256 lanes x VPL 16-byte vectors; sum(x^2) and sum(do * x) come
+// out of ONE pass and one barrier (mean(do * n) = rstd * sum(do * x) / cols), the weight row lives in registers, every lane owns the
+// same 8 VPL columns for all rows and sums their dw in registers; 512 workgroups = 2 per CU.  At the end dw goes through LDS so that a
+// wave's atomic instruction covers 64 consecutive columns: all workgroups' atomics meet on the same cols / 32 cache lines, and it is
+// line operations they cost (lane-strided: 0.15 ms per call; consecutive: 0.02 ms).  Measured at 5120 columns with dw and the
+// residual branch, 16384 / 131072 rows: 0.17 / 1.13 ms = 3.9 / 4.7 TB/s (r02 kernel: 0.46 / 3.58 ms; profiles/r03_rmsnorm_bwd_ab.jsonl).
+// rmsnorm_bwd_wave_kernel (r02: a wave per row, dw in 8 VPL registers per lane) keeps the wider rows.
 // ---------------------------------------------------------------------------------------------
 template <int VPL>
-__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy,
+__global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ x,
+                                                             const bf16_t* __restrict__ w, const bf16_t* __restrict__ res,
+                                                             bf16_t* __restrict__ dx, float* __restrict__ dw_acc, int64_t rows,
+                                                             int cols, float eps) {
+  __shared__ float red[2 * 4 * 2];                   // [parity][wave][ss, dr]
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nvec = cols >> 3;
+  float dwl[VPL][8];                                 // this lane's columns 8 (tid + 256 i) .. + 7, summed over the workgroup's rows
+#pragma unroll
+  for (int i = 0; i < VPL; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) dwl[i][j] = 0.f;
+  const u32x4* wr = reinterpret_cast<const u32x4*>(w);
+  u32x4 wv4[VPL];
+#pragma unroll
+  for (int i = 0; i < VPL; ++i) {
+    const int vi = tid + i * 256;
+    if (vi < nvec) wv4[i] = wr[vi];
+  }
+  int par = 0;
+  for (int64_t row = blockIdx.x; row < rows; row += gridDim.x, par ^= 1) {
+    const u32x4* xr = reinterpret_cast<const u32x4*>(x + row * (int64_t)cols);
+    const u32x4* gr = reinterpret_cast<const u32x4*>(dy + row * (int64_t)cols);
+    const u32x4* rr = reinterpret_cast<const u32x4*>(res + row * (int64_t)cols);
+    u32x4 xv[VPL], gv[VPL], rv[VPL];
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int vi = tid + i * 256;
+      if (vi < nvec) {
+        xv[i] = xr[vi]; gv[i] = gr[vi];
+        if (res) rv[i] = rr[vi];
+      }
+    }
+    float ss = 0.f, dr = 0.f;
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      if (tid + i * 256 < nvec) {
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float a = bf16lo_to_f32(xv[i][j]), b = bf16hi_to_f32(xv[i][j]);
+          const float d0 = bf16_round(bf16lo_to_f32(gv[i][j]) * bf16lo_to_f32(wv4[i][j]));
+          const float d1 = bf16_round(bf16hi_to_f32(gv[i][j]) * bf16hi_to_f32(wv4[i][j]));
+          ss += a * a + b * b;
+          dr += d0 * a + d1 * b;
+        }
+      }
+    }
+    ss = wave_reduce_sum(ss); dr = wave_reduce_sum(dr);
+    if (lane == 0) { red[(par * 4 + wv) * 2] = ss; red[(par * 4 + wv) * 2 + 1] = dr; }
+    __syncthreads();
+    float ss_t = 0.f, dr_t = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) { ss_t += red[(par * 4 + k) * 2]; dr_t += red[(par * 4 + k) * 2 + 1]; }
+    const float rstd = rsqrtf(ss_t / (float)cols + eps);
+    const float c = dr_t * rstd / (float)cols;       // mean(do * n), n = x * rstd
+    u32x4* dxr = reinterpret_cast<u32x4*>(dx + row * (int64_t)cols);
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int vi = tid + i * 256;
+      if (vi < nvec) {
+        u32x4 o;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          const float x0 = bf16lo_to_f32(xv[i][j]) * rstd, x1 = bf16hi_to_f32(xv[i][j]) * rstd;
+          const float g0 = bf16lo_to_f32(gv[i][j]), g1 = bf16hi_to_f32(gv[i][j]);
+          const float d0 = bf16_round(g0 * bf16lo_to_f32(wv4[i][j])), d1 = bf16_round(g1 * bf16hi_to_f32(wv4[i][j]));
+          dwl[i][2 * j] += bf16_round(g0 * bf16_round(x0));
+          dwl[i][2 * j + 1] += bf16_round(g1 * bf16_round(x1));
+          float r0 = rstd * (d0 - x0 * c), r1 = rstd * (d1 - x1 * c);
+          if (res) {
+            r0 = bf16_round(r0) + bf16lo_to_f32(rv[i][j]);
+            r1 = bf16_round(r1) + bf16hi_to_f32(rv[i][j]);
+          }
+          o[j] = pack_bf16x2(r0, r1);
+        }
+        dxr[vi] = o;
+      }
+    }
+  }
+  if (dw_acc) {
+    // flush through LDS so that a wave's atomic instruction covers 64 CONSECUTIVE columns (two cache lines) instead of 64 columns
+    // 32 bytes apart (sixteen lines): the atomics of all workgroups meet on the same cols / 32 lines, and line operations are what they cost
+    extern __shared__ float dw_lds[];                // [8][nvec]: element e of vector vi at e * nvec + vi (bank = lane)
+#pragma unroll
+    for (int i = 0; i < VPL; ++i) {
+      const int vi = tid + i * 256;
+      if (vi < nvec) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) dw_lds[j * nvec + vi] = dwl[i][j];
+      }
+    }
+    __syncthreads();
+    for (int i = tid; i < cols; i += 256) atomicAdd(dw_acc + i, dw_lds[(i & 7) * nvec + (i >> 3)]);
+  }
+}
+
+
+template <int VPL>
+__global__ __launch_bounds__(256) void rmsnorm_bwd_wave_kernel(const bf16_t* __restrict__ dy,
                                                           const bf16_t* __restrict__ x,
                                                           const bf16_t* __restrict__ w,
                                                           const bf16_t* __restrict__ res,
@@ -146,6 +249,7 @@ __global__ __launch_bounds__(256) void rmsnorm_bwd_kernel(const bf16_t* __restri
     }
   }
 }
+
 
 // ---------------------------------------------------------------------------------------------
 // SwiGLU on the unfused fc1 output y = [gate | up]  ([rows, 2F] bf16):
@@ -613,10 +717,18 @@ extern "C" int vita_rmsnorm_bwd(const void* dy, const void* x, const void* w, co
   if (!dy || !x || !w || !dx || rows < 0 || cols <= 0) return VITA_ERR_INVALID_ARG;
   if ((cols & 7) || cols > 8192) return VITA_ERR_UNSUPPORTED;
   if (rows == 0) return VITA_OK;
-  const int vpl = (cols + 511) / 512;
-  dim3 grid((unsigned)((rows + 3) / 4 < 512 ? (rows + 3) / 4 : 512)), block(256);   // 2 workgroups per CU
   hipStream_t st = (hipStream_t)stream;
-#define VITA_RB(V) hipLaunchKernelGGL(rmsnorm_bwd_kernel<V>, grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)res, (bf16_t*)dx, dw_acc, rows, cols, eps)
+  const char* e = vita_dev_getenv("VITA_RMSNORM_BWD");           // developer A/B switch: "o" = the r02 wave-per-row kernel everywhere
+  if (cols <= 6144 && !(e && e[0] == 'o')) {
+    dim3 grid((unsigned)(rows < 512 ? rows : 512)), block(256);  // 2 workgroups per CU
+#define VITA_RW(V) hipLaunchKernelGGL(rmsnorm_bwd_kernel<V>, grid, block, (size_t)cols * 4, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)res, (bf16_t*)dx, dw_acc, rows, cols, eps)
+    if (cols <= 2048) VITA_RW(1); else if (cols <= 4096) VITA_RW(2); else VITA_RW(3);
+#undef VITA_RW
+    return vita_check_launch();
+  }
+  const int vpl = (cols + 511) / 512;
+  dim3 grid((unsigned)((rows + 3) / 4 < 512 ? (rows + 3) / 4 : 512)), block(256);
+#define VITA_RB(V) hipLaunchKernelGGL(rmsnorm_bwd_wave_kernel<V>, grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, (const bf16_t*)res, (bf16_t*)dx, dw_acc, rows, cols, eps)
   if (vpl <= 2) VITA_RB(2); else if (vpl <= 4) VITA_RB(4); else if (vpl <= 8) VITA_RB(8); else if (vpl <= 10) VITA_RB(10); else VITA_RB(16);
 #undef VITA_RB
   return vita_check_launch();

@@ -102,6 +102,9 @@ def _run_ranks(cp, fn, amd, monkeypatch):
         flat = out.view(grp.cp, -1)
         for q, v in enumerate(vals):
             flat[q].copy_(v.reshape(-1))
+        # every rank has ENQUEUED its copies before any owner goes on: an owner that drops `inp` right after the collective (a send
+        # buffer local to an autograd node) hands the block back to the allocator, and a copy enqueued later would read its next tenant
+        grp.barrier.wait()
 
     def reduce_scatter_tensor(out, inp, group=None, async_op=False, op=None):
         r, vals = rendezvous(inp)
@@ -314,6 +317,7 @@ def _run_grid(tp, cp, fn, amd, monkeypatch):
         flat = out.view(group.size, -1)
         for q, v in enumerate(vals):
             flat[q].copy_(v.reshape(-1))
+        group.barrier.wait()                                # (see _run_ranks: copies enqueued before an owner may free `inp`)
 
     def reduce_scatter_tensor(out, inp, group=None, async_op=False, op=None):
         r, vals = rendezvous(group, inp)
