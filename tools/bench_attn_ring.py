@@ -11,15 +11,21 @@ DEV = "cuda"
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
 LOG = open(os.path.join(ROOT, "gpurun_out", "r03_attn_ring.jsonl"), "a")
 Hq, Hkv, D = 40, 8, 128
-for S in [int(x) for x in (sys.argv[1:] or ["16384", "32768", "131072"])]:
+# generalised: --var NAME A B switches any developer variable between two values (default: the ring depth 2 vs 4)
+VAR, VA, VB = "VITA_ATTN64_RING", "2", "4"
+argv = sys.argv[1:]
+if argv[:1] == ["--var"]:
+    VAR, VA, VB = argv[1:4]
+    argv = argv[4:]
+for S in [int(x) for x in (argv or ["16384", "32768", "131072"])]:
     g = torch.Generator(device=DEV).manual_seed(S)
     q = torch.randn(1, S, Hq, D, generator=g, device=DEV).bfloat16()
     k = torch.randn(1, S, Hkv, D, generator=g, device=DEV).bfloat16()
     v = torch.randn(1, S, Hkv, D, generator=g, device=DEV).bfloat16()
-    outs, times = {}, {"2": [], "4": []}
+    outs, times = {}, {VA: [], VB: []}
     for rnd in range(4):
-        for ring in ("2", "4"):
-            os.environ["VITA_ATTN64_RING"] = ring
+        for ring in (VA, VB):
+            os.environ[VAR] = ring
             o = torch.empty_like(q)
             ops.flash_attn(q, k, v, causal=True, out=o)          # warm
             a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
@@ -30,9 +36,9 @@ for S in [int(x) for x in (sys.argv[1:] or ["16384", "32768", "131072"])]:
             times[ring].append(a.elapsed_time(b) / 2)
             outs[ring] = o
     fl = 4.0 * D * Hq * S * (S + 1) / 2
-    rec = {"kind": "attn64_ring_ab", "S": S, "ms_ring2": sorted(times["2"]), "ms_ring4": sorted(times["4"]),
-           "tflops_ring2_median": fl / sorted(times["2"])[1] / 1e9, "tflops_ring4_median": fl / sorted(times["4"])[1] / 1e9,
-           "bit_identical": bool(torch.equal(outs["2"], outs["4"])),
-           "max_abs_diff": float((outs["2"].float() - outs["4"].float()).abs().max())}
+    rec = {"kind": "attn64_ab", "var": VAR, "S": S, "ms_" + VA: sorted(times[VA]), "ms_" + VB: sorted(times[VB]),
+           "tflops_%s_median" % VA: fl / sorted(times[VA])[1] / 1e9, "tflops_%s_median" % VB: fl / sorted(times[VB])[1] / 1e9,
+           "bit_identical": bool(torch.equal(outs[VA], outs[VB])),
+           "max_abs_diff": float((outs[VA].float() - outs[VB].float()).abs().max())}
     print(json.dumps(rec), flush=True)
     LOG.write(json.dumps(rec) + "\n"); LOG.flush()
