@@ -91,7 +91,7 @@ struct TileIt {
 // starts at the (even) tile of its first row's segment, and a tile that begins before the segment of the wave's LAST row gets a
 // second arithmetic mask (key >= seg_start[row]); rows whose segment starts later see such tiles as all-masked: P = 0, the running
 // maximum stays at its initial -1e30 and the first visible tile rescales the (zero) state by exp2(-1e30 - m) = 0.
-template <int NSLOT, bool PACKED, bool PK = false>
+template <int NSLOT, bool PACKED>
 __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
   constexpr int LDS_V = NSLOT * TILEB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -242,9 +242,6 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
   unsigned pk[2][2][4][4];                           // packed P^T[parity][qb][frag f][4 dwords]; frag f = regs 8 (f & 1) .. of kb = f >> 1
   float m_run[2] = {-1.0e30f, -1.0e30f}, l_run[2] = {0.f, 0.f}, m_neg[2], alpha[2] = {1.f, 1.f}, mxc[4];
   float ea = 0.f, eb = 0.f, mx0_keep = 0.f;
-  // PK (r03 experiment, VITA_ATTN64_PK=1): the scale-subtract and the row sums as packed fp32 pairs (v_pk_fma_f32 / v_pk_add_f32)
-  typedef float f32x2 __attribute__((ext_vector_type(2)));
-  f32x2 l2[2] = {{0.f, 0.f}, {0.f, 0.f}};
 
   constexpr SlotMap MAP1 = make_map1(), MAP2 = make_map2();
 
@@ -252,20 +249,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
   // half 0: the two fma + exp2 of the pair, half 1: row sum, bf16 pack (an exp2 result is never consumed by the next instruction)
   auto exp_half = [&](int par, int h) __attribute__((always_inline)) {
     const int g = h >> 3, pr = (h >> 1) & 3, qb = g & 1, f = g >> 1, kb = f >> 1, r = 8 * (f & 1) + 2 * pr;
-    if constexpr (PK) {
-      if ((h & 1) == 0) {
-        const f32x2 s2 = {sb[par][qb][kb][r], sb[par][qb][kb][r + 1]};
-        const f32x2 c2 = {scale_log2e, scale_log2e}, m2 = {m_neg[qb], m_neg[qb]};
-        const f32x2 t = __builtin_elementwise_fma(s2, c2, m2);
-        ea = __builtin_amdgcn_exp2f(t[0]);
-        eb = __builtin_amdgcn_exp2f(t[1]);
-      } else {
-        const f32x2 e2 = {ea, eb};
-        l2[qb] += e2;
-        pk[par][qb][f][pr] = pack_bf16x2(ea, eb);
-        asm volatile("" :: "v"(pk[par][qb][f][pr]), "v"(l2[qb]));
-      }
-    } else if ((h & 1) == 0) {
+    if ((h & 1) == 0) {
       ea = __builtin_amdgcn_exp2f(fmaf(sb[par][qb][kb][r], scale_log2e, m_neg[qb]));
       eb = __builtin_amdgcn_exp2f(fmaf(sb[par][qb][kb][r + 1], scale_log2e, m_neg[qb]));
     } else {
@@ -294,7 +278,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
         alpha[qb2] = __builtin_amdgcn_exp2f(m_run[qb2] - m_new);
         m_run[qb2] = m_new;
         m_neg[qb2] = -m_new;
-        if constexpr (PK) { const f32x2 a2 = {alpha[qb2], alpha[qb2]}; l2[qb2] *= a2; } else l_run[qb2] *= alpha[qb2];
+        l_run[qb2] *= alpha[qb2];
       }
     }
   };
@@ -510,7 +494,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
   asm volatile("s_nop 15\n\ts_nop 15" : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[0][2]), "+a"(o[0][3]), "+a"(o[1][0]), "+a"(o[1][1]), "+a"(o[1][2]), "+a"(o[1][3]));
 #pragma unroll
   for (int qb = 0; qb < 2; ++qb) {
-    const float l_tot = swap32_sum(PK ? l2[qb][0] + l2[qb][1] : l_run[qb]);
+    const float l_tot = swap32_sum(l_run[qb]);
     const float inv = l_tot > 0.f ? 1.0f / l_tot : 0.f;
     const int64_t orow = (int64_t)qc * p.chunk_len + q_off + 32 * qb + l31;
     bf16_t* op = p.o + (int64_t)b * p.o_bs + orow * p.o_rs + (int64_t)kvh * p.o_gs + (int64_t)hq * p.o_hs;
@@ -549,15 +533,9 @@ int vita_attn64_launch(const AttnArgs& a, int64_t nblocks, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd64_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILEB);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd64_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILEB);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd64_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILEB);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd64_kernel<2, false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILEB);
   });
   if (a.seg_start) {
     hipLaunchKernelGGL((flash_fwd64_kernel<2, true>), dim3((unsigned)nblocks), dim3(256), 4 * TILEB, st, a);
-    return vita_check_launch();
-  }
-  const char* pk = vita_dev_getenv("VITA_ATTN64_PK");             // developer A/B switch: packed fp32 softmax arithmetic
-  if (pk && pk[0] == '1') {
-    hipLaunchKernelGGL((flash_fwd64_kernel<2, false, true>), dim3((unsigned)nblocks), dim3(256), 4 * TILEB, st, a);
     return vita_check_launch();
   }
   const char* e = vita_dev_getenv("VITA_ATTN64_RING");           // developer A/B switch: 4 = four-slot rings, a barrier every two tiles
