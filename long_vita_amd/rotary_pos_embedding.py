@@ -49,21 +49,24 @@ class RotaryEmbedding:
         return local_rows * mpu.get_context_parallel_world_size()
 
 
-_COS_SIN_CACHE = {"ref": None, "version": None, "val": None}
+_COS_SIN_CACHE = {"entry": None}              # (weakref to the angle tensor, its version, (cos, sin)): ONE object, replaced whole
 
 
 def _cos_sin(freqs):
     """`freqs` is either this module's (cos, sin) pair or Megatron's fp32 angle tensor [s, 1, 1, dim]
     (rotary_pos_embedding.py:106-108), which every one of the 48 layers passes again: the bf16 tables are built once per
     tensor — keyed by the tensor OBJECT (a weak reference: a freed tensor whose address is re-used by another one never hits)
-    and its version counter."""
+    and its version counter.  The entry is read once and replaced as a whole, and a miss returns the tables it has just built,
+    never what the cache holds afterwards: threads that drive different ranks in one process (the simulated-rank tests) alternate
+    angle tensors, and a key / value pair written in two steps handed one rank the other rank's tables."""
     if isinstance(freqs, (tuple, list)):
         return freqs
-    ref = _COS_SIN_CACHE["ref"]
-    if ref is None or ref() is not freqs or _COS_SIN_CACHE["version"] != freqs._version:
-        _COS_SIN_CACHE["val"] = ops.rope_cos_sin(freqs)
-        _COS_SIN_CACHE["ref"], _COS_SIN_CACHE["version"] = weakref.ref(freqs), freqs._version
-    return _COS_SIN_CACHE["val"]
+    entry = _COS_SIN_CACHE["entry"]
+    if entry is not None and entry[0]() is freqs and entry[1] == freqs._version:
+        return entry[2]
+    val = ops.rope_cos_sin(freqs)
+    _COS_SIN_CACHE["entry"] = (weakref.ref(freqs), freqs._version, val)
+    return val
 
 
 def apply_rotary_pos_emb(t: torch.Tensor, freqs, config=None, cu_seqlens=None) -> torch.Tensor:

@@ -84,6 +84,17 @@ class _FakeGroup:
         self.cp, self.slots, self.barrier = cp, {}, threading.Barrier(cp)
 
 
+def _ring_sum(parts, r):
+    """Segment r of a ring reduce-scatter over len(parts) ranks: rank r + 1 sends first, every hop adds the next rank's part in the
+    tensor's dtype (RCCL reduces bf16 in bf16: one rounding per hop), rank r adds last."""
+    n = len(parts)
+    acc = parts[(r + 1) % n]
+    for h in range(2, n + 1):
+        nxt = parts[(r + h) % n]
+        acc = (acc.float() + nxt.float()).to(nxt.dtype)
+    return acc
+
+
 def _run_ranks(cp, fn, amd, monkeypatch):
     import torch.distributed as dist
     grp = _FakeGroup(cp)
@@ -108,8 +119,7 @@ def _run_ranks(cp, fn, amd, monkeypatch):
 
     def reduce_scatter_tensor(out, inp, group=None, async_op=False, op=None):
         r, vals = rendezvous(inp)
-        acc = sum(v.view(grp.cp, -1)[r].float() for v in vals)
-        out.view(-1).copy_(acc.to(out.dtype))
+        out.view(-1).copy_(_ring_sum([v.view(grp.cp, -1)[r] for v in vals], r))
         grp.barrier.wait()
 
     def all_reduce(t, group=None, op=None, async_op=False):
@@ -321,7 +331,7 @@ def _run_grid(tp, cp, fn, amd, monkeypatch):
 
     def reduce_scatter_tensor(out, inp, group=None, async_op=False, op=None):
         r, vals = rendezvous(group, inp)
-        out.view(-1).copy_(sum(v.view(group.size, -1)[r].float() for v in vals).to(out.dtype))
+        out.view(-1).copy_(_ring_sum([v.view(group.size, -1)[r] for v in vals], r))
         group.barrier.wait()
 
     def all_reduce(t, group=None, op=None, async_op=False):
