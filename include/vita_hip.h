@@ -342,6 +342,9 @@ int vita_layernorm_param_grad(const void* dy, const void* x, float* dgamma, floa
 int vita_layernorm_bwd(const void* dy, const void* x, const void* w, void* dx, float* dgamma, float* dbeta,
                        int64_t rows, int cols, float eps, void* stream);
 int vita_gelu_fwd(const void* x, void* a, int64_t n, int tanh_form, void* stream);
+/* ABI 14: dx = bf16(dy * gelu_tanh'(x)) — the backward of `partial(F.gelu, approximate="tanh")`, SigLIP's activation
+ * (M/pretrain_long_vita.py:290; SigLIPViTTransformerLayer's MLP, M/core/models/vision/siglip_vit_model.py:29-86). */
+int vita_gelu_tanh_bwd(const void* x, const void* dy, void* dx, int64_t n, void* stream);
 int vita_bias_scale_res_fwd(const void* x, const void* bias, const void* scale, const void* residual, void* out,
                             int64_t rows, int cols, void* stream);
 int vita_bias_scale_res_bwd(const void* g, const void* x, const void* bias, const void* scale, void* dx, float* d_bias,

@@ -266,17 +266,19 @@ class LayerNormFn(torch.autograd.Function):
 
 
 class GeluFn(torch.autograd.Function):
-    """bf16(gelu(x)), erf form (`args.activation_func = torch.nn.functional.gelu`, M/pretrain_long_vita.py:207): vita_gelu_fwd / vita_gelu_bwd."""
+    """bf16(gelu(x)): erf form (`args.activation_func = torch.nn.functional.gelu`, M/pretrain_long_vita.py:207) or, `tanh=True`, the
+    tanh approximation of SigLIP (`partial(F.gelu, approximate="tanh")`, :290): vita_gelu_fwd / vita_gelu_bwd / vita_gelu_tanh_bwd."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, tanh=False):
         ctx.save_for_backward(x)
-        return ops.gelu(x.contiguous())
+        ctx.tanh = bool(tanh)
+        return ops.gelu(x.contiguous(), tanh=ctx.tanh)
 
     @staticmethod
     def backward(ctx, g):
         (x,) = ctx.saved_tensors
-        return ops.gelu_bwd(x.contiguous(), g.contiguous()).view_as(x)
+        return ops.gelu_bwd(x.contiguous(), g.contiguous(), tanh=ctx.tanh).view_as(x), None
 
 
 class BiasScaleResidualFn(torch.autograd.Function):

@@ -308,9 +308,10 @@ __global__ __launch_bounds__(256) void swiglu_bwd_kernel(const bf16_t* __restric
 }
 
 // GELU (erf) backward: dx = bf16(dy * gelu'(x))
+// tanh_form: d/dx [0.5 x (1 + tanh u)], u = c (x + 0.044715 x^3)  =  0.5 (1 + tanh u) + 0.5 x (1 - tanh^2 u) c (1 + 0.134145 x^2)   (SigLIP)
 __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict__ x,
                                                        const bf16_t* __restrict__ dy,
-                                                       bf16_t* __restrict__ dx, int64_t n8) {
+                                                       bf16_t* __restrict__ dx, int64_t n8, int tanh_form) {
   for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n8;
        i += (int64_t)gridDim.x * blockDim.x) {
     const u32x4 xv = reinterpret_cast<const u32x4*>(x)[i];
@@ -323,9 +324,14 @@ __global__ __launch_bounds__(256) void gelu_bwd_kernel(const bf16_t* __restrict_
       for (int h = 0; h < 2; ++h) {
         const float xx = h ? bf16hi_to_f32(xv[j]) : bf16lo_to_f32(xv[j]);
         const float gg = h ? bf16hi_to_f32(gv[j]) : bf16lo_to_f32(gv[j]);
-        const float cdf = 0.5f * (1.0f + erff(xx * 0.70710678118654752440f));
-        const float pdf = 0.39894228040143267794f * __expf(-0.5f * xx * xx);
-        r[h] = gg * (cdf + xx * pdf);
+        if (tanh_form) {
+          const float th = tanhf(0.79788456080286535588f * (xx + 0.044715f * xx * xx * xx));
+          r[h] = gg * (0.5f * (1.0f + th) + 0.5f * xx * (1.0f - th * th) * 0.79788456080286535588f * (1.0f + 0.134145f * xx * xx));
+        } else {
+          const float cdf = 0.5f * (1.0f + erff(xx * 0.70710678118654752440f));
+          const float pdf = 0.39894228040143267794f * __expf(-0.5f * xx * xx);
+          r[h] = gg * (cdf + xx * pdf);
+        }
       }
       o[j] = pack_bf16x2(r[0], r[1]);
     }
@@ -762,13 +768,21 @@ extern "C" int vita_swiglu_bwd(const void* y, const void* da, void* dy, int64_t 
   return vita_check_launch();
 }
 
-extern "C" int vita_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, void* stream) {
+static int gelu_bwd_launch(const void* x, const void* dy, void* dx, int64_t n, int tanh_form, void* stream) {
   if (!x || !dy || !dx || n < 0) return VITA_ERR_INVALID_ARG;
   if (n & 7) return VITA_ERR_UNSUPPORTED;
   if (n == 0) return VITA_OK;
   hipLaunchKernelGGL(gelu_bwd_kernel, dim3(grid_for(n / 8, 256)), dim3(256), 0, (hipStream_t)stream,
-                     (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n / 8);
+                     (const bf16_t*)x, (const bf16_t*)dy, (bf16_t*)dx, n / 8, tanh_form);
   return vita_check_launch();
+}
+
+extern "C" int vita_gelu_bwd(const void* x, const void* dy, void* dx, int64_t n, void* stream) {
+  return gelu_bwd_launch(x, dy, dx, n, 0, stream);
+}
+
+extern "C" int vita_gelu_tanh_bwd(const void* x, const void* dy, void* dx, int64_t n, void* stream) {
+  return gelu_bwd_launch(x, dy, dx, n, 1, stream);
 }
 
 extern "C" int vita_layernorm_bwd(const void* dy, const void* x, const void* w, void* dx, float* dgamma, float* dbeta,

@@ -51,8 +51,9 @@ class HipDotProductAttention(torch.nn.Module):
         from .autograd_fns import FlashAttnCPFn, FlashAttnFn, FlashAttnNonCausalFn
         sq, b, np_, hn = query.shape
         if not self._impl.causal:                      # the ViT layers (AttnMaskType.no_mask): batch = frames
-            out = FlashAttnNonCausalFn.apply(query.transpose(0, 1), key.transpose(0, 1), value.transpose(0, 1),
-                                             self._impl.softmax_scale if self._impl.softmax_scale is not None else 1.0 / hn ** 0.5)
+            scale = self._impl.softmax_scale if self._impl.softmax_scale is not None else 1.0 / hn ** 0.5
+            q, k, v = (_pad_head_dim(t.transpose(0, 1)) for t in (query, key, value))      # SigLIP: 72 -> 128 zero columns
+            out = FlashAttnNonCausalFn.apply(q, k, v, scale)[..., :hn]
             return out.transpose(0, 1).reshape(sq, b, np_ * hn)
         if b != 1:
             # vita_flash_attn_bwd is a batch-1 kernel (every Long-VITA script trains --micro-batch-size 1)
@@ -70,6 +71,18 @@ class HipDotProductAttention(torch.nn.Module):
             out = FlashAttnFn.apply(q, k, v, self._impl.softmax_scale, self._impl.causal,
                                     None if seg is None else seg[0], None if seg is None else seg[1])
         return out.transpose(0, 1).reshape(sq, b, np_ * hn)
+
+
+def _pad_head_dim(t: torch.Tensor) -> torch.Tensor:
+    """[..., hn] -> [..., 64 | 128] with zero columns when hn is neither (SigLIP-400M: kv_channels = 72, M/pretrain_long_vita.py:276):
+    zero columns of Q / K add nothing to a score, zero columns of V give zero output columns, which the caller drops; the softmax
+    scale stays 1 / sqrt(hn).  A no-op for the sizes the kernels tile."""
+    hn = t.shape[-1]
+    if hn in (64, 128):
+        return t
+    if hn > 128:
+        raise NotImplementedError(f"head size {hn}: the attention kernels are built for 64 and 128 (smaller sizes are zero-padded)")
+    return torch.nn.functional.pad(t, (0, (64 if hn < 64 else 128) - hn))
 
 
 class DotProductAttention:
@@ -105,8 +118,12 @@ class DotProductAttention:
             seg = training_utils.get_packed_segments() if self.causal else None
             if seg is not None and (b != 1 or cp > 1):
                 raise NotImplementedError("packed samples run micro-batch 1, CP = 1 (reference stage 2)")
-            out = ops.flash_attn(q, k, v, causal=self.causal, softmax_scale=self.softmax_scale,
-                                 seg_start=None if seg is None else seg[0])
+            if not self.causal and hn not in (64, 128):
+                scale = self.softmax_scale if self.softmax_scale is not None else 1.0 / hn ** 0.5
+                out = ops.flash_attn(_pad_head_dim(q), _pad_head_dim(k), _pad_head_dim(v), causal=False, softmax_scale=scale)[..., :hn]
+            else:
+                out = ops.flash_attn(q, k, v, causal=self.causal, softmax_scale=self.softmax_scale,
+                                     seg_start=None if seg is None else seg[0])
         return out.transpose(0, 1).reshape(sq, b, np_ * hn)                           # [sq, b, hp] :285-289
 
     __call__ = forward

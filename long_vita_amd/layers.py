@@ -300,15 +300,21 @@ class ViTMLP(torch.nn.Module):
     M/pretrain_long_vita.py:207) as two torch ops; here, without autograd, bias + GELU are the epilogue of the fc1 GEMM
     (VITA_EPI_BIAS_GELU: one kernel), and with autograd the GEMM (+ bias) is followed by vita_gelu_fwd, whose input the backward keeps."""
 
-    def __init__(self, config, submodules, is_expert: bool = False, input_size: int = None):
+    def __init__(self, config, submodules, is_expert: bool = False, input_size: int = None, unfused_bias: bool = False):
         super().__init__()
+        import functools
         from megatron.core.transformer.spec_utils import build_module
         if is_expert or getattr(config, "gated_linear_unit", False):
             raise NotImplementedError("ViTMLP is the dense, non-gated MLP of the vision encoders")
         act = getattr(config, "activation_func", torch.nn.functional.gelu)
-        if act is not torch.nn.functional.gelu:
-            raise NotImplementedError("ViTMLP under Megatron is built for erf GELU (InternViT); SigLIP's tanh GELU runs in the "
-                                      "stand-alone vision.MegatronVisionModel")
+        # InternViT: torch.nn.functional.gelu (M/pretrain_long_vita.py:207); SigLIP: partial(F.gelu, approximate="tanh") (:290)
+        self.tanh = (isinstance(act, functools.partial) and act.func is torch.nn.functional.gelu and not act.args
+                     and act.keywords == {"approximate": "tanh"})
+        if act is not torch.nn.functional.gelu and not self.tanh:
+            raise NotImplementedError("ViTMLP: activation_func must be F.gelu or partial(F.gelu, approximate='tanh')")
+        # unfused_bias (SigLIP's local spec, vit_layer_specs.py:30-53): Megatron's MLP adds the fc1 bias to the bf16-ROUNDED product as an op
+        # of its own before the activation (skip_bias_add linears, no bias_activation_fusion); the InternViT specs fold it into the GEMM
+        self.unfused_bias = bool(unfused_bias)
         self.config = config
         self.input_size = input_size if input_size is not None else config.hidden_size
         self.linear_fc1 = build_module(submodules.linear_fc1, self.input_size, config.ffn_hidden_size, config=config,
@@ -323,12 +329,16 @@ class ViTMLP(torch.nn.Module):
         fc1 = self.linear_fc1
         grad = torch.is_grad_enabled() and (hidden_states.requires_grad or fc1.weight.requires_grad)
         plain = type(fc1) is ColumnParallelLinear and not fc1.sequence_parallel and mpu.get_tensor_model_parallel_world_size() == 1
-        if not grad and plain and fc1.bias is not None:
+        fused_epi = {(False, False): ops.EPI_BIAS_GELU, (True, True): ops.EPI_BIAS2_GELU_TANH}.get((self.unfused_bias, self.tanh))
+        if not grad and plain and fc1.bias is not None and fused_epi is not None:
             s, b, h = hidden_states.shape                                     # inference: GEMM + bias + GELU in one kernel
-            a = ops.gemm(hidden_states.reshape(s * b, h), fc1.weight, ops.EPI_BIAS_GELU, fc1.bias).view(s, b, -1)
+            a = ops.gemm(hidden_states.reshape(s * b, h), fc1.weight, fused_epi, fc1.bias).view(s, b, -1)
+        elif self.unfused_bias:
+            y, bias = fc1(hidden_states)                                      # skip_bias_add: the bf16 product and the bias, added as an op of its own
+            a = F_.GeluFn.apply(y if bias is None else BiasAddFn.apply(y, bias), self.tanh)
         else:
             y, _ = fc1.forward_fused_bias(hidden_states)                      # GEMM + bias (one rounding), pre-activation kept for the backward
-            a = F_.GeluFn.apply(y)
+            a = F_.GeluFn.apply(y, self.tanh)
         return self.linear_fc2(a)                                              # (output, bias): the bias goes into the residual kernel
 
 

@@ -21,7 +21,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libvita_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "vita_hip.h")
 
-ABI_VERSION = 13
+ABI_VERSION = 14
 VITA_OK = 0
 VITA_ERR_INVALID_ARG = -1
 VITA_ERR_UNSUPPORTED = -2
@@ -155,6 +155,7 @@ PROTOTYPES = {
     "vita_swiglu_fwd": (_i, [_p, _p, _l, _i, _p]),
     "vita_swiglu_bwd": (_i, [_p, _p, _p, _l, _i, _p]),
     "vita_gelu_bwd": (_i, [_p, _p, _p, _l, _p]),
+    "vita_gelu_tanh_bwd": (_i, [_p, _p, _p, _l, _p]),
     "vita_layernorm_param_grad": (_i, [_p, _p, _p, _p, _l, _i, _f, _i, _p]),
     "vita_layernorm_bwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _f, _p]),
     "vita_gelu_fwd": (_i, [_p, _p, _l, _i, _p]),

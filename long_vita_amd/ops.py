@@ -250,6 +250,13 @@ def gemm(a: torch.Tensor, w: torch.Tensor, epilogue: int = EPI_NONE, bias: Optio
         raise ValueError("out has wrong shape")
     if M == 0:                                  # an empty selection (a logit mask with no True on this rank): nothing to launch
         return y
+    if K % 64:
+        # the kernels step the contraction in 64s; a contraction that is not a multiple (SigLIP's FFN 4304 = 67 x 64 + 16,
+        # M/pretrain_long_vita.py:268-307) runs on zero-padded copies of both operands: exact, the padding adds zeros to every sum
+        kp = (K + 63) // 64 * 64
+        a = torch.nn.functional.pad(a, (0, kp - K))
+        w = torch.nn.functional.pad(w, (0, kp - K))
+        K = kp
     r_ptr, ldr = None, 0
     if residual is not None:
         if residual.shape != (M, N) or residual.stride(1) != 1:
@@ -463,10 +470,11 @@ def swiglu_bwd(y: torch.Tensor, da: torch.Tensor, out=None) -> torch.Tensor:
     return dy
 
 
-def gelu_bwd(x: torch.Tensor, dy: torch.Tensor) -> torch.Tensor:
+def gelu_bwd(x: torch.Tensor, dy: torch.Tensor, tanh: bool = False) -> torch.Tensor:
     dx = torch.empty_like(x)
-    _L.check(_L.load().vita_gelu_bwd(_dev(x, "x", BF16), _dev(dy, "dy", BF16), _dev(dx, "dx", BF16), x.numel(),
-                                     _stream()), "vita_gelu_bwd")
+    fn = _L.load().vita_gelu_tanh_bwd if tanh else _L.load().vita_gelu_bwd
+    _L.check(fn(_dev(x, "x", BF16), _dev(dy, "dy", BF16), _dev(dx, "dx", BF16), x.numel(), _stream()),
+             "vita_gelu_tanh_bwd" if tanh else "vita_gelu_bwd")
     return dx
 
 

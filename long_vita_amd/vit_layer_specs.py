@@ -73,13 +73,13 @@ def _layer_classes():
     return _CLASSES[base]
 
 
-def _vit_spec(layer_cls, fused_norm: bool):
+def _vit_spec(layer_cls, fused_norm: bool, unfused_bias: bool = False):
     m = _megatron()
     attn = m["ModuleSpec"](module=m["SelfAttention"], params={"attn_mask_type": m["AttnMaskType"].no_mask},
                            submodules=m["SelfAttentionSubmodules"](
                                linear_qkv=LayerNormColumnParallelLinear if fused_norm else ColumnParallelLinear,
                                core_attention=HipDotProductAttention, linear_proj=RowParallelLinear))
-    mlp = m["ModuleSpec"](module=ViTMLP, submodules=m["MLPSubmodules"](
+    mlp = m["ModuleSpec"](module=ViTMLP, params={"unfused_bias": unfused_bias}, submodules=m["MLPSubmodules"](
         linear_fc1=LayerNormColumnParallelLinear if fused_norm else ColumnParallelLinear, linear_fc2=RowParallelLinear))
     norm = m["IdentityOp"] if fused_norm else Norm
     return m["ModuleSpec"](module=layer_cls, submodules=m["TransformerLayerSubmodules"](
@@ -97,6 +97,9 @@ def get_vit_layer_with_transformer_engine_spec_for_intern(use_te=True):
 
 
 def get_vit_layer_local_spec_for_siglip(use_te=True):
-    """vit_layer_specs.py:30-53 — SigLIP-400M: no LayerScale; head size 72 / FFN 4304 run through the padded weights of
-    vision.MegatronVisionModel in the stand-alone driver; the Megatron-built layer needs MFMA-tileable sizes (kv_channels 64 or 128)."""
-    return _vit_spec(_layer_classes()[1], fused_norm=False)
+    """vit_layer_specs.py:30-53 — SigLIP-400M (M/pretrain_long_vita.py:268-307: hidden 1152, 16 heads x 72, FFN 4304, tanh GELU, no
+    LayerScale, no class token).  The sizes the MFMA kernels do not tile are padded where they are used: head size 72 -> 128 with zero
+    columns inside HipDotProductAttention (scores and outputs unchanged), the 4304-deep contractions of fc2 and of fc1's dgrad -> 4352
+    with zero columns inside ops.gemm; parameters keep Megatron's shapes.  Biases of proj / fc1 / fc2 meet the bf16-rounded product in
+    an op of their own (skip_bias_add, no fusion: `unfused_bias`), as the reference's modules do."""
+    return _vit_spec(_layer_classes()[1], fused_norm=False, unfused_bias=True)

@@ -399,3 +399,62 @@ def test_vit_layer_built_by_megatron_matches_the_oracle_forward_and_backward(meg
     with torch.no_grad():                                                             # inference: fc1 + bias + GELU in one GEMM epilogue
         out2, _ = layer(x.transpose(0, 1).contiguous().to(DEV), attention_mask=None)
     tol("no-grad path vs autograd path", rel_l2(out2, out), 1e-5)              # measured 0: the same rounding chain
+
+
+def test_siglip_layer_built_by_megatron_at_its_real_sizes(megatron):
+    """BASELINE config 2 names SigLIP next to InternViT: `get_vit_layer_local_spec_for_siglip` (M/core/models/vision/vit_layer_specs.py:30-53,
+    taken by MegatronVisionModel for `--vision-model-type siglip_400m`, M/pretrain_long_vita.py:268-307,366-370) at SigLIP-400M's own
+    sizes — hidden 1152, 16 heads x 72, FFN 4304, tanh GELU, no LayerScale, 1024 tokens — none of which the MFMA kernels tile: the head
+    size is zero-padded to 128 inside HipDotProductAttention, the 4304-deep contractions (fc2 forward, fc1 dgrad) to 4352 inside
+    ops.gemm; the biases of proj / fc1 / fc2 meet the bf16-rounded product in ops of their own (skip_bias_add).  Output, input gradient
+    and all 12 parameter gradients vs torch autograd over oracle.vit.vit_layer(siglip_400m) (pinned on transformers' SiglipVisionModel
+    by siglip_vit.pt); the no-grad call takes the fused BIAS2_GELU_TANH epilogue."""
+    import functools
+    from oracle import vit as ovit
+    vls = sys.modules["long_vita_megatron.core.models.vision.vit_layer_specs"]
+    vcfg = ovit.ViTConfig.siglip_400m(num_layers=1)
+    vp = ovit.init_vit_params(vcfg, seed=71)
+    gen = torch.Generator().manual_seed(72)
+    lp = {k: v.clone() for k, v in vp["layers"][0].items() if k not in ("ls1", "ls2")}
+    for k in ("ln1_w", "ln2_w"):
+        lp[k] = (1 + 0.1 * torch.randn(lp[k].shape, generator=gen)).bfloat16()
+    for k in ("ln1_b", "ln2_b", "qkv_b", "proj_b", "fc1_b", "fc2_b"):
+        lp[k] = (0.1 * torch.randn(lp[k].shape, generator=gen)).bfloat16()
+    n, S, H = 2, vcfg.seq, vcfg.hidden
+    assert (S, H, vcfg.head_dim, vcfg.ffn) == (1024, 1152, 72, 4304)
+    x = (torch.randn(n, S, H, generator=gen) * 0.5).bfloat16()
+    go = torch.randn(n, S, H, generator=gen).bfloat16()
+    xo = x.clone().requires_grad_(True)
+    lpo = {k: v.clone().requires_grad_(True) for k, v in lp.items()}
+    ref = ovit.vit_layer(xo, lpo, vcfg)
+    ref.backward(go)
+
+    mcfg = dm.TransformerConfig(hidden_size=H, num_attention_heads=vcfg.heads, num_query_groups=vcfg.heads, kv_channels=vcfg.head_dim,
+                                ffn_hidden_size=vcfg.ffn, normalization="LayerNorm", layernorm_epsilon=vcfg.ln_eps, add_bias_linear=True,
+                                add_qkv_bias=True, gated_linear_unit=False,
+                                activation_func=functools.partial(torch.nn.functional.gelu, approximate="tanh"))
+    layer = dm.build_module(vls.get_vit_layer_local_spec_for_siglip(), config=mcfg, layer_number=1)
+    assert type(layer).__name__ == "SigLIPViTTransformerLayer" and all(q.is_cuda for q in layer.parameters())
+    names = {"ln1_w": "input_layernorm.weight", "ln1_b": "input_layernorm.bias", "qkv_w": "self_attention.linear_qkv.weight",
+             "qkv_b": "self_attention.linear_qkv.bias", "proj_w": "self_attention.linear_proj.weight",
+             "proj_b": "self_attention.linear_proj.bias", "ln2_w": "pre_mlp_layernorm.weight", "ln2_b": "pre_mlp_layernorm.bias",
+             "fc1_w": "mlp.linear_fc1.weight", "fc1_b": "mlp.linear_fc1.bias", "fc2_w": "mlp.linear_fc2.weight", "fc2_b": "mlp.linear_fc2.bias"}
+    assert set(names.values()) == {k for k, _ in layer.named_parameters()}           # no ls1 / ls2: siglip_vit_model.py has no LayerScale
+    assert tuple(dict(layer.named_parameters())["mlp.linear_fc2.weight"].shape) == (1152, 4304)     # Megatron's shapes, not padded ones
+    layer.load_state_dict({v: lp[k].to(DEV) for k, v in names.items()})
+    xh = x.transpose(0, 1).contiguous().to(DEV).requires_grad_(True)
+    out, _ = layer(xh, attention_mask=None)
+    assert out.shape == (S, n, H) and out.dtype == torch.bfloat16
+    e_fwd = rel_l2(out.transpose(0, 1), ref)
+    out.backward(go.transpose(0, 1).contiguous().to(DEV))
+    params = dict(layer.named_parameters())
+    errs = {"out": e_fwd, "dx": rel_l2(xh.grad.transpose(0, 1), xo.grad)}
+    for k, nme in names.items():
+        assert params[nme].grad is not None, nme
+        errs[k] = rel_l2(params[nme].grad, lpo[k].grad)
+    _record("siglip_layer_local", errs)
+    tol("forward", e_fwd, 4.4e-3)                                                    # measured 2.9e-3 (no LayerScale: the branch outputs enter the stream at full size)
+    tol("worst gradient", max(v for k, v in errs.items() if k != "out"), 7.4e-3)     # measured 4.9e-3 (ln1_w)
+    with torch.no_grad():
+        out2, _ = layer(x.transpose(0, 1).contiguous().to(DEV), attention_mask=None)
+    tol("no-grad path vs autograd path", rel_l2(out2, out), 1e-5)                    # measured 0: the same rounding chain
