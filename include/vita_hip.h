@@ -256,6 +256,10 @@ int vita_flash_attn_fwd(const vita_attn_params* p, void* stream);
  *   memory (one split's output + two lse vectors) and cp_size > 1, split 0 attends to the rank's OWN two chunks straight from
  *   kv_packed while gather 0 is in flight, then to the 2 CP - 2 remote chunks, and vita_attn_merge joins the two partials;
  *   scratch = NULL keeps one launch per split behind its gather.
+ *   Choosing n_split: every split is one attention launch over n_q_heads / n_split heads x s_local / 256 row tiles, one workgroup
+ *   per CU, and short launches waste their last round: at s_local = 16384, 40 : 8 heads (2560 workgroups per layer) 1 / 2 / 4 splits
+ *   take 18.0-18.3 / 18.8-19.0 / 18.9-19.9 ms per layer (profiles/r03_cp8_rank_attn.jsonl); the host mirror keeps >= 2560
+ *   workgroups per launch (long_vita_amd.ops.cp_kv_split).
  * vita_cp_attn_bwd: d_out like out; lse from the forward; delta from vita_attn_delta; dq like q; dkv_packed like kv_packed
  *   receives this rank's dK / dV; p->dkv_workspace (same size as workspace) takes the gathered-layout dK / dV. */
 typedef struct vita_cp_context vita_cp_context;

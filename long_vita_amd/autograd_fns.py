@@ -433,7 +433,7 @@ class FlashAttnCPFn(torch.autograd.Function):
         hkv = k.shape[2]
         if s_l % 2:
             raise ValueError("local sequence must hold two zig-zag chunks")
-        n_split = 4 if hkv % 4 == 0 else (2 if hkv % 2 == 0 else 1)      # gather j + 1 runs under the attention of split j
+        n_split = ops.cp_kv_split(hkv, hq, s_l)                            # gather j + 1 runs under the attention of split j
         hg = hkv // n_split
         kv_local = torch.empty(n_split, 2, s_l, hg, d, dtype=q.dtype, device=q.device)
         kv_local[:, 0].copy_(k[0].reshape(s_l, n_split, hg, d).permute(1, 0, 2, 3))

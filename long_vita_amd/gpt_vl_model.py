@@ -58,8 +58,9 @@ class GPTVLModel:
         self.core_attention = DotProductAttention(cfg.heads, cfg.kv_groups, cfg.head_dim, causal=True)
         self.output_layer = ColumnParallelLinear.from_weight(params["lm_head"], bias=None)
         self._ws = {}
-        # K/V all-gather messages per layer (split by kv head; gather j+1 overlaps attention j)
-        self.kv_split = 4 if cfg.kv_groups % 4 == 0 else (2 if cfg.kv_groups % 2 == 0 else 1)
+        # K/V all-gather messages per layer (split by kv head; gather j+1 overlaps attention j): None = ops.cp_kv_split's rule for the
+        # local sequence length (as fine as every attention launch still fills the chip for >= 5 rounds); an int fixes it
+        self.kv_split = None
         self.force_cp_path = bool(int(os.environ.get("VITA_FORCE_CP", "0")))   # diagnostics only
         self.decode_fused = bool(int(os.environ.get("VITA_DECODE_FUSED", "1")))   # one C call per half layer (decode)
         self.decode_graph = bool(int(os.environ.get("VITA_DECODE_GRAPH", "0")))   # capture the token step (CP = 1)
@@ -100,8 +101,9 @@ class GPTVLModel:
         if ws is None:
             c = self.cfg
             e = lambda *shape: torch.empty(*shape, dtype=torch.bfloat16, device=device)  # noqa: E731
+            n_msg = self.kv_split if self.kv_split is not None else ops.cp_kv_split(c.kv_groups, c.heads, s)
             ws = {"x": e(s, c.hidden), "qkv": e(s, c.qkv_out), "ctx": e(1, s, c.heads, c.head_dim),
-                  "act": e(s, c.ffn), "kv": e(self.kv_split, 2, s, c.kv_groups // self.kv_split, c.head_dim)}
+                  "act": e(s, c.ffn), "kv": e(n_msg, 2, s, c.kv_groups // n_msg, c.head_dim)}
             self._ws = {k: v for k, v in self._ws.items() if k == "decode"}    # keep one prefill size only
             self._ws[s] = ws
         return ws
@@ -115,12 +117,12 @@ class GPTVLModel:
         use_cp = cp > 1 or self.force_cp_path          # force: exercise pack + all-gather + chunk tables at CP = 1
         x = ops.rmsnorm(h, lp["ln1"], c.eps, out=ws["x"])
         qkv = ops.gemm(x, lp["qkv_w"], ops.EPI_BIAS, lp["qkv_b"], out=ws["qkv"])
-        ops.rope_qkv_(qkv, c.kv_groups, c.qpg, c.head_dim, cos, sin, ws["kv"] if use_cp else None, self.kv_split)
+        ops.rope_qkv_(qkv, c.kv_groups, c.qpg, c.head_dim, cos, sin, ws["kv"] if use_cp else None, ws["kv"].shape[0])
         m5 = qkv.view(1, s, c.kv_groups, c.qpg + 2, c.head_dim)
         q5 = m5[:, :, :, : c.qpg]                                  # grouped query view, read in place
         if kv_dst is not None:
             if use_cp:       # packed send buffer [split, 2, s, groups/split, d] -> [2, s, groups, d]
-                kv_dst[:, :s].view(2, s, self.kv_split, -1, c.head_dim).copy_(ws["kv"].permute(1, 2, 0, 3, 4))
+                kv_dst[:, :s].view(2, s, ws["kv"].shape[0], -1, c.head_dim).copy_(ws["kv"].permute(1, 2, 0, 3, 4))
             else:
                 kv_dst[0, :s].copy_(m5[0, :, :, c.qpg])
                 kv_dst[1, :s].copy_(m5[0, :, :, c.qpg + 1])

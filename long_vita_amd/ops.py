@@ -8,6 +8,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Optional, Sequence
 
 import torch
@@ -110,6 +111,29 @@ def rope_apply_(t: torch.Tensor, cos: torch.Tensor, sin: torch.Tensor, sign: int
                                        _dev(cos, "cos", BF16), _dev(sin, "sin", BF16), sign, _stream()),
              "vita_rope_apply")
     return t
+
+
+def cp_kv_split(kv_groups: int, n_heads: int, s_local: int) -> int:
+    """K / V all-gather messages (= attention launches) per layer under context parallelism.  Gather j + 1 runs under the attention of
+    split j, gather 0 under the attention over the rank's own chunks — so more splits hide more of the exchange, but every split is
+    a launch over n_heads / split heads x s_local / 256 row tiles, one 512-register workgroup per CU, and short launches waste their
+    last round.  Measured on one rank of the 128K prefill at CP = 8 (S_l = 16384, 2560 workgroups per layer; own chunks first, one
+    stream per split; tools/bench_cp8_rank_attn.py, profiles/r03_cp8_rank_attn.jsonl): 1 message 18.0-18.3 ms per layer, 2 messages
+    18.8-19.0, 4 messages 18.9-19.9 (without the streams 20.3-26.5) — against 0.3-1 ms of exchange per layer that the own-chunk
+    attention (2.2 ms) covers at any split.  Rule: split as finely as every launch keeps >= 10 full rounds (2560 workgroups);
+    problems too small for one such launch keep the finest split (nothing fills the chip there, the launches overlap on their
+    streams).  VITA_CP_KV_SPLIT=1|2|4 overrides (a deployment knob: the right value depends on the node's all-gather bandwidth)."""
+    finest = 4 if kv_groups % 4 == 0 else (2 if kv_groups % 2 == 0 else 1)
+    env = os.environ.get("VITA_CP_KV_SPLIT")
+    if env:
+        n = int(env)
+        if n < 1 or kv_groups % n:
+            raise ValueError(f"VITA_CP_KV_SPLIT={env}: must divide the {kv_groups} kv heads")
+        return n
+    n, wgs = finest, n_heads * max(s_local // 256, 1)
+    while n > 1 and wgs >= 2560 and wgs // n < 2560:
+        n //= 2
+    return n
 
 
 def rope_qkv_(mixed_qkv: torch.Tensor, groups: int, q_per_group: int, head_dim: int, cos: torch.Tensor,
