@@ -122,13 +122,16 @@ def cp_kv_split(kv_groups: int, n_heads: int, s_local: int) -> int:
     18.8-19.0, 4 messages 18.9-19.9 (without the streams 20.3-26.5) — against 0.3-1 ms of exchange per layer that the own-chunk
     attention (2.2 ms) covers at any split.  Rule: split as finely as every launch keeps >= 10 full rounds (2560 workgroups);
     problems too small for one such launch keep the finest split (nothing fills the chip there, the launches overlap on their
-    streams).  VITA_CP_KV_SPLIT=1|2|4 overrides (a deployment knob: the right value depends on the node's all-gather bandwidth)."""
+    streams).  VITA_CP_KV_SPLIT=n overrides with AT MOST n messages (a deployment knob: the right value depends on the node's
+    all-gather bandwidth)."""
     finest = 4 if kv_groups % 4 == 0 else (2 if kv_groups % 2 == 0 else 1)
     env = os.environ.get("VITA_CP_KV_SPLIT")
     if env:
         n = int(env)
-        if n < 1 or kv_groups % n:
-            raise ValueError(f"VITA_CP_KV_SPLIT={env}: must divide the {kv_groups} kv heads")
+        if n < 1:
+            raise ValueError(f"VITA_CP_KV_SPLIT={env}: a positive number of messages")
+        while kv_groups % n:                 # at most that many: a tensor-parallel rank holds fewer kv heads
+            n -= 1
         return n
     n, wgs = finest, n_heads * max(s_local // 256, 1)
     while n > 1 and wgs >= 2560 and wgs // n < 2560:

@@ -995,7 +995,7 @@ def test_adaptor_stacks_on_top_of_the_references_adaptor():
 def test_cp_kv_split_keeps_every_attention_launch_at_ten_rounds_of_workgroups(monkeypatch):
     """ops.cp_kv_split: messages (= attention launches) per layer under CP.  40 : 8 heads — 128K at CP = 8 (S_l = 16384: 2560 workgroups
     per layer) takes ONE message, CP = 4 two, CP = 2 and the 1M prefill four; config 5's tensor-parallel half (20 : 4 heads, S_l = 32768)
-    one; sizes too small for a single full launch keep the finest split; the override is validated against the kv heads."""
+    one; sizes too small for a single full launch keep the finest split; the override means "at most"."""
     from long_vita_amd import ops
     monkeypatch.delenv("VITA_CP_KV_SPLIT", raising=False)
     assert [ops.cp_kv_split(8, 40, s) for s in (16384, 32768, 65536, 131072)] == [1, 2, 4, 4]
@@ -1003,6 +1003,9 @@ def test_cp_kv_split_keeps_every_attention_launch_at_ten_rounds_of_workgroups(mo
     assert ops.cp_kv_split(8, 40, 2048) == 4 and ops.cp_kv_split(2, 4, 512) == 2 and ops.cp_kv_split(1, 5, 1024) == 1
     monkeypatch.setenv("VITA_CP_KV_SPLIT", "2")
     assert ops.cp_kv_split(8, 40, 16384) == 2
+    assert ops.cp_kv_split(1, 5, 16384) == 1                       # at most: a tensor-parallel rank with one kv head
     monkeypatch.setenv("VITA_CP_KV_SPLIT", "3")
+    assert ops.cp_kv_split(8, 40, 16384) == 2
+    monkeypatch.setenv("VITA_CP_KV_SPLIT", "0")
     with pytest.raises(ValueError):
         ops.cp_kv_split(8, 40, 16384)
