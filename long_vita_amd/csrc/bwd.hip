@@ -426,15 +426,32 @@ __global__ __launch_bounds__(256) void layernorm_bwd_kernel(const bf16_t* __rest
       }
     }
   }
+  // flush (r03, as rmsnorm_bwd_kernel): the workgroup's four waves are summed in LDS and the atomics go out with consecutive lanes on
+  // consecutive columns — one instruction touches two cache lines instead of sixteen, and every workgroup adds into the same lines
+  extern __shared__ float pg_lds[];                  // [2][8][nvec]: element e of vector vi of dgamma | dbeta at e * nvec + vi
+  const int wv = threadIdx.x >> 6;
+  for (int w4 = 0; w4 < 4; ++w4) {
+    if (wv == w4) {
 #pragma unroll
-  for (int i = 0; i < VPL; ++i) {
-    const int vi = lane + i * 64;
-    if (vi < nvec)
+      for (int i = 0; i < VPL; ++i) {
+        const int vi = lane + i * 64;
+        if (vi < nvec) {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        atomicAdd(dgamma + vi * 8 + j, dgl[i][j]);
-        atomicAdd(dbeta + vi * 8 + j, dbl[i][j]);
+          for (int j = 0; j < 8; ++j) {
+            float* pgm = pg_lds + j * nvec + vi;
+            float* pbt = pg_lds + cols + j * nvec + vi;
+            *pgm = (w4 ? *pgm : 0.f) + dgl[i][j];
+            *pbt = (w4 ? *pbt : 0.f) + dbl[i][j];
+          }
+        }
       }
+    }
+    __syncthreads();
+  }
+  for (int i = threadIdx.x; i < cols; i += 256) {
+    const int at = (i & 7) * nvec + (i >> 3);
+    atomicAdd(dgamma + i, pg_lds[at]);
+    atomicAdd(dbeta + i, pg_lds[cols + at]);
   }
 }
 
@@ -792,7 +809,7 @@ extern "C" int vita_layernorm_bwd(const void* dy, const void* x, const void* w, 
   if (rows == 0) return VITA_OK;
   dim3 grid((unsigned)((rows + 3) / 4 < 512 ? (rows + 3) / 4 : 512)), block(256);
   hipStream_t st = (hipStream_t)stream;
-#define VITA_LB(V) hipLaunchKernelGGL(layernorm_bwd_kernel<V>, grid, block, 0, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)dx, dgamma, dbeta, rows, cols, eps)
+#define VITA_LB(V) hipLaunchKernelGGL(layernorm_bwd_kernel<V>, grid, block, (size_t)cols * 8, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)dx, dgamma, dbeta, rows, cols, eps)
   const int vpl = (cols + 511) / 512;
   if (vpl <= 2) VITA_LB(2); else if (vpl <= 4) VITA_LB(4); else if (vpl <= 8) VITA_LB(8); else VITA_LB(16);
 #undef VITA_LB
