@@ -811,6 +811,10 @@ extern "C" int vita_layernorm_bwd(const void* dy, const void* x, const void* w, 
   hipStream_t st = (hipStream_t)stream;
 #define VITA_LB(V) hipLaunchKernelGGL(layernorm_bwd_kernel<V>, grid, block, (size_t)cols * 8, st, (const bf16_t*)dy, (const bf16_t*)x, (const bf16_t*)w, (bf16_t*)dx, dgamma, dbeta, rows, cols, eps)
   const int vpl = (cols + 511) / 512;
+  static std::atomic<unsigned long long> attr_set{0};           // cols = 8192 needs 64 KiB of dynamic LDS for the flush image
+  vita_device_once(attr_set, [&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&layernorm_bwd_kernel<16>), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  });
   if (vpl <= 2) VITA_LB(2); else if (vpl <= 4) VITA_LB(4); else if (vpl <= 8) VITA_LB(8); else VITA_LB(16);
 #undef VITA_LB
   return vita_check_launch();
