@@ -506,6 +506,7 @@ __global__ __launch_bounds__(256) void bias_scale_res_bwd_kernel(const bf16_t* _
                                                                  const bf16_t* __restrict__ bias, const bf16_t* __restrict__ scale,
                                                                  bf16_t* __restrict__ dx, float* __restrict__ d_bias,
                                                                  float* __restrict__ d_scale, int64_t rows, int cols, int rows_per_block) {
+  extern __shared__ float bs_lds[];                  // the flush image [2][8][nvec]: element e of vector vi of d_bias | d_scale at e * nvec + vi
   const int nvec = cols >> 3;
   const int64_t r0 = (int64_t)blockIdx.x * rows_per_block;
   const int64_t r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
@@ -532,11 +533,15 @@ __global__ __launch_bounds__(256) void bias_scale_res_bwd_kernel(const bf16_t* _
       }
       if (dx) reinterpret_cast<u32x4*>(dx + r * (int64_t)cols)[vi] = o;
     }
+    // flush through LDS: consecutive lanes on consecutive columns (see rmsnorm_bwd_kernel)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      if (d_bias) atomicAdd(d_bias + vi * 8 + j, ab[j]);
-      if (d_scale) atomicAdd(d_scale + vi * 8 + j, as[j]);
-    }
+    for (int j = 0; j < 8; ++j) { bs_lds[j * nvec + vi] = ab[j]; bs_lds[cols + j * nvec + vi] = as[j]; }
+  }
+  __syncthreads();
+  for (int i = threadIdx.x; i < cols; i += blockDim.x) {
+    const int at = (i & 7) * nvec + (i >> 3);
+    if (d_bias) atomicAdd(d_bias + i, bs_lds[at]);
+    if (d_scale) atomicAdd(d_scale + i, bs_lds[cols + at]);
   }
 }
 
@@ -844,9 +849,14 @@ extern "C" int vita_bias_scale_res_bwd(const void* g, const void* x, const void*
   if (!g || !x || rows < 0 || cols <= 0) return VITA_ERR_INVALID_ARG;
   if (cols & 7) return VITA_ERR_UNSUPPORTED;
   if (rows == 0) return VITA_OK;
+  if (cols > 8192) return VITA_ERR_UNSUPPORTED;       // the flush image: 2 x cols floats of LDS
+  static std::atomic<unsigned long long> attr_set{0};
+  vita_device_once(attr_set, [&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&bias_scale_res_bwd_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  });
   const int rpb = 64;
   hipLaunchKernelGGL(bias_scale_res_bwd_kernel, dim3((unsigned)((rows + rpb - 1) / rpb)), dim3(cols / 8 < 256 ? (cols / 8 + 63) / 64 * 64 : 256),
-                     0, (hipStream_t)stream, (const bf16_t*)g, (const bf16_t*)x, (const bf16_t*)bias, (const bf16_t*)scale,
+                     (size_t)cols * 8, (hipStream_t)stream, (const bf16_t*)g, (const bf16_t*)x, (const bf16_t*)bias, (const bf16_t*)scale,
                      (bf16_t*)dx, d_bias, d_scale, rows, cols, rpb);
   return vita_check_launch();
 }
