@@ -236,8 +236,13 @@ def test_gemm_strided_a_and_errors(ops):
     tol("ops.gemm(a, w), ref", rel_l2(ops.gemm(a, w), ref), 2e-3)
     with pytest.raises(RuntimeError):
         ops.gemm(a, torch.zeros(64, 512, dtype=torch.bfloat16, device=DEV))     # weight shape mismatch
-    with pytest.raises(RuntimeError):
-        ops.gemm(big[:, :100].contiguous(), torch.zeros(8, 100, dtype=torch.bfloat16, device=DEV))  # K % 64
+    # a contraction that is not a multiple of 64 (SigLIP's FFN 4304) runs on zero-padded copies: exact
+    a100, w100 = big[:, :100].contiguous(), torch.randn(8, 100, generator=g(29)).bfloat16().to(DEV)
+    ref100 = (a100.float().cpu() @ w100.float().cpu().t()).bfloat16()
+    tol("ops.gemm(a100, w100), ref100", rel_l2(ops.gemm(a100, w100), ref100), 2e-3)
+    with pytest.raises(RuntimeError):                                            # the C entry point itself still refuses it
+        ops._L.check(ops._L.load().vita_gemm_bf16(a100.data_ptr(), 100, w100.data_ptr(), 100, torch.empty(100, 8, dtype=torch.bfloat16,
+                     device=DEV).data_ptr(), 8, 100, 8, 100, 0, None, None, None, 0, None), "vita_gemm_bf16")
     with pytest.raises(RuntimeError):
         ops.rmsnorm(torch.zeros(4, 64).bfloat16(), torch.ones(64).bfloat16())    # CPU tensor: no fallback
 
