@@ -31,11 +31,13 @@ layer = dm.build_module(specs.get_gpt_layer_with_transformer_engine_spec(), conf
 layer.load_state_dict({"self_attention.linear_qkv.weight": lp["qkv_w"], "self_attention.linear_qkv.bias": lp["qkv_b"],
                        "self_attention.linear_proj.weight": lp["o_w"], "mlp.linear_fc1.weight": lp["fc1_w"], "mlp.linear_fc2.weight": lp["fc2_w"],
                        "self_attention.linear_qkv.layer_norm_weight": lp["ln1"], "mlp.linear_fc1.layer_norm_weight": lp["ln2"]})
-from oracle import glue            # fp32 angle table exactly as Megatron's RotaryEmbedding hands it over (test infrastructure, not timed)
 for S in [int(x) for x in (sys.argv[1:] or ["16384", "131072"])]:
     g = torch.Generator(device=DEV).manual_seed(S)
     x = (torch.randn(S, cfg.hidden, generator=g, device=DEV) * 0.5).bfloat16()
-    freqs = glue.rope_emb(S, glue.rope_inv_freq(cfg.head_dim, cfg.rope_theta)).to(DEV)
+    # the fp32 angle table as Megatron's RotaryEmbedding hands it over: [s, 1, 1, d] = cat(outer(pos, inv_freq)) x 2 (rotary_pos_embedding.py:74-122)
+    inv_freq = 1.0 / (cfg.rope_theta ** (torch.arange(0, cfg.head_dim, 2, dtype=torch.float32) / cfg.head_dim))
+    ang = torch.outer(torch.arange(S, dtype=torch.float32), inv_freq)
+    freqs = torch.cat((ang, ang), dim=-1)[:, None, None, :].to(DEV)
     cos, sin = model.rotary_pos_emb(S)
     ws = model._workspace(S, x.device)
 
