@@ -1009,3 +1009,50 @@ def test_cp_kv_split_keeps_every_attention_launch_at_ten_rounds_of_workgroups(mo
     monkeypatch.setenv("VITA_CP_KV_SPLIT", "0")
     with pytest.raises(ValueError):
         ops.cp_kv_split(8, 40, 16384)
+
+
+def test_vit_layer_specs_construct_on_cpu_with_the_references_parameter_names():
+    """The three ViT spec builders registered on `long_vita_megatron.core.models.vision.vit_layer_specs.*` (M/core/models/vision/vit_layer_specs.py:30-101),
+    built by the stand-in `build_module` on the CPU: layer classes, leaves, the parameter names the reference's checkpoints use (ls1 / ls2 only for
+    InternViT), Megatron's shapes at SigLIP-400M's sizes (nothing padded), the activation / bias-chain flags — and the head-size padding helper."""
+    import functools
+    import dummy_megatron as dm
+    import long_vita_amd.megatron_adaptor as ad
+    from long_vita_amd import layers
+    from long_vita_amd.dot_product_attention import HipDotProductAttention, _pad_head_dim
+    from long_vita_amd.patch_utils import MindSpeedPatchesManager as aspm
+    aspm.patches_info = {}
+    names = dm.install()
+    try:
+        assert ad.exe_adaptation(create_dummy=True)
+        vls = sys.modules["long_vita_megatron.core.models.vision.vit_layer_specs"]
+        base = dict(num_query_groups=16, num_attention_heads=16, normalization="LayerNorm", add_bias_linear=True, add_qkv_bias=True,
+                    gated_linear_unit=False, use_cpu_initialization=True)
+        icfg = dm.TransformerConfig(hidden_size=1024, kv_channels=64, ffn_hidden_size=4096, activation_func=torch.nn.functional.gelu, **base)
+        for builder, fused in ((vls.get_vit_layer_local_spec_for_intern, False), (vls.get_vit_layer_with_transformer_engine_spec_for_intern, True)):
+            lyr = dm.build_module(builder(), config=icfg, layer_number=1)
+            assert type(lyr).__name__ == "InternViTTransformerLayer" and isinstance(lyr.self_attention.core_attention, HipDotProductAttention)
+            assert isinstance(lyr.mlp, layers.ViTMLP) and not lyr.mlp.tanh and not lyr.mlp.unfused_bias
+            keys = {k for k, _ in lyr.named_parameters()}
+            assert {"ls1", "ls2", "mlp.linear_fc1.weight", "mlp.linear_fc2.bias", "self_attention.linear_proj.bias"} <= keys
+            assert ("self_attention.linear_qkv.layer_norm_weight" in keys) == fused and ("input_layernorm.weight" in keys) == (not fused)
+            assert float(lyr.ls1.detach().float().mean()) == pytest.approx(0.01, rel=1e-2)    # intern_vit_model.py:43-44
+        scfg = dm.TransformerConfig(hidden_size=1152, kv_channels=72, ffn_hidden_size=4304,
+                                    activation_func=functools.partial(torch.nn.functional.gelu, approximate="tanh"), **base)
+        sl = dm.build_module(vls.get_vit_layer_local_spec_for_siglip(), config=scfg, layer_number=1)
+        assert type(sl).__name__ == "SigLIPViTTransformerLayer" and sl.mlp.tanh and sl.mlp.unfused_bias
+        shapes = {k: tuple(v.shape) for k, v in sl.named_parameters()}
+        assert "ls1" not in shapes and shapes["mlp.linear_fc2.weight"] == (1152, 4304) and shapes["self_attention.linear_qkv.weight"] == (3456, 1152)
+        bad = dm.TransformerConfig(hidden_size=1152, kv_channels=72, ffn_hidden_size=4304, activation_func=torch.nn.functional.silu, **base)
+        with pytest.raises(NotImplementedError):
+            dm.build_module(vls.get_vit_layer_local_spec_for_siglip(), config=bad, layer_number=1)
+        # head sizes the kernels do not tile are zero-padded (scores and the kept output columns unchanged); 64 / 128 pass through
+        t = torch.randn(2, 5, 3, 72)
+        p_ = _pad_head_dim(t)
+        assert p_.shape == (2, 5, 3, 128) and torch.equal(p_[..., :72], t) and float(p_[..., 72:].abs().max()) == 0.0
+        assert _pad_head_dim(torch.zeros(1, 1, 1, 64)).shape[-1] == 64 and _pad_head_dim(torch.zeros(1, 1, 1, 40)).shape[-1] == 64
+        with pytest.raises(NotImplementedError):
+            _pad_head_dim(torch.zeros(1, 1, 1, 160))
+    finally:
+        dm.uninstall(names)
+        aspm.patches_info = {}
