@@ -153,6 +153,9 @@ int vita_cp_src_tgt(const int64_t* hit_idx, int64_t n_hit, int tok_per_img,
  *   VITA_EPI_BIAS2_GELU_TANH   C = bf16(gelu_tanh(bf16(bf16(v) + bias[n])))     (SigLIP MLP: linear_fc1 returns its
  *                              bias unfused (skip_bias_add), M/core/models/vision/siglip_vit_model.py:66-69)
  *   VITA_EPI_BIAS2_RES         C = bf16(R[m,n] + bf16(bf16(v) + bias[n]))        (SigLIP linear_proj / linear_fc2, :50-52,69-72)
+ *   VITA_EPI_BIAS2_GELU        C = bf16(gelu_erf(bf16(bf16(v) + bias[n])))      (InternViT MLP under Megatron's local spec: linear_fc1 is
+ *                              skip_bias_add and `bias_activation_fusion` is off, M/pretrain_long_vita.py:213 — MLP.forward adds
+ *                              the bias to the bf16 product as an op of its own before F.gelu)
  *   VITA_EPI_SWIGLU            W holds [gate(N) ; up(N)] = 2N rows (fc1 = cat[gate, up],
  *                              R/tools/hf2mcore_long_vita.py:612); C[M,N] = bf16(bf16(silu(bf16(g))) * bf16(u))
  * ------------------------------------------------------------------------------------------- */
@@ -164,6 +167,7 @@ int vita_cp_src_tgt(const int64_t* hit_idx, int64_t n_hit, int tok_per_img,
 #define VITA_EPI_SWIGLU 5
 #define VITA_EPI_BIAS2_GELU_TANH 6
 #define VITA_EPI_BIAS2_RES 7
+#define VITA_EPI_BIAS2_GELU 8
 
 int vita_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc,
                    int64_t M, int64_t N, int64_t K, int epilogue, const void* bias,

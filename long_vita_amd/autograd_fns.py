@@ -77,7 +77,7 @@ class LinearFn(torch.autograd.Function):
             out = ops.gemm_skinny(x, weight)
         else:
             out = ops.gemm(x, weight, ops.EPI_BIAS if bias is not None else ops.EPI_NONE, bias)   # :409-411
-        return out.view(m // b, b, -1)
+        return out.view(m // b, b, out.shape[-1])     # explicit width: m == 0 (no row selected on this rank) must reshape too
 
     @staticmethod
     def backward(ctx, grad_output):

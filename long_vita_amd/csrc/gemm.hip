@@ -62,7 +62,7 @@ __device__ __forceinline__ int tile_off(int row, int slot) {
 template <int EPI>
 __device__ __forceinline__ void epilogue_math(float (&o)[4], bool has_bias, const float (&b)[4], const float (&sc)[4],
                                               const float (&r)[4]) {
-  if (EPI == VITA_EPI_BIAS2_GELU_TANH || EPI == VITA_EPI_BIAS2_RES) {      // bias added to the ROUNDED product
+  if (EPI == VITA_EPI_BIAS2_GELU_TANH || EPI == VITA_EPI_BIAS2_RES || EPI == VITA_EPI_BIAS2_GELU) {      // bias added to the ROUNDED product
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = bf16_round(o[j]);
   }
@@ -70,7 +70,7 @@ __device__ __forceinline__ void epilogue_math(float (&o)[4], bool has_bias, cons
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] += b[j];
   }
-  if (EPI == VITA_EPI_BIAS_GELU) {
+  if (EPI == VITA_EPI_BIAS_GELU || EPI == VITA_EPI_BIAS2_GELU) {
 #pragma unroll
     for (int j = 0; j < 4; ++j) o[j] = gelu_erf(bf16_round(o[j]));
   }
@@ -1036,6 +1036,9 @@ extern "C" int vita_gemm_bf16(const void* A, int64_t lda, const void* W, int64_t
     case VITA_EPI_BIAS2_RES:
       if (!bias || !R || (ldr & 3)) return VITA_ERR_INVALID_ARG;
       return launch_gemm<VITA_EPI_BIAS2_RES>(a, st);
+    case VITA_EPI_BIAS2_GELU:
+      if (!bias) return VITA_ERR_INVALID_ARG;
+      return launch_gemm<VITA_EPI_BIAS2_GELU>(a, st);
     default: return VITA_ERR_INVALID_ARG;
   }
 }

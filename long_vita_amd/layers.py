@@ -312,8 +312,9 @@ class ViTMLP(torch.nn.Module):
                      and act.keywords == {"approximate": "tanh"})
         if act is not torch.nn.functional.gelu and not self.tanh:
             raise NotImplementedError("ViTMLP: activation_func must be F.gelu or partial(F.gelu, approximate='tanh')")
-        # unfused_bias (SigLIP's local spec, vit_layer_specs.py:30-53): Megatron's MLP adds the fc1 bias to the bf16-ROUNDED product as an op
-        # of its own before the activation (skip_bias_add linears, no bias_activation_fusion); the InternViT specs fold it into the GEMM
+        # unfused_bias (every local ViT spec of the reference: `bias_activation_fusion = False`, M/pretrain_long_vita.py:213,296): Megatron's
+        # MLP adds the fc1 bias to the bf16-ROUNDED product as an op of its own before the activation (skip_bias_add linears); False = the
+        # TransformerEngine order (bias inside the GEMM, one rounding) of the TE spec
         self.unfused_bias = bool(unfused_bias)
         self.config = config
         self.input_size = input_size if input_size is not None else config.hidden_size
@@ -329,7 +330,8 @@ class ViTMLP(torch.nn.Module):
         fc1 = self.linear_fc1
         grad = torch.is_grad_enabled() and (hidden_states.requires_grad or fc1.weight.requires_grad)
         plain = type(fc1) is ColumnParallelLinear and not fc1.sequence_parallel and mpu.get_tensor_model_parallel_world_size() == 1
-        fused_epi = {(False, False): ops.EPI_BIAS_GELU, (True, True): ops.EPI_BIAS2_GELU_TANH}.get((self.unfused_bias, self.tanh))
+        fused_epi = {(False, False): ops.EPI_BIAS_GELU, (True, True): ops.EPI_BIAS2_GELU_TANH,
+                     (True, False): ops.EPI_BIAS2_GELU}.get((self.unfused_bias, self.tanh))
         if not grad and plain and fc1.bias is not None and fused_epi is not None:
             s, b, h = hidden_states.shape                                     # inference: GEMM + bias + GELU in one kernel
             a = ops.gemm(hidden_states.reshape(s * b, h), fc1.weight, fused_epi, fc1.bias).view(s, b, -1)

@@ -27,7 +27,8 @@ VITA_ERR_INVALID_ARG = -1
 VITA_ERR_UNSUPPORTED = -2
 VITA_ERR_LAUNCH = -3
 
-EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_RESIDUAL, EPI_BIAS_SCALE_RES, EPI_SWIGLU, EPI_BIAS2_GELU_TANH, EPI_BIAS2_RES = range(8)
+(EPI_NONE, EPI_BIAS, EPI_BIAS_GELU, EPI_RESIDUAL, EPI_BIAS_SCALE_RES, EPI_SWIGLU, EPI_BIAS2_GELU_TANH, EPI_BIAS2_RES,
+ EPI_BIAS2_GELU) = range(9)
 
 
 class VitaLibraryError(ImportError):

@@ -14,7 +14,7 @@ from typing import Optional, Sequence
 import torch
 
 from . import lib as _L
-from .lib import (EPI_BIAS, EPI_BIAS2_GELU_TANH, EPI_BIAS2_RES, EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_NONE,  # noqa: F401
+from .lib import (EPI_BIAS, EPI_BIAS2_GELU, EPI_BIAS2_GELU_TANH, EPI_BIAS2_RES, EPI_BIAS_GELU, EPI_BIAS_SCALE_RES, EPI_NONE,  # noqa: F401
                   EPI_RESIDUAL, EPI_SWIGLU, AttnParams)
 
 BF16 = torch.bfloat16
@@ -60,6 +60,8 @@ def layernorm(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor
     xc = x if x.is_contiguous() else x.contiguous()
     rows = xc.numel() // cols
     y = torch.empty_like(xc) if out is None else out
+    if rows == 0:
+        return y
     _L.check(_L.load().vita_layernorm_fwd(_dev(xc, "x", BF16), _dev(weight, "weight", BF16), _opt(bias, "bias", BF16),
                                           _dev(y, "out", BF16), rows, cols, float(eps), _stream()),
              "vita_layernorm_fwd")
@@ -282,7 +284,7 @@ def gemm(a: torch.Tensor, w: torch.Tensor, epilogue: int = EPI_NONE, bias: Optio
         # M/pretrain_long_vita.py:268-307) runs on zero-padded copies of both operands: exact, the padding adds zeros to every sum
         kp = (K + 63) // 64 * 64
         a = torch.nn.functional.pad(a, (0, kp - K))
-        w = torch.nn.functional.pad(w, (0, kp - K))
+        w = _padded_weight(w, kp)
         K = kp
     r_ptr, ldr = None, 0
     if residual is not None:
@@ -293,6 +295,27 @@ def gemm(a: torch.Tensor, w: torch.Tensor, epilogue: int = EPI_NONE, bias: Optio
                                       _dev(y, "out", BF16), y.stride(0), M, N, K, epilogue, _opt(bias, "bias", BF16),
                                       _opt(scale, "scale", BF16), r_ptr, ldr, _stream()), "vita_gemm_bf16")
     return y
+
+
+_PAD_CACHE: dict = {}
+
+
+def _padded_weight(w: torch.Tensor, kp: int) -> torch.Tensor:
+    """The zero-padded copy of a weight whose contraction length is not a multiple of 64 (SigLIP's fc2: K = 4304), made once per
+    weight VERSION: only `torch.nn.Parameter`s are cached — keyed by identity of the storage and shape, validated by torch's in-place
+    version counter, so an optimizer step or a checkpoint load invalidates the copy.  Anything else (activations, the transposed weight
+    of a dgrad: fresh tensors whose address the allocator reuses) is padded per call.  The cache drops its oldest entry beyond 128."""
+    if not isinstance(w, torch.nn.Parameter):
+        return torch.nn.functional.pad(w, (0, kp - w.shape[1]))
+    key = (w.data_ptr(), tuple(w.shape), w.stride(0), w.device.index)
+    hit = _PAD_CACHE.get(key)
+    if hit is not None and hit[0] == w._version:
+        return hit[1]
+    padded = torch.nn.functional.pad(w.detach(), (0, kp - w.shape[1]))
+    if len(_PAD_CACHE) >= 128:
+        _PAD_CACHE.pop(next(iter(_PAD_CACHE)))
+    _PAD_CACHE[key] = (w._version, padded)
+    return padded
 
 
 def gemm_tn_ok(a_t: torch.Tensor, w_t: torch.Tensor) -> bool:
@@ -484,6 +507,8 @@ def rmsnorm_bwd(dy, x, weight, eps: float, dw_acc: Optional[torch.Tensor] = None
 def swiglu(y: torch.Tensor, out=None) -> torch.Tensor:
     rows, two_f = y.shape
     a = torch.empty((rows, two_f // 2), dtype=BF16, device=y.device) if out is None else out
+    if rows == 0:
+        return a
     _L.check(_L.load().vita_swiglu_fwd(_dev(y, "y", BF16), _dev(a, "a", BF16), rows, two_f // 2, _stream()),
              "vita_swiglu_fwd")
     return a
@@ -492,6 +517,8 @@ def swiglu(y: torch.Tensor, out=None) -> torch.Tensor:
 def swiglu_bwd(y: torch.Tensor, da: torch.Tensor, out=None) -> torch.Tensor:
     rows, two_f = y.shape
     dy = torch.empty_like(y) if out is None else out
+    if rows == 0:
+        return dy
     _L.check(_L.load().vita_swiglu_bwd(_dev(y, "y", BF16), _dev(da, "da", BF16), _dev(dy, "dy", BF16), rows,
                                        two_f // 2, _stream()), "vita_swiglu_bwd")
     return dy
@@ -499,6 +526,8 @@ def swiglu_bwd(y: torch.Tensor, da: torch.Tensor, out=None) -> torch.Tensor:
 
 def gelu_bwd(x: torch.Tensor, dy: torch.Tensor, tanh: bool = False) -> torch.Tensor:
     dx = torch.empty_like(x)
+    if x.numel() == 0:
+        return dx
     fn = _L.load().vita_gelu_tanh_bwd if tanh else _L.load().vita_gelu_bwd
     _L.check(fn(_dev(x, "x", BF16), _dev(dy, "dy", BF16), _dev(dx, "dx", BF16), x.numel(), _stream()),
              "vita_gelu_tanh_bwd" if tanh else "vita_gelu_bwd")
@@ -510,6 +539,8 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, eps: 
     """Backward of layernorm(): returns dx; dgamma / dbeta (fp32 [cols], zeroed by the caller) receive the parameter gradients."""
     cols = x.shape[-1]
     dx = torch.empty_like(x) if out is None else out
+    if x.numel() == 0:                      # an empty frame batch: no rows, dgamma / dbeta stay as the caller zeroed them
+        return dx
     _L.check(_L.load().vita_layernorm_bwd(_dev(dy, "dy", BF16), _dev(x, "x", BF16), _dev(weight, "weight", BF16), _dev(dx, "dx", BF16),
                                           _dev(dgamma, "dgamma", torch.float32), _dev(dbeta, "dbeta", torch.float32),
                                           x.numel() // cols, cols, float(eps), _stream()), "vita_layernorm_bwd")
@@ -518,6 +549,8 @@ def layernorm_bwd(dy: torch.Tensor, x: torch.Tensor, weight: torch.Tensor, eps: 
 
 def gelu(x: torch.Tensor, tanh: bool = False) -> torch.Tensor:
     a = torch.empty_like(x)
+    if x.numel() == 0:
+        return a
     _L.check(_L.load().vita_gelu_fwd(_dev(x, "x", BF16), _dev(a, "a", BF16), x.numel(), int(tanh), _stream()), "vita_gelu_fwd")
     return a
 
@@ -526,6 +559,8 @@ def bias_scale_residual(x: torch.Tensor, bias: Optional[torch.Tensor], scale: Op
     """bf16(residual + bf16(bf16(x + bias) * scale)) — InternViTTransformerLayer's LayerScale residual; bias / scale optional."""
     cols = x.shape[-1]
     out = torch.empty_like(x)
+    if x.numel() == 0:
+        return out
     _L.check(_L.load().vita_bias_scale_res_fwd(_dev(x, "x", BF16), _opt(bias, "bias", BF16), _opt(scale, "scale", BF16),
                                                _dev(residual, "residual", BF16), _dev(out, "out", BF16), x.numel() // cols, cols,
                                                _stream()), "vita_bias_scale_res_fwd")
@@ -537,6 +572,8 @@ def bias_scale_residual_bwd(g: torch.Tensor, x: torch.Tensor, bias, scale, d_bia
     """-> dx = bf16(g * scale) (g itself when scale is None); d_bias / d_scale fp32 [cols] accumulate (zeroed by the caller)."""
     cols = x.shape[-1]
     dx = torch.empty_like(x) if scale is not None else None
+    if x.numel() == 0:
+        return g if dx is None else dx
     _L.check(_L.load().vita_bias_scale_res_bwd(_dev(g, "g", BF16), _dev(x, "x", BF16), _opt(bias, "bias", BF16), _opt(scale, "scale", BF16),
                                                _opt(dx, "dx", BF16), _opt(d_bias, "d_bias", torch.float32),
                                                _opt(d_scale, "d_scale", torch.float32), x.numel() // cols, cols, _stream()),
@@ -760,6 +797,8 @@ def add(a: torch.Tensor, b: torch.Tensor, out: Optional[torch.Tensor] = None) ->
     if a.shape != b.shape or not a.is_contiguous() or not b.is_contiguous():
         raise ValueError("add: contiguous tensors of equal shape")
     y = torch.empty_like(a) if out is None else out
+    if a.numel() == 0:
+        return y
     _L.check(_L.load().vita_add_bf16(_dev(a, "a", BF16), _dev(b, "b", BF16), _dev(y, "out", BF16), a.numel(), _stream()), "vita_add_bf16")
     return y
 

@@ -88,7 +88,7 @@ def _vit_spec(layer_cls, fused_norm: bool, unfused_bias: bool = False):
 
 def get_vit_layer_local_spec_for_intern(use_te=True):
     """vit_layer_specs.py:79-101 — the spec every reference script builds the InternViT-300M from."""
-    return _vit_spec(_layer_classes()[0], fused_norm=False)
+    return _vit_spec(_layer_classes()[0], fused_norm=False, unfused_bias=True)     # Megatron MLP, bias_activation_fusion off (:213)
 
 
 def get_vit_layer_with_transformer_engine_spec_for_intern(use_te=True):
