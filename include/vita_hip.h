@@ -306,6 +306,30 @@ int vita_vit_assemble(const void* patch_embeds, const void* cls_token, const voi
 int vita_pixel_shuffle_ln(const void* x, const void* w, const void* b, void* y, int64_t n,
                           int grid, int hidden, int has_cls, float eps, void* stream);
 
+/* ABI 15 — the same front / back end under Megatron's module seams (InternViTModel.forward / SigLIPViTModel.forward,
+ * M/core/models/vision/intern_vit_model.py:190-261, siglip_vit_model.py:165-228; MegatronVisionModel.forward_downsample /
+ * forward_projection, M/pretrain_long_vita.py:436-483), forward AND backward (stage 2 trains the encoder, the projector always trains):
+ *   vita_patchify14_ex    token_major != 0: patch row = patch * n + image — Megatron's [s, b, h] order, so the conv GEMM's output IS
+ *                         rows 1.. of the encoder input and the backward's gradient rows line up with the patch rows (no transposes).
+ *   vita_vit_assemble_ex  token_major as above for patch_embeds and x; pos_row0 = first row of the position table that is looked up
+ *                         (InternViTModel without a class token uses rows 1 .. seq, :141-143).
+ *   vita_vit_assemble_bwd d_pos[seq, h] = bf16(sum over images of dx[., s, :]) (fp32 sums) — the position table's gradient; its row 0
+ *                         is also the class token's (x[:, 0] = cls + pos[0]).
+ *   vita_pixel_shuffle_ln_ex   x addressed as x[image * img_stride + token * tok_stride + c] (elements, multiples of 8): the
+ *                         contiguous [n, seq, h] tensor or the permuted view of the encoder's [s, b, h] output (no copy);
+ *                         norm == 0: the pure permutation (forward_downsample alone; w / b unused).
+ *   vita_pixel_shuffle_ln_bwd  dx (x's strides; NULL = frozen encoder; the class token's row receives zeros) and, norm != 0,
+ *                         dgamma / dbeta (fp32 [4 h], accumulated: caller zeroes).  4 h <= 4096. */
+int vita_patchify14_ex(const void* images, void* patches, int64_t n, int H, int W, int k_pad, int token_major, void* stream);
+int vita_vit_assemble_ex(const void* patch_embeds, const void* cls_token, const void* pos_emb, void* x, int64_t n, int n_patches,
+                         int hidden, int has_cls, int pos_row0, int token_major, void* stream);
+int vita_vit_assemble_bwd(const void* dx, void* d_pos, int64_t n, int seq, int hidden, int token_major, void* stream);
+int vita_pixel_shuffle_ln_ex(const void* x, const void* w, const void* b, void* y, int64_t n, int grid, int hidden, int has_cls,
+                             float eps, int norm, int64_t img_stride, int64_t tok_stride, void* stream);
+int vita_pixel_shuffle_ln_bwd(const void* dy, const void* x, const void* w, void* dx, float* dgamma, float* dbeta, int64_t n,
+                              int grid, int hidden, int has_cls, float eps, int norm, int64_t img_stride, int64_t tok_stride,
+                              void* stream);
+
 /* ---------------------------------------------------------------------------------------------
  * Backward pass (training step, reference: torch autograd over the forward modules; the only
  * first-party backward code is M/core/tensor_parallel/layers.py:416-534).
@@ -365,6 +389,11 @@ int vita_bias_scale_res_bwd(const void* g, const void* x, const void* bias, cons
 int vita_ce_loss(const void* logits, int64_t ld, const int64_t* labels, float* loss, void* dlogits,
                  int64_t ld_d, const float* grad_scale, int64_t rows, int vocab, int* err_flag,
                  void* stream);
+/* ABI 15: the same on fp32 logits with fp32 dlogits — what `tensor_parallel.vocab_parallel_cross_entropy(logits.float(), labels)`
+ * receives (megatron LanguageModule.compute_language_model_loss, called at gpt_vl_model.py:414); loss may be NULL when only
+ * dlogits is wanted (the autograd backward re-runs the row pass with grad_scale = the incoming gradient). */
+int vita_ce_loss_f32(const float* logits, int64_t ld, const int64_t* labels, float* loss, float* dlogits,
+                     int64_t ld_d, const float* grad_scale, int64_t rows, int vocab, int* err_flag, void* stream);
 
 /* dst_f32[idx[i], :] += float(src_bf16[i, :]) — word-embedding weight gradient (the backward of
  * M/core/tensor_parallel/layers.py:216-232); idx[i] < 0 skips row i (visual-token positions). */

@@ -52,6 +52,35 @@ def _tp():
     return mpu.get_tensor_model_parallel_world_size(), mpu.get_tensor_model_parallel_group()
 
 
+def weight_bias_grads(go: torch.Tensor, x: torch.Tensor, need_weight: bool, need_bias: bool, n_out: int, dtype):
+    """grad_weight = grad_output.t().matmul(total_input), grad_bias = grad_output.sum(dim=0) (layers.py:522-524) for go [rows, n_out],
+    x [rows, k].  The TN kernel takes both operands contraction-major as they are; shapes it does not tile (output dims not multiples
+    of 256) go through two vita_transpose_bf16 passes and the NT GEMM.  No rows (an empty logit-mask selection on this rank): zeros."""
+    grad_weight = grad_bias = None
+    if go.shape[0] == 0:
+        if need_weight:
+            grad_weight = torch.zeros(n_out, x.shape[1], dtype=dtype, device=go.device)
+        if need_bias:
+            grad_bias = torch.zeros(n_out, dtype=dtype, device=go.device)
+        return grad_weight, grad_bias
+    if not (need_weight or need_bias):
+        return None, None
+    go_p, x_p = pad_rows(go), pad_rows(x.contiguous())
+    if ops.gemm_tn_ok(go_p, x_p):                # both operands contraction-major as they are: no transposed copies
+        if need_weight:
+            grad_weight = ops.gemm_tn(go_p, x_p)                                          # :522-523
+        if need_bias:
+            ones = torch.ones(go_p.shape[0], 256, dtype=go_p.dtype, device=go_p.device)
+            grad_bias = ops.gemm_tn(go_p, ones)[:, 0].contiguous()                        # :524
+    else:
+        go_t = transpose(go_p)
+        if need_weight:
+            grad_weight = wgrad(go_t, x_p)
+        if need_bias:
+            grad_bias = bias_grad(go_t)
+    return grad_weight, grad_bias
+
+
 # ------------------------------------------------------------------------------------------------
 # LinearWithGradAccumulationAndAsyncCommunication (M/core/tensor_parallel/layers.py:366-534), logit_mask included
 # ------------------------------------------------------------------------------------------------
@@ -100,26 +129,7 @@ class LinearFn(torch.autograd.Function):
             sub = torch.empty(input.shape, dtype=input.dtype, device=input.device)
             dist.reduce_scatter_tensor(sub, grad_input.contiguous(), group=group)
             grad_input = sub
-        grad_weight = grad_bias = None
-        if go.shape[0] == 0:                    # an empty logit-mask selection on this rank: zero parameter gradients
-            if ctx.needs_input_grad[1]:
-                grad_weight = torch.zeros_like(weight)
-            if ctx.use_bias:
-                grad_bias = torch.zeros(weight.shape[0], dtype=weight.dtype, device=weight.device)
-        elif ctx.needs_input_grad[1] or ctx.use_bias:
-            go_p, x_p = pad_rows(go), pad_rows(x.contiguous())
-            if ops.gemm_tn_ok(go_p, x_p):                # both operands contraction-major as they are: no transposed copies
-                if ctx.needs_input_grad[1]:
-                    grad_weight = ops.gemm_tn(go_p, x_p)                                          # :522-523
-                if ctx.use_bias:
-                    ones = torch.ones(go_p.shape[0], 256, dtype=go_p.dtype, device=go_p.device)
-                    grad_bias = ops.gemm_tn(go_p, ones)[:, 0].contiguous()                        # :524
-            else:
-                go_t = transpose(go_p)
-                if ctx.needs_input_grad[1]:
-                    grad_weight = wgrad(go_t, x_p)
-                if ctx.use_bias:
-                    grad_bias = bias_grad(go_t)
+        grad_weight, grad_bias = weight_bias_grads(go, x, ctx.needs_input_grad[1], ctx.use_bias, weight.shape[0], weight.dtype)
         return grad_input, grad_weight, grad_bias, None, None, None
 
 

@@ -628,17 +628,25 @@ __global__ __launch_bounds__(256) void layernorm_param_grad_kernel(const bf16_t*
 //   dlogits[i, v] = bf16( (softmax_v - [v == label]) * grad_scale[i] )     (optional)
 // One workgroup per row.
 // ---------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(256) void ce_loss_kernel(const bf16_t* __restrict__ logits, int64_t ld,
+__device__ __forceinline__ float ce_ld(const bf16_t* p, int64_t i) { return bf16_to_f32(p[i]); }
+__device__ __forceinline__ float ce_ld(const float* p, int64_t i) { return p[i]; }
+__device__ __forceinline__ void ce_st(bf16_t* p, int64_t i, float v) { p[i] = f32_to_bf16(v); }
+__device__ __forceinline__ void ce_st(float* p, int64_t i, float v) { p[i] = v; }
+
+// T = bf16_t (the stand-alone step: logits as the head GEMM left them) or float (Megatron hands vocab_parallel_cross_entropy
+// `logits.float()`, language_module.compute_language_model_loss; the gradient then has to be fp32 too)
+template <typename T>
+__global__ __launch_bounds__(256) void ce_loss_kernel(const T* __restrict__ logits, int64_t ld,
                                                       const int64_t* __restrict__ labels,
                                                       float* __restrict__ loss,
-                                                      bf16_t* __restrict__ dlogits, int64_t ldd,
+                                                      T* __restrict__ dlogits, int64_t ldd,
                                                       const float* __restrict__ grad_scale,
                                                       int V, int* __restrict__ err_flag) {
   __shared__ float red[16];
   const int64_t row = blockIdx.x;
-  const bf16_t* lr = logits + row * ld;
+  const T* lr = logits + row * ld;
   float mx = -INFINITY;
-  for (int v = threadIdx.x; v < V; v += blockDim.x) mx = fmaxf(mx, bf16_to_f32(lr[v]));
+  for (int v = threadIdx.x; v < V; v += blockDim.x) mx = fmaxf(mx, ce_ld(lr, v));
 #pragma unroll
   for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
   __syncthreads();
@@ -646,7 +654,7 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const bf16_t* __restrict__
   __syncthreads();
   mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   float se = 0.f;
-  for (int v = threadIdx.x; v < V; v += blockDim.x) se += __expf(bf16_to_f32(lr[v]) - mx);
+  for (int v = threadIdx.x; v < V; v += blockDim.x) se += __expf(ce_ld(lr, v) - mx);
   se = block_reduce_sum(se, red);
   const int64_t lab = labels[row];
   if (lab < 0 || lab >= V) {
@@ -654,15 +662,15 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const bf16_t* __restrict__
     return;
   }
   const float lse = mx + __logf(se);
-  if (threadIdx.x == 0) loss[row] = lse - bf16_to_f32(lr[lab]);
+  if (threadIdx.x == 0 && loss) loss[row] = lse - ce_ld(lr, lab);
   if (dlogits) {
     const float gs = grad_scale ? grad_scale[row] : 1.0f;
     const float inv = 1.0f / se;
-    bf16_t* dr = dlogits + row * ldd;
+    T* dr = dlogits + row * ldd;
     for (int v = threadIdx.x; v < V; v += blockDim.x) {
-      float pr = __expf(bf16_to_f32(lr[v]) - mx) * inv;
+      float pr = __expf(ce_ld(lr, v) - mx) * inv;
       if (v == lab) pr -= 1.0f;
-      dr[v] = f32_to_bf16(pr * gs);
+      ce_st(dr, v, pr * gs);
     }
   }
 }
@@ -910,9 +918,21 @@ extern "C" int vita_ce_loss(const void* logits, int64_t ld, const int64_t* label
   if (!logits || !labels || !loss || rows < 0 || vocab <= 0) return VITA_ERR_INVALID_ARG;
   if (rows == 0) return VITA_OK;
   if (rows > 0x7fffffff) return VITA_ERR_UNSUPPORTED;
-  hipLaunchKernelGGL(ce_loss_kernel, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+  hipLaunchKernelGGL(ce_loss_kernel<bf16_t>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream,
                      (const bf16_t*)logits, ld, labels, loss, (bf16_t*)dlogits, ld_d, grad_scale, vocab,
                      err_flag);
+  return vita_check_launch();
+}
+
+// the same on fp32 logits / fp32 dlogits; `loss` may be NULL (a backward call that only wants dlogits)
+extern "C" int vita_ce_loss_f32(const float* logits, int64_t ld, const int64_t* labels, float* loss,
+                                float* dlogits, int64_t ld_d, const float* grad_scale, int64_t rows,
+                                int vocab, int* err_flag, void* stream) {
+  if (!logits || !labels || (!loss && !dlogits) || rows < 0 || vocab <= 0) return VITA_ERR_INVALID_ARG;
+  if (rows == 0) return VITA_OK;
+  if (rows > 0x7fffffff) return VITA_ERR_UNSUPPORTED;
+  hipLaunchKernelGGL(ce_loss_kernel<float>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream,
+                     logits, ld, labels, loss, dlogits, ld_d, grad_scale, vocab, err_flag);
   return vita_check_launch();
 }
 

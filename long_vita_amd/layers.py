@@ -332,7 +332,9 @@ class ViTMLP(torch.nn.Module):
         plain = type(fc1) is ColumnParallelLinear and not fc1.sequence_parallel and mpu.get_tensor_model_parallel_world_size() == 1
         fused_epi = {(False, False): ops.EPI_BIAS_GELU, (True, True): ops.EPI_BIAS2_GELU_TANH,
                      (True, False): ops.EPI_BIAS2_GELU}.get((self.unfused_bias, self.tanh))
-        if not grad and plain and fc1.bias is not None and fused_epi is not None:
+        if fc1.bias is None:                                                  # the projector's MLP (add_bias_linear = False): gelu(bf16(x W^T))
+            fused_epi = None if self.tanh else ops.EPI_BIAS_GELU
+        if not grad and plain and fused_epi is not None:
             s, b, h = hidden_states.shape                                     # inference: GEMM + bias + GELU in one kernel
             a = ops.gemm(hidden_states.reshape(s * b, h), fc1.weight, fused_epi, fc1.bias).view(s, b, -1)
         elif self.unfused_bias:

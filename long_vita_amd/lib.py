@@ -21,7 +21,7 @@ CSRC_DIR = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libvita_hip.so")
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "vita_hip.h")
 
-ABI_VERSION = 14
+ABI_VERSION = 15
 VITA_OK = 0
 VITA_ERR_INVALID_ARG = -1
 VITA_ERR_UNSUPPORTED = -2
@@ -149,6 +149,11 @@ PROTOTYPES = {
     "vita_patchify14": (_i, [_p, _p, _l, _i, _i, _i, _p]),
     "vita_vit_assemble": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _p]),
     "vita_pixel_shuffle_ln": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _f, _p]),
+    "vita_patchify14_ex": (_i, [_p, _p, _l, _i, _i, _i, _i, _p]),
+    "vita_vit_assemble_ex": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _i, _i, _p]),
+    "vita_vit_assemble_bwd": (_i, [_p, _p, _l, _i, _i, _i, _p]),
+    "vita_pixel_shuffle_ln_ex": (_i, [_p, _p, _p, _p, _l, _i, _i, _i, _f, _i, _l, _l, _p]),
+    "vita_pixel_shuffle_ln_bwd": (_i, [_p, _p, _p, _p, _p, _p, _l, _i, _i, _i, _f, _i, _l, _l, _p]),
     # backward
     "vita_rope_qkv_bwd": (_i, [_p, _l, _i, _i, _i, _p, _p, _p]),
     "vita_transpose_bf16": (_i, [_p, _l, _p, _l, _l, _l, _p]),
@@ -163,6 +168,7 @@ PROTOTYPES = {
     "vita_bias_scale_res_fwd": (_i, [_p, _p, _p, _p, _p, _l, _i, _p]),
     "vita_bias_scale_res_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _i, _p]),
     "vita_ce_loss": (_i, [_p, _l, _p, _p, _p, _l, _p, _l, _i, _p, _p]),
+    "vita_ce_loss_f32": (_i, [_p, _l, _p, _p, _p, _l, _p, _l, _i, _p, _p]),
     "vita_row_scatter_add_f32": (_i, [_p, _p, _p, _l, _l, _i, _p, _p]),
     "vita_attn_delta": (_i, [_p, _p, _p, _l, _i, _i, _l, _l, _l, _l, _p]),
     "vita_flash_attn_bwd": (_i, [C.POINTER(AttnBwdParams), _p]),

@@ -21,6 +21,19 @@ reference patches on the prefill path:
         gpt_layer_specs.py of this package: the same ModuleSpec trees with HIP-backed leaves — norm + column-parallel linear,
         row-parallel linear, core attention — so a Megatron-built decoder layer runs every kernel through libvita_hip.so)
 
+  r04 — the rest of the path under the reference's entry points (VERDICT r3 "missing" 1; vision_modules.py):
+  long_vita_megatron.core.models.vision.intern_vit_model.InternViTModel / ...siglip_vit_model.SigLIPViTModel   the ViT front end
+        (conv1 + class token + position embedding: vita_patchify14 -> vita_gemm_bf16 -> vita_vit_assemble, with backward) around Megatron's
+        TransformerBlock; the names `pretrain_long_vita.py:48-49` imports
+  long_vita_megatron.core.models.vision.multimodal_projector.MultimodalProjector   (imported inside MegatronVisionModel.__init__, :393)
+  long_vita_megatron.core.models.multimodal.gpt_vl_model.GPTVLModel.__init__   (wrapper: after the reference built
+        `external_feature_model`, its forward_once / forward_downsample / forward_projection — methods of a class that lives in the
+        ENTRY SCRIPT — are rebound to the fused pixel-shuffle + LayerNorm kernel (with backward) + the HIP projector)
+  megatron.core.transformer.custom_layers.transformer_engine.TENorm   -> layers.Norm: the decoder's `final_layernorm`
+        (M/core/transformer/transformer_block.py:201; the reference's adaptor carries the same patch commented out, :55-57)
+  megatron.core.tensor_parallel.cross_entropy.vocab_parallel_cross_entropy   -> vita_ce_loss (forward and backward), the loss behind
+        `compute_language_model_loss` (gpt_vl_model.py:414)
+
 LanguageModelEmbedding, ColumnParallelLinear and the spec leaves are `torch.nn.Module`s with Megatron's constructor
 signatures, Parameters under Megatron's names and autograd (layers.py, language_model_embedding.py, autograd_fns.py).
 Targets of the reference that stay Megatron-resident (not arithmetic of this path): TransformerConfig (:96-97, extra
@@ -98,7 +111,9 @@ def _targets():
     from .gpt_layer_specs import get_gpt_layer_local_spec, get_gpt_layer_with_transformer_engine_spec
     from .language_model_embedding import LanguageModelEmbedding
     from .layers import ColumnParallelLinear
+    from .layers import Norm
     from .rotary_pos_embedding import apply_rotary_pos_emb
+    from . import vision_modules as vm
     return [
         ("megatron.core.transformer.dot_product_attention.DotProductAttention.forward",
          dot_product_attention_forward_wrapper),
@@ -117,16 +132,31 @@ def _targets():
         (VIT_SPECS + "get_vit_layer_local_spec_for_intern", vls.get_vit_layer_local_spec_for_intern),
         (VIT_SPECS + "get_vit_layer_with_transformer_engine_spec_for_intern", vls.get_vit_layer_with_transformer_engine_spec_for_intern),
         (VIT_SPECS + "get_vit_layer_local_spec_for_siglip", vls.get_vit_layer_local_spec_for_siglip),
+        # r04: the ViT front end, the projector, MegatronVisionModel's downsample / projection, the final norm and the loss
+        (VISION + "intern_vit_model.InternViTModel", vm.InternViTModel),
+        (VISION + "siglip_vit_model.SigLIPViTModel", vm.SigLIPViTModel),
+        (VISION + "multimodal_projector.MultimodalProjector", vm.MultimodalProjector),
+        ("long_vita_megatron.core.models.multimodal.gpt_vl_model.GPTVLModel.__init__", vm.gpt_vl_model_init_wrapper),
+        ("megatron.core.transformer.custom_layers.transformer_engine.TENorm", Norm),
+        ("megatron.core.tensor_parallel.cross_entropy.vocab_parallel_cross_entropy", vm.vocab_parallel_cross_entropy),
     ]
 
 
-VIT_SPECS = "long_vita_megatron.core.models.vision.vit_layer_specs."
+VISION = "long_vita_megatron.core.models.vision."
+VIT_SPECS = VISION + "vit_layer_specs."
 # registered here but not by the reference: RoPE (it leaves Megatron's in place and relies on apex's fused kernel, :102-103) and the
 # three ViT layer-spec builders, which live in the reference's OWN package (M/core/models/vision/vit_layer_specs.py:30-101) — the
 # reference has no reason to patch itself; a drop-in that must not edit the reference swaps them through the same manager
 EXTRA_TARGETS = ("megatron.core.models.common.embeddings.rotary_pos_embedding.apply_rotary_pos_emb",
                  VIT_SPECS + "get_vit_layer_local_spec_for_intern", VIT_SPECS + "get_vit_layer_with_transformer_engine_spec_for_intern",
-                 VIT_SPECS + "get_vit_layer_local_spec_for_siglip")
+                 VIT_SPECS + "get_vit_layer_local_spec_for_siglip",
+                 # r04: classes of the reference's own package and two Megatron names it leaves alone (torch / TE / Megatron arithmetic
+                 # that stays on the path unless it is swapped): see the module docstring
+                 VISION + "intern_vit_model.InternViTModel", VISION + "siglip_vit_model.SigLIPViTModel",
+                 VISION + "multimodal_projector.MultimodalProjector",
+                 "long_vita_megatron.core.models.multimodal.gpt_vl_model.GPTVLModel.__init__",
+                 "megatron.core.transformer.custom_layers.transformer_engine.TENorm",
+                 "megatron.core.tensor_parallel.cross_entropy.vocab_parallel_cross_entropy")
 
 PATCHES = [name for name, _ in _targets()]
 

@@ -436,38 +436,92 @@ def attn_merge_(o_a: torch.Tensor, lse_a: torch.Tensor, o_b: torch.Tensor, lse_b
 # ------------------------------------------------------------------------------------------------
 # ViT helpers
 # ------------------------------------------------------------------------------------------------
-def patchify14(images: torch.Tensor, k_pad: int = 640) -> torch.Tensor:
+def patchify14(images: torch.Tensor, k_pad: int = 640, token_major: bool = False) -> torch.Tensor:
+    """im2col of Conv2d(3, h, 14, stride 14): [n, 3, H, W] -> [n * P, k_pad] (columns 588.. zero).  token_major: row = patch * n + image
+    (Megatron's [s, b, h] order) instead of image * P + patch."""
     n, c, H, W = images.shape
     if c != 3:
         raise ValueError("images must be [n, 3, H, W]")
     im = images.contiguous()
     out = torch.empty((n * (H // 14) * (W // 14), k_pad), dtype=BF16, device=im.device)
-    _L.check(_L.load().vita_patchify14(_dev(im, "images", BF16), _dev(out, "patches"), n, H, W, k_pad, _stream()),
+    _L.check(_L.load().vita_patchify14_ex(_dev(im, "images", BF16), _dev(out, "patches"), n, H, W, k_pad, int(token_major), _stream()),
              "vita_patchify14")
     return out
 
 
 def vit_assemble(patch_embeds: torch.Tensor, cls_token: Optional[torch.Tensor], pos_emb: torch.Tensor, n: int,
-                 n_patches: int) -> torch.Tensor:
+                 n_patches: int, pos_row0: int = 0, token_major: bool = False) -> torch.Tensor:
+    """cat(cls, patch_embeds) + pos[pos_row0 + s] -> [n, seq, h], or [seq, n, h] with token_major (patch_embeds rows token-major too)."""
     hidden = patch_embeds.shape[-1]
     has_cls = cls_token is not None
-    x = torch.empty((n, n_patches + int(has_cls), hidden), dtype=BF16, device=patch_embeds.device)
-    _L.check(_L.load().vita_vit_assemble(_dev(patch_embeds.contiguous(), "patch_embeds", BF16),
-                                         _opt(cls_token, "cls_token", BF16), _dev(pos_emb.contiguous(), "pos_emb", BF16),
-                                         _dev(x, "x"), n, n_patches, hidden, int(has_cls), _stream()),
+    seq = n_patches + int(has_cls)
+    if pos_emb.shape[0] < pos_row0 + seq:
+        raise ValueError("position table too short")
+    x = torch.empty((seq, n, hidden) if token_major else (n, seq, hidden), dtype=BF16, device=patch_embeds.device)
+    _L.check(_L.load().vita_vit_assemble_ex(_dev(patch_embeds.contiguous(), "patch_embeds", BF16),
+                                            _opt(cls_token, "cls_token", BF16), _dev(pos_emb.contiguous(), "pos_emb", BF16),
+                                            _dev(x, "x"), n, n_patches, hidden, int(has_cls), int(pos_row0), int(token_major), _stream()),
              "vita_vit_assemble")
     return x
 
 
-def pixel_shuffle_ln(x: torch.Tensor, weight: torch.Tensor, bias: Optional[torch.Tensor], grid: int, has_cls: bool,
-                     eps: float = 1e-5) -> torch.Tensor:
+def vit_assemble_bwd(dx: torch.Tensor, token_major: bool = False) -> torch.Tensor:
+    """dx [n, seq, h] (or [seq, n, h], token_major) -> bf16 [seq, h] = sum over the images (fp32 accumulation): the gradient of the
+    position rows that were looked up; row 0 is also the class token's."""
+    if dx.dim() != 3 or not dx.is_contiguous():
+        raise ValueError("dx must be a contiguous 3-D tensor")
+    seq, n = (dx.shape[0], dx.shape[1]) if token_major else (dx.shape[1], dx.shape[0])
+    hidden = dx.shape[2]
+    out = torch.empty((seq, hidden), dtype=BF16, device=dx.device)
+    if n == 0:
+        return out.zero_()
+    _L.check(_L.load().vita_vit_assemble_bwd(_dev(dx, "dx", BF16), _dev(out, "d_pos"), n, seq, hidden, int(token_major), _stream()),
+             "vita_vit_assemble_bwd")
+    return out
+
+
+def _img_tok_strides(x: torch.Tensor):
+    """x [n, seq, h] with unit inner stride (contiguous, or the permuted view of an [s, b, h] tensor): (image, token) strides."""
+    if x.dim() != 3 or x.stride(2) != 1:
+        raise ValueError("x must be [n, seq, h] with a unit inner stride")
+    return x.stride(0), x.stride(1)
+
+
+def pixel_shuffle_ln(x: torch.Tensor, weight: Optional[torch.Tensor], bias: Optional[torch.Tensor], grid: int, has_cls: bool,
+                     eps: float = 1e-5, norm: bool = True) -> torch.Tensor:
+    """drop cls + pixel_shuffle(0.5) (+ LayerNorm(4 h) when norm): x [n, seq, h] (any image / token stride) -> [n, (grid/2)^2, 4 h]."""
     n, _, hidden = x.shape
-    xc = x.contiguous()
+    if x.stride(2) != 1 or (x.stride(0) | x.stride(1)) & 7:
+        x = x.contiguous()
+    si, st = _img_tok_strides(x)
     y = torch.empty((n, (grid // 2) ** 2, hidden * 4), dtype=BF16, device=x.device)
-    _L.check(_L.load().vita_pixel_shuffle_ln(_dev(xc, "x", BF16), _dev(weight, "weight", BF16), _opt(bias, "bias", BF16),
-                                             _dev(y, "y"), n, grid, hidden, int(has_cls), float(eps), _stream()),
+    if n == 0:
+        return y
+    _L.check(_L.load().vita_pixel_shuffle_ln_ex(_dev(x, "x", BF16), _opt(weight, "weight", BF16), _opt(bias, "bias", BF16),
+                                                _dev(y, "y"), n, grid, hidden, int(has_cls), float(eps), int(norm), si, st, _stream()),
              "vita_pixel_shuffle_ln")
     return y
+
+
+def pixel_shuffle_ln_bwd(dy: torch.Tensor, x: torch.Tensor, weight: Optional[torch.Tensor], grid: int, has_cls: bool, eps: float,
+                         dgamma: Optional[torch.Tensor], dbeta: Optional[torch.Tensor], want_dx: bool = True, norm: bool = True):
+    """Backward of pixel_shuffle_ln: returns dx (x's shape, contiguous; the class token's row zero) or None; dgamma / dbeta fp32 [4 h]
+    (zeroed by the caller) accumulate the LayerNorm parameter gradients."""
+    n, seq, hidden = x.shape
+    if x.stride(2) != 1 or (x.stride(0) | x.stride(1)) & 7:
+        x = x.contiguous()
+    dx = torch.empty((n, seq, hidden), dtype=BF16, device=x.device) if want_dx else None
+    if n == 0:
+        return dx
+    if want_dx and not x.is_contiguous():
+        # dx is written with x's strides: give it the same layout ([s, b, h] memory, viewed [n, seq, h])
+        dx = torch.empty_strided((n, seq, hidden), x.stride(), dtype=BF16, device=x.device)
+    si, st = _img_tok_strides(x)
+    _L.check(_L.load().vita_pixel_shuffle_ln_bwd(_dev(dy.contiguous(), "dy", BF16), _dev(x, "x", BF16), _opt(weight, "weight", BF16),
+                                                 _opt(dx, "dx", BF16), _opt(dgamma, "dgamma", torch.float32),
+                                                 _opt(dbeta, "dbeta", torch.float32), n, grid, hidden, int(has_cls), float(eps),
+                                                 int(norm), si, st, _stream()), "vita_pixel_shuffle_ln_bwd")
+    return dx
 
 
 # ------------------------------------------------------------------------------------------------
@@ -592,17 +646,23 @@ def layernorm_param_grad(dy, x, dgamma: torch.Tensor, dbeta: torch.Tensor, eps: 
 
 
 def ce_loss(logits: torch.Tensor, labels: torch.Tensor, grad_scale: Optional[torch.Tensor] = None,
-            want_grad: bool = False):
-    """logits [n, V] bf16, labels [n] int64 -> loss [n] fp32 (, dlogits [n, V] bf16)."""
+            want_grad: bool = False, want_loss: bool = True):
+    """logits [n, V] bf16 (or fp32: dlogits fp32 too), labels [n] int64 -> loss [n] fp32 (, dlogits [n, V]); grad_scale fp32 [n]."""
     n, V = logits.shape
-    loss = torch.empty(n, dtype=torch.float32, device=logits.device)
-    dl = torch.empty_like(logits) if want_grad else None
+    f32 = logits.dtype == torch.float32
+    if not f32 and logits.dtype != BF16:
+        raise ValueError("logits must be bf16 or fp32")
+    if logits.stride(1) != 1:
+        logits = logits.contiguous()
+    loss = torch.empty(n, dtype=torch.float32, device=logits.device) if (want_loss or not f32) else None
+    dl = torch.empty_like(logits, memory_format=torch.contiguous_format) if want_grad else None
+    if n == 0:
+        return (loss, dl) if want_grad else loss
     flag = _err_flag(logits.device)
-    _L.check(_L.load().vita_ce_loss(_dev(logits, "logits", BF16), logits.stride(0),
-                                    _dev(labels.contiguous(), "labels", torch.int64), _dev(loss, "loss"),
-                                    _opt(dl, "dlogits"), dl.stride(0) if want_grad else 0,
-                                    _opt(grad_scale, "grad_scale", torch.float32), n, V, _dev(flag, "flag"),
-                                    _stream()), "vita_ce_loss")
+    fn = _L.load().vita_ce_loss_f32 if f32 else _L.load().vita_ce_loss
+    _L.check(fn(_dev(logits, "logits"), logits.stride(0), _dev(labels.contiguous(), "labels", torch.int64), _opt(loss, "loss"),
+                _opt(dl, "dlogits"), dl.stride(0) if want_grad else 0, _opt(grad_scale, "grad_scale", torch.float32), n, V,
+                _dev(flag, "flag"), _stream()), "vita_ce_loss")
     if int(flag.item()):
         raise IndexError("vita_ce_loss: label out of range")
     return (loss, dl) if want_grad else loss

@@ -11,6 +11,14 @@ not vendor) that BUILD and CALL the modules this repo replaces — test infrastr
       skip_bias_add=True)` / `linear_fc2`), the `[sq, b, ng, (np/ng + 2) hn]` split of the mixed QKV, RoPE through
       `apply_rotary_pos_emb(t, freqs, config=, cu_seqlens=)`, residuals through `bias_dropout_add`;
   * enums.AttnMaskType, identity_op.IdentityOp, a parallel_state with TP = CP = 1, TransformerConfig as a plain dataclass.
+  * r04: TransformerBlock (the layer stack + `final_layernorm` built from the name `TENorm` of its own module namespace, as
+    M/core/transformer/transformer_block.py:16-18,201 imports and calls it; `--recompute-granularity full --recompute-method block
+    --recompute-num-layers N` through `tensor_parallel.checkpoint`), tensor_parallel.checkpoint itself (CheckpointFunction of
+    megatron/core/tensor_parallel/random.py restated: forward under no_grad keeping the inputs and the RNG states, backward = the
+    function re-run with autograd on — the way Megatron RE-ENTERS this package's autograd Functions), a `GPTVLModel` shell that
+    builds `external_feature_model` the way the reference's does (gpt_vl_model.py:110-113), and `MegatronVisionModel`: the class
+    of the reference's ENTRY SCRIPT (M/pretrain_long_vita.py:310-520) restated as plain torch — constructor wiring, forward_once /
+    forward_chunk / forward, the torch pixel_shuffle and torch.nn.LayerNorm the drop-in has to displace.
 No arithmetic lives here except the SwiGLU of Megatron's MLP (`F.silu(gate) * up`, computed through the product's SwiGLUFn so
 that the layer stays on the library) — the point is that the product's modules survive Megatron's own construction calls.
 """
@@ -100,6 +108,9 @@ class TransformerConfig:
     init_method: Optional[Callable] = None
     output_layer_init_method: Optional[Callable] = None
     init_method_std: float = 0.02
+    recompute_granularity: Optional[str] = None
+    recompute_method: Optional[str] = None
+    recompute_num_layers: Optional[int] = None
 
     def __post_init__(self):
         if self.init_method is None:
@@ -243,7 +254,202 @@ class TransformerLayer(torch.nn.Module):
         return hidden_states, context
 
 
+class _TENormPlaceholder:
+    """megatron.core.transformer.custom_layers.transformer_engine.TENorm: needs TransformerEngine; the adaptor replaces it."""
+
+    def __new__(cls, config, hidden_size, eps=1e-5):
+        raise AssertionError("TransformerEngine's TENorm must not be constructed: the adaptor registers layers.Norm on this name")
+
+
+class CheckpointFunction(torch.autograd.Function):
+    """megatron.core.tensor_parallel.random.CheckpointFunction (distribute_saved_activations = False)."""
+
+    @staticmethod
+    def forward(ctx, run_function, distribute_saved_activations, *args):
+        ctx.run_function = run_function
+        ctx.fwd_cpu_rng_state = torch.get_rng_state()
+        ctx.fwd_cuda_rng_state = torch.cuda.get_rng_state() if torch.cuda.is_available() else None
+        with torch.no_grad():
+            outputs = run_function(*args)
+        ctx.save_for_backward(*args)
+        return outputs
+
+    @staticmethod
+    def backward(ctx, *args):
+        if not torch.autograd._is_checkpoint_valid():
+            raise RuntimeError("Checkpointing is not compatible with .grad(), please use .backward() if possible")
+        inputs = ctx.saved_tensors
+        bwd_cpu_rng_state = torch.get_rng_state()
+        torch.set_rng_state(ctx.fwd_cpu_rng_state)
+        if ctx.fwd_cuda_rng_state is not None:
+            bwd_cuda_rng_state = torch.cuda.get_rng_state()
+            torch.cuda.set_rng_state(ctx.fwd_cuda_rng_state)
+        detached_inputs = tuple(x.detach().requires_grad_(x.requires_grad) if isinstance(x, torch.Tensor) else x for x in inputs)
+        with torch.enable_grad():
+            outputs = ctx.run_function(*detached_inputs)
+        torch.set_rng_state(bwd_cpu_rng_state)
+        if ctx.fwd_cuda_rng_state is not None:
+            torch.cuda.set_rng_state(bwd_cuda_rng_state)
+        if isinstance(outputs, torch.Tensor):
+            outputs = (outputs,)
+        outputs, args = zip(*filter(lambda x: torch.is_tensor(x[0]), zip(outputs, args)))
+        torch.autograd.backward(outputs, args)
+        grads = tuple(inp.grad if isinstance(inp, torch.Tensor) else inp for inp in detached_inputs)
+        return (None, None) + grads
+
+
+def checkpoint(function, distribute_saved_activations, *args):
+    """megatron.core.tensor_parallel.checkpoint."""
+    return CheckpointFunction.apply(function, distribute_saved_activations, *args)
+
+
+class TransformerBlock(torch.nn.Module):
+    """megatron.core.transformer.transformer_block.TransformerBlock: `num_layers` layers from one spec, the final norm through the
+    module-level name TENorm, activation recompute per Megatron's `_checkpointed_forward` (method "block": the first
+    recompute_num_layers layers are checkpointed one by one; "uniform": chunks of recompute_num_layers layers)."""
+
+    def __init__(self, config, spec, post_layer_norm: bool = True, pre_process: bool = True, post_process: bool = True):
+        super().__init__()
+        self.config, self.pre_process, self.post_process, self.input_tensor = config, pre_process, post_process, None
+        self.layers = torch.nn.ModuleList([build_module(spec, config=config, layer_number=i + 1) for i in range(config.num_layers)])
+        self.num_layers_per_pipeline_rank = len(self.layers)
+        if post_process and post_layer_norm:
+            norm = sys.modules["megatron.core.transformer.transformer_block"].TENorm          # transformer_block.py:16-18,201
+            self.final_layernorm = norm(config=config, hidden_size=config.hidden_size, eps=config.layernorm_epsilon)
+
+    def set_input_tensor(self, input_tensor):
+        self.input_tensor = input_tensor
+
+    def _checkpointed_forward(self, hidden_states, attention_mask, rotary_pos_emb, packed_seq_params):
+        tp = sys.modules["megatron.core.tensor_parallel"]
+
+        def custom(start, end):
+            def custom_forward(hidden_states, attention_mask, rotary_pos_emb):
+                for index in range(start, end):
+                    hidden_states, _ = self.layers[index](hidden_states, attention_mask=attention_mask, rotary_pos_emb=rotary_pos_emb,
+                                                          packed_seq_params=packed_seq_params)
+                return hidden_states
+            return custom_forward
+
+        n, k = len(self.layers), self.config.recompute_num_layers
+        if self.config.recompute_method == "uniform":
+            for l in range(0, n, k):
+                hidden_states = tp.checkpoint(custom(l, min(l + k, n)), False, hidden_states, attention_mask, rotary_pos_emb)
+        elif self.config.recompute_method == "block":
+            for l in range(n):
+                if l < k:
+                    hidden_states = tp.checkpoint(custom(l, l + 1), False, hidden_states, attention_mask, rotary_pos_emb)
+                else:
+                    hidden_states = custom(l, l + 1)(hidden_states, attention_mask, rotary_pos_emb)
+        else:
+            raise ValueError("Invalid activation recompute method.")
+        return hidden_states
+
+    def forward(self, hidden_states, attention_mask=None, context=None, context_mask=None, rotary_pos_emb=None, inference_params=None,
+                packed_seq_params=None):
+        if not self.pre_process:
+            hidden_states = self.input_tensor
+        if getattr(self.config, "recompute_granularity", None) == "full" and self.training:
+            hidden_states = self._checkpointed_forward(hidden_states, attention_mask, rotary_pos_emb, packed_seq_params)
+        else:
+            for layer in self.layers:
+                hidden_states, context = layer(hidden_states, attention_mask=attention_mask, rotary_pos_emb=rotary_pos_emb,
+                                               inference_params=inference_params, packed_seq_params=packed_seq_params)
+        if self.post_process and hasattr(self, "final_layernorm"):
+            hidden_states = self.final_layernorm(hidden_states)
+        return hidden_states
+
+
+class GPTVLModel(torch.nn.Module):
+    """The part of long_vita_megatron.core.models.multimodal.gpt_vl_model.GPTVLModel.__init__ the vision drop-in hangs on (:110-113):
+    `self.external_feature_model = external_feature_model_provider(config, *external_args)`."""
+
+    def __init__(self, config, transformer_layer_spec=None, vocab_size=0, max_sequence_length=0, pre_process=True, post_process=True,
+                 external_feature_model_provider=None, external_args=(), **kwargs):
+        super().__init__()
+        self.config, self.pre_process, self.post_process = config, pre_process, post_process
+        if pre_process:
+            self.external_feature_model = external_feature_model_provider(config, *external_args)
+
+
+class MegatronVisionModel(torch.nn.Module):
+    """The reference's entry-script class (M/pretrain_long_vita.py:310-596), plain torch: what runs when nothing displaces it.
+    `args` = the namespace get_args() would return (vision_* flags, image_size, hidden_size); the ViT class, its layer spec and
+    MultimodalProjector are taken from the (patched) module names the script imports them from."""
+
+    def __init__(self, args, vit_config, projector_config):
+        super().__init__()
+        for k in ("vision_seq_length", "image_token_length", "vision_model_type", "vision_context_parallel", "vision_downsample_ratio",
+                  "vision_downsample_stride", "add_class_token", "vision_model_freeze", "vision_projector_freeze",
+                  "vision_model_recompute", "vision_projector_recompute"):
+            setattr(self, k, getattr(args, k))
+        vis = "long_vita_megatron.core.models.vision."
+        specs = sys.modules[vis + "vit_layer_specs"]
+        if self.vision_model_type == "intern_300m":                                       # :346-356 (use_te = False is hard-coded)
+            spec, vit_module = specs.get_vit_layer_local_spec_for_intern(), sys.modules[vis + "intern_vit_model"].InternViTModel
+        elif self.vision_model_type == "siglip_400m":                                     # :366-372
+            spec, vit_module = specs.get_vit_layer_local_spec_for_siglip(), sys.modules[vis + "siglip_vit_model"].SigLIPViTModel
+        else:
+            raise NotImplementedError(self.vision_model_type)
+        self.vit = vit_module(vit_config, spec, add_class_token=args.add_class_token, patch_dim=args.patch_dim, img_h=args.image_size,
+                              img_w=args.image_size, vision_context_parallel=args.vision_context_parallel)
+        MultimodalProjector = sys.modules[vis + "multimodal_projector"].MultimodalProjector            # imported inside __init__ (:393)
+        proj_input_size = vit_config.hidden_size
+        if self.vision_downsample_ratio != 1:
+            proj_input_size = vit_config.hidden_size * int(1 / self.vision_downsample_ratio) ** 2
+        self.vision_projection = MultimodalProjector(projector_config, MLPSubmodules(linear_fc1=None, linear_fc2=None), "mlp",
+                                                     proj_input_size)
+        self.pre_proj_layernorm = torch.nn.LayerNorm(proj_input_size) if args.vision_projector_pre_norm else torch.nn.Identity()
+
+    def forward_projection(self, vit_output):                                             # :436-450
+        return self.vision_projection(self.pre_proj_layernorm(vit_output))
+
+    def forward_downsample(self, vit_output):                                             # :452-470
+        if self.add_class_token:
+            vit_output = vit_output[:, 1:, :]
+        if self.vision_downsample_ratio != 1:
+            h = w = int(vit_output.shape[1] ** 0.5)
+            vit_output = vit_output.reshape(vit_output.shape[0], h, w, -1)
+            vit_output = self.pixel_shuffle(vit_output, scale_factor=self.vision_downsample_ratio)
+            vit_output = vit_output.reshape(vit_output.shape[0], -1, vit_output.shape[-1])
+        return vit_output
+
+    def forward_once(self, images, attention_mask):                                       # :485-520
+        from contextlib import nullcontext
+        tp = sys.modules["megatron.core.tensor_parallel"]
+        with (torch.no_grad() if self.vision_model_freeze else nullcontext()):
+            vit_output = self.vit(images, attention_mask)
+            vit_output = tp.checkpoint(self.forward_downsample, False, vit_output) if self.vision_model_recompute else \
+                self.forward_downsample(vit_output)
+        with (torch.no_grad() if self.vision_projector_freeze else nullcontext()):
+            if self.vision_projector_recompute:
+                return tp.checkpoint(self.forward_projection, False, vit_output)
+            return self.forward_projection(vit_output)
+
+    def forward_chunk(self, images, attention_mask):                                      # :522-533
+        return torch.cat([self.forward_once(c, attention_mask) for c in torch.split(images, 256, dim=0)], dim=0)
+
+    def forward(self, **kw_args):                                                         # :535-570 (no vision context parallelism)
+        return self.forward_chunk(kw_args["images"], None)
+
+    def pixel_shuffle(self, x, scale_factor=0.5):                                         # :572-582
+        n, w, h, c = x.size()
+        x = x.view(n, w, int(h * scale_factor), int(c / scale_factor))
+        x = x.permute(0, 2, 1, 3).contiguous()
+        x = x.view(n, int(h * scale_factor), int(w * scale_factor), int(c / (scale_factor * scale_factor)))
+        return x.permute(0, 2, 1, 3).contiguous()
+
+
+def _vocab_parallel_cross_entropy_placeholder(vocab_parallel_logits, target, label_smoothing=0.0):
+    raise AssertionError("Megatron's vocab-parallel cross entropy must not run: the adaptor registers the library's on this name")
+
+
 _STUBS = {
+    "megatron.core.transformer.custom_layers.transformer_engine": dict(TENorm=_TENormPlaceholder),
+    "megatron.core.transformer.transformer_block": dict(TransformerBlock=TransformerBlock, TENorm=_TENormPlaceholder),
+    "megatron.core.tensor_parallel": dict(checkpoint=checkpoint, vocab_parallel_cross_entropy=_vocab_parallel_cross_entropy_placeholder),
+    "megatron.core.tensor_parallel.cross_entropy": dict(vocab_parallel_cross_entropy=_vocab_parallel_cross_entropy_placeholder),
+    "long_vita_megatron.core.models.multimodal.gpt_vl_model": dict(GPTVLModel=GPTVLModel),
     "megatron.core.transformer.spec_utils": dict(ModuleSpec=ModuleSpec, build_module=build_module),
     "megatron.core.transformer.enums": dict(AttnMaskType=AttnMaskType),
     "megatron.core.transformer.identity_op": dict(IdentityOp=IdentityOp, IdentityFuncOp=IdentityFuncOp),
@@ -261,7 +467,9 @@ def install():
     for full in list(_STUBS) + ["megatron.core.models.gpt.gpt_layer_specs", "megatron.core.models.common.embeddings.rotary_pos_embedding",
                                 "megatron.core.models.common.embeddings.language_model_embedding", "megatron.core.tensor_parallel.layers",
                                 "megatron.core.transformer.dot_product_attention", "megatron.core.parallel_state",
-                                "long_vita_megatron.core.models.vision.vit_layer_specs"]:
+                                "long_vita_megatron.core.models.vision.vit_layer_specs", "long_vita_megatron.core.models.vision.intern_vit_model",
+                                "long_vita_megatron.core.models.vision.siglip_vit_model",
+                                "long_vita_megatron.core.models.vision.multimodal_projector"]:
         parts = full.split(".")
         for i in range(1, len(parts) + 1):
             names.add(".".join(parts[:i]))

@@ -350,7 +350,7 @@ def test_vit_layer_built_by_megatron_matches_the_oracle_forward_and_backward(meg
     (bf16 rounding chain; pinned to the reference's HF InternVisionModel by hf_vit.pt); the no-grad call takes the fused-epilogue path."""
     from oracle import vit as ovit
     vls = sys.modules["long_vita_megatron.core.models.vision.vit_layer_specs"]
-    vcfg = ovit.ViTConfig(num_layers=1)
+    vcfg = ovit.ViTConfig(num_layers=1, unfused_bias=spec == "local")        # local spec: Megatron MLP adds fc1's bias unfused (:213)
     vp = ovit.init_vit_params(vcfg, seed=61)
     gen = torch.Generator().manual_seed(62)
     lp = {k: v.clone() for k, v in vp["layers"][0].items()}
@@ -458,3 +458,215 @@ def test_siglip_layer_built_by_megatron_at_its_real_sizes(megatron):
     with torch.no_grad():
         out2, _ = layer(x.transpose(0, 1).contiguous().to(DEV), attention_mask=None)
     tol("no-grad path vs autograd path", rel_l2(out2, out), 1e-5)                    # measured 0: the same rounding chain
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# r04 — the rest of the path under the reference's entry classes (VERDICT r3 "missing" 1): ViT front end, downsample + projector,
+# final norm, loss; activation recompute re-entering the autograd Functions
+# ---------------------------------------------------------------------------------------------------------------------------------
+def _vision_model(ovit, vcfg, vp, args_over=None, vit_grad=True):
+    """MegatronVisionModel (the entry script's class: tests/dummy_megatron.py restates it in plain torch) constructed through the
+    PATCHED names — InternViTModel, the ViT layer spec, MultimodalProjector — inside a GPTVLModel whose __init__ the adaptor wrapped."""
+    import types
+    H = vcfg.hidden
+    vit_cfg = dm.TransformerConfig(num_layers=vcfg.num_layers, hidden_size=H, num_attention_heads=vcfg.heads, num_query_groups=vcfg.heads,
+                                   kv_channels=vcfg.head_dim, ffn_hidden_size=vcfg.ffn, normalization="LayerNorm",
+                                   layernorm_epsilon=vcfg.ln_eps, add_bias_linear=True, add_qkv_bias=True, gated_linear_unit=False,
+                                   activation_func=torch.nn.functional.gelu)
+    proj_cfg = dm.TransformerConfig(hidden_size=vcfg.llm_hidden, ffn_hidden_size=H, add_bias_linear=False, gated_linear_unit=False,
+                                    activation_func=torch.nn.functional.gelu)              # M/pretrain_long_vita.py:397-410
+    a = dict(vision_seq_length=vcfg.seq, image_token_length=256, vision_model_type="intern_300m", vision_context_parallel=False,
+             vision_downsample_ratio=0.5, vision_downsample_stride=1, add_class_token=True, vision_model_freeze=not vit_grad,
+             vision_projector_freeze=False, vision_model_recompute=False, vision_projector_recompute=False, patch_dim=14,
+             image_size=vcfg.image, vision_projector_pre_norm=True)
+    a.update(args_over or {})
+    args = types.SimpleNamespace(**a)
+    gpt_cls = sys.modules["long_vita_megatron.core.models.multimodal.gpt_vl_model"].GPTVLModel
+    model = gpt_cls(proj_cfg, external_feature_model_provider=lambda cfg: dm.MegatronVisionModel(args, vit_cfg, proj_cfg).to(DEV).bfloat16())   # Float16Module
+    efm = model.external_feature_model
+    sd = {"vit.conv1.weight": vp["conv_w"], "vit.conv1.bias": vp["conv_b"], "vit.class_token": vp["cls"],
+          "vit.position_embeddings.weight": vp["pos"], "pre_proj_layernorm.weight": vp["proj_ln_w"],
+          "pre_proj_layernorm.bias": vp["proj_ln_b"], "vision_projection.encoder.linear_fc1.weight": vp["proj_fc1"],
+          "vision_projection.encoder.linear_fc2.weight": vp["proj_fc2"]}
+    lnames = {"ln1_w": "input_layernorm.weight", "ln1_b": "input_layernorm.bias", "qkv_w": "self_attention.linear_qkv.weight",
+              "qkv_b": "self_attention.linear_qkv.bias", "proj_w": "self_attention.linear_proj.weight",
+              "proj_b": "self_attention.linear_proj.bias", "ls1": "ls1", "ln2_w": "pre_mlp_layernorm.weight",
+              "ln2_b": "pre_mlp_layernorm.bias", "fc1_w": "mlp.linear_fc1.weight", "fc1_b": "mlp.linear_fc1.bias",
+              "fc2_w": "mlp.linear_fc2.weight", "fc2_b": "mlp.linear_fc2.bias", "ls2": "ls2"}
+    for i, lp in enumerate(vp["layers"]):
+        for k, nme in lnames.items():
+            sd[f"vit.decoder.layers.{i}.{nme}"] = lp[k]
+    assert set(sd) == {k for k, _ in efm.named_parameters()}, sorted(set(sd) ^ {k for k, _ in efm.named_parameters()})
+    efm.load_state_dict({k: v.to(DEV) for k, v in sd.items()})                        # the reference's checkpoint names
+    if not vit_grad:
+        for k, q in efm.named_parameters():
+            if k.startswith("vit."):
+                q.requires_grad = False                                               # GPTVLModel.vision_model_freeze (:186-195)
+    return efm, sd
+
+
+def _randomised_vit_params(ovit, vcfg, seed):
+    vp = ovit.init_vit_params(vcfg, seed=seed)
+    gen = torch.Generator().manual_seed(seed + 1)
+    for lp in vp["layers"]:
+        for k in ("ln1_w", "ln2_w"):
+            lp[k] = (1 + 0.1 * torch.randn(lp[k].shape, generator=gen)).bfloat16()
+        for k in ("ln1_b", "ln2_b"):
+            lp[k] = (0.1 * torch.randn(lp[k].shape, generator=gen)).bfloat16()
+    vp["proj_ln_w"] = (1 + 0.1 * torch.randn(vp["proj_ln_w"].shape, generator=gen)).bfloat16()
+    vp["proj_ln_b"] = (0.1 * torch.randn(vp["proj_ln_b"].shape, generator=gen)).bfloat16()
+    vp["cls"] = (0.5 * torch.randn(vp["cls"].shape, generator=gen)).bfloat16()
+    return vp
+
+
+@pytest.mark.parametrize("mode", ["stage2_vit_trains_projector_recompute", "stage3_vit_frozen"])
+def test_vision_tower_under_the_reference_entry_classes_forward_and_every_gradient(megatron, mode):
+    """`external_feature_model(images=...)` as GPTVLModel.forward calls it (gpt_vl_model.py:285-300): MegatronVisionModel ->
+    InternViTModel (conv1 + class token + position embedding + 2 layers through TransformerBlock) -> drop class token + pixel shuffle +
+    LayerNorm(4096) -> MultimodalProjector, every class obtained from the dotted name the reference imports it from after the adaptor
+    ran.  The torch pieces the reference would run (torch.nn.LayerNorm.forward, the torch pixel_shuffle, Conv2d.forward) are made to
+    raise: the library must have displaced them.  Output and EVERY parameter gradient (conv weight / bias, class token, position
+    table, 2 x 14 layer parameters, pre-norm weight / bias, both projector weights) vs torch autograd over oracle.vit.vision_model
+    (the bf16 chain; pinned on the reference's HF InternVisionModel + ResamplerProjector by hf_vit.pt)."""
+    from oracle import vit as ovit
+    stage2 = mode.startswith("stage2")
+    vcfg = ovit.ViTConfig(num_layers=2, llm_hidden=1024, unfused_bias=True)            # Megatron MLP: bias_activation_fusion off (:213)
+    vp = _randomised_vit_params(ovit, vcfg, seed=81)
+    gen = torch.Generator().manual_seed(83)
+    n = 3
+    images = torch.randn(n, 3, vcfg.image, vcfg.image, generator=gen).bfloat16()
+    go = torch.randn(n, 256, vcfg.llm_hidden, generator=gen).bfloat16()
+    vpo = {k: (v.clone().requires_grad_(True) if torch.is_tensor(v) else [{kk: vv.clone().requires_grad_(True) for kk, vv in lp.items()} for lp in v])
+           for k, v in vp.items()}
+    ref = ovit.vision_model(images, vpo, vcfg)
+    ref.backward(go)
+
+    # stage 2 trains the encoder (its output carries a graph, so tensor_parallel.checkpoint around downsample + projection has an input that
+    # requires grad); stage 3 / 4 freeze it (`--vision-model-freeze`, stage3 .sh:203) and run the projector without recompute
+    efm, sd = _vision_model(ovit, vcfg, vp, dict(vision_projector_recompute=stage2), vit_grad=stage2)
+    assert getattr(efm, "_vita_hip_installed", False) and type(efm.vit).__module__ == "long_vita_amd.vision_modules"
+    assert type(efm.vision_projection).__module__ == "long_vita_amd.vision_modules"
+
+    def boom(*a, **k):
+        raise AssertionError("a torch op of the reference's vision path ran")
+    efm.pre_proj_layernorm.forward = boom
+    efm.pixel_shuffle = boom
+    efm.vit.conv1.forward = boom
+    efm.vit.position_embeddings.forward = boom
+    efm.train()
+    out = efm(images=images.to(DEV))
+    assert out.shape == (n, 256, vcfg.llm_hidden) and out.dtype == torch.bfloat16
+    tol("forward", rel_l2(out, ref), 9.0e-3)
+    out.backward(go.to(DEV))
+    flat = {"vit.conv1.weight": vpo["conv_w"], "vit.conv1.bias": vpo["conv_b"], "vit.class_token": vpo["cls"],
+            "vit.position_embeddings.weight": vpo["pos"], "pre_proj_layernorm.weight": vpo["proj_ln_w"],
+            "pre_proj_layernorm.bias": vpo["proj_ln_b"], "vision_projection.encoder.linear_fc1.weight": vpo["proj_fc1"],
+            "vision_projection.encoder.linear_fc2.weight": vpo["proj_fc2"]}
+    okeys = {"input_layernorm.weight": "ln1_w", "input_layernorm.bias": "ln1_b", "self_attention.linear_qkv.weight": "qkv_w",
+             "self_attention.linear_qkv.bias": "qkv_b", "self_attention.linear_proj.weight": "proj_w",
+             "self_attention.linear_proj.bias": "proj_b", "ls1": "ls1", "pre_mlp_layernorm.weight": "ln2_w",
+             "pre_mlp_layernorm.bias": "ln2_b", "mlp.linear_fc1.weight": "fc1_w", "mlp.linear_fc1.bias": "fc1_b",
+             "mlp.linear_fc2.weight": "fc2_w", "mlp.linear_fc2.bias": "fc2_b", "ls2": "ls2"}
+    errs = {}
+    for name, q in efm.named_parameters():
+        if name.startswith("vit.") and not stage2:
+            assert q.grad is None, name                                                # frozen encoder: nothing reaches it
+            continue
+        if name in flat:
+            want = flat[name].grad
+        else:
+            _, _, _, li, rest = name.split(".", 4)
+            want = vpo["layers"][int(li)][okeys[rest]].grad
+        assert q.grad is not None, name
+        errs[name] = rel_l2(q.grad, want)
+    _record("vision_tower_" + mode, dict(errs, out=rel_l2(out, ref)))
+    assert len(errs) == (36 if stage2 else 4)
+    tol("worst gradient", max(errs.values()), 2.0e-2)
+    with torch.no_grad():                                                              # inference: the fused epilogues, no autograd nodes
+        efm.eval()
+        out2 = efm(images=images.to(DEV))
+    tol("no-grad path vs autograd path", rel_l2(out2, out), 2e-3)
+
+
+def test_transformer_block_final_norm_recompute_and_loss_run_on_the_library(megatron):
+    """(1) `TransformerBlock(config, spec, post_process=True)` builds `final_layernorm` from the module-level name TENorm
+    (M/core/transformer/transformer_block.py:201): after the adaptor that name is layers.Norm -> RMSNorm with library forward / backward.
+    (2) `--recompute-granularity full --recompute-method block --recompute-num-layers 1`: Megatron's tensor_parallel.checkpoint re-enters
+    this package's autograd Functions in the backward (forward under no_grad, re-run with grad) — outputs and every gradient must
+    equal the run without recompute BIT FOR BIT (same kernels, same order).
+    (3) `tensor_parallel.vocab_parallel_cross_entropy(logits.float(), labels)` (compute_language_model_loss, gpt_vl_model.py:414):
+    loss and d logits vs torch's cross entropy in fp32."""
+    from long_vita_amd import layers
+    tb_mod = sys.modules["megatron.core.transformer.transformer_block"]
+    S = 512
+    def build(recompute):
+        mcfg = dm.TransformerConfig(num_layers=2, hidden_size=CFG["hidden"], num_attention_heads=CFG["heads"],
+                                    num_query_groups=CFG["kv_groups"], kv_channels=CFG["head_dim"], ffn_hidden_size=CFG["ffn"],
+                                    recompute_granularity="full" if recompute else None, recompute_method="block" if recompute else None,
+                                    recompute_num_layers=1 if recompute else None)
+        torch.manual_seed(7)
+        blk = tb_mod.TransformerBlock(mcfg, megatron.get_gpt_layer_with_transformer_engine_spec(), post_process=True)
+        return blk
+    ref_blk = build(False)
+    assert isinstance(ref_blk.final_layernorm, layers.RMSNorm)
+    blk = build(True)
+    blk.load_state_dict(ref_blk.state_dict())
+    with torch.no_grad():
+        ref_blk.final_layernorm.weight.copy_(1 + 0.1 * torch.randn(CFG["hidden"], generator=torch.Generator().manual_seed(3)).to(DEV))
+        blk.final_layernorm.weight.copy_(ref_blk.final_layernorm.weight)
+    g = torch.Generator().manual_seed(91)
+    x = (torch.randn(S, 1, CFG["hidden"], generator=g) * 0.5).bfloat16().to(DEV)
+    go = torch.randn(S, 1, CFG["hidden"], generator=g).bfloat16().to(DEV)
+    freqs = glue.rope_emb(S, glue.rope_inv_freq(CFG["head_dim"], 1e6)).to(DEV)
+    outs = []
+    for b_ in (ref_blk, blk):
+        b_.train()
+        xi = x.clone().requires_grad_(True)
+        o = b_(xi, attention_mask=None, rotary_pos_emb=freqs)
+        o.backward(go)
+        outs.append((o.detach(), xi.grad, {k: v.grad for k, v in b_.named_parameters()}))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for k in outs[0][2]:
+        assert outs[1][2][k] is not None and torch.equal(outs[0][2][k], outs[1][2][k]), k
+    # the final norm against the oracle restatement of RMSNorm on the layer stack's output
+    with torch.no_grad():
+        pre = ref_blk.final_layernorm
+        h = x.clone()
+        for layer in ref_blk.layers:
+            h, _ = layer(h, attention_mask=None, rotary_pos_emb=freqs)
+        want = glue.rmsnorm(h.cpu(), pre.weight.cpu(), 1e-6)
+    tol("final_layernorm vs oracle RMSNorm", rel_l2(outs[0][0], want), 3e-3)
+
+    # ---- loss ----------------------------------------------------------------------------------------------------------------------
+    tpm = sys.modules["megatron.core.tensor_parallel"]
+    n, V = 37, 1536
+    logits = (torch.randn(n, 1, V, generator=g) * 3).bfloat16()
+    labels = torch.randint(0, V, (n, 1), generator=g)
+    gl = torch.rand(n, 1, generator=g)
+    lo = logits.float().clone().requires_grad_(True)
+    want = torch.nn.functional.cross_entropy(lo.view(n, V), labels.view(n), reduction="none").view(n, 1)
+    (want * gl).sum().backward()
+    lh = logits.to(DEV).requires_grad_(True)
+    loss = tpm.vocab_parallel_cross_entropy(lh.float(), labels.to(DEV))                # as compute_language_model_loss calls it
+    assert loss.shape == (n, 1) and loss.dtype == torch.float32
+    (loss * gl.to(DEV)).sum().backward()
+    tol("loss", rel_l2(loss, want), 1e-5)
+    tol("d logits", rel_l2(lh.grad, lo.grad), 3e-3)                                    # bf16 leaf: the fp32 gradient is rounded once
+    with pytest.raises(IndexError):
+        tpm.vocab_parallel_cross_entropy(lh.float(), torch.full((n, 1), V, dtype=torch.int64, device=DEV))
+
+
+def test_output_layer_with_a_logit_mask_that_selects_nothing(megatron):
+    """under CP the answer tokens of a 128K row all sit on CP rank 0 — every other rank's `logit_mask` is all
+    False.  ColumnParallelLinear(output_layer).forward must return an empty [0, b, V] tensor (the reference's masked_select does), and
+    its backward zero parameter gradients and a zero input gradient of the full [s, b, c] shape."""
+    cpl_cls = sys.modules["megatron.core.tensor_parallel.layers"].ColumnParallelLinear
+    cfg = dm.TransformerConfig(hidden_size=256)
+    lin = cpl_cls(256, 512, config=cfg, init_method=cfg.init_method, bias=True, skip_bias_add=False)
+    x = torch.randn(64, 1, 256, device=DEV).bfloat16().requires_grad_(True)
+    mask = torch.zeros(1, 64, dtype=torch.bool, device=DEV)
+    out, _ = lin(x, logit_mask=mask)
+    assert out.shape == (0, 1, 512)
+    out.sum().backward()
+    assert x.grad.shape == x.shape and float(x.grad.abs().sum()) == 0.0
+    assert float(lin.weight.grad.abs().sum()) == 0.0 and float(lin.bias.grad.abs().sum()) == 0.0

@@ -1032,7 +1032,9 @@ def test_vit_layer_specs_construct_on_cpu_with_the_references_parameter_names():
         for builder, fused in ((vls.get_vit_layer_local_spec_for_intern, False), (vls.get_vit_layer_with_transformer_engine_spec_for_intern, True)):
             lyr = dm.build_module(builder(), config=icfg, layer_number=1)
             assert type(lyr).__name__ == "InternViTTransformerLayer" and isinstance(lyr.self_attention.core_attention, HipDotProductAttention)
-            assert isinstance(lyr.mlp, layers.ViTMLP) and not lyr.mlp.tanh and not lyr.mlp.unfused_bias
+            # local spec = Megatron's MLP with bias_activation_fusion off (M/pretrain_long_vita.py:213): fc1's bias meets the ROUNDED product;
+            # TE spec = the bias inside the GEMM
+            assert isinstance(lyr.mlp, layers.ViTMLP) and not lyr.mlp.tanh and lyr.mlp.unfused_bias == (not fused)
             keys = {k for k, _ in lyr.named_parameters()}
             assert {"ls1", "ls2", "mlp.linear_fc1.weight", "mlp.linear_fc2.bias", "self_attention.linear_proj.bias"} <= keys
             assert ("self_attention.linear_qkv.layer_norm_weight" in keys) == fused and ("input_layernorm.weight" in keys) == (not fused)
