@@ -192,11 +192,11 @@ def row_scatter_(dst: torch.Tensor, dst_idx: torch.Tensor, src: torch.Tensor,
     if src_idx is not None:
         src_idx = src_idx.reshape(-1).contiguous()
     n = dst_idx.numel()
+    if n == 0:                                  # nothing selected (an all-False logit mask on this rank): dst as it is
+        return dst
     cols = dst.numel() // max(dst.shape[0], 1)
     if src.numel() // max(src.shape[0], 1) != cols or src.dtype != dst.dtype:
         raise ValueError("row width / dtype mismatch")
-    if n == 0:
-        return dst
     flag = _err_flag(dst.device) if check_bounds else None
     _L.check(_L.load().vita_row_scatter(_dev(src, "src"), src.shape[0], _opt(src_idx, "src_idx", torch.int64),
                                         _dev(dst, "dst"), dst.shape[0], _dev(dst_idx, "dst_idx", torch.int64), n, cols,

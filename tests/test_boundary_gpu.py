@@ -556,7 +556,7 @@ def test_vision_tower_under_the_reference_entry_classes_forward_and_every_gradie
     efm.train()
     out = efm(images=images.to(DEV))
     assert out.shape == (n, 256, vcfg.llm_hidden) and out.dtype == torch.bfloat16
-    tol("forward", rel_l2(out, ref), 9.0e-3)
+    tol("forward", rel_l2(out, ref), 4.9e-3)                                         # measured 3.2e-3
     out.backward(go.to(DEV))
     flat = {"vit.conv1.weight": vpo["conv_w"], "vit.conv1.bias": vpo["conv_b"], "vit.class_token": vpo["cls"],
             "vit.position_embeddings.weight": vpo["pos"], "pre_proj_layernorm.weight": vpo["proj_ln_w"],
@@ -581,11 +581,11 @@ def test_vision_tower_under_the_reference_entry_classes_forward_and_every_gradie
         errs[name] = rel_l2(q.grad, want)
     _record("vision_tower_" + mode, dict(errs, out=rel_l2(out, ref)))
     assert len(errs) == (36 if stage2 else 4)
-    tol("worst gradient", max(errs.values()), 2.0e-2)
+    tol("worst gradient", max(errs.values()), 9.8e-3 if stage2 else 5.6e-3)              # measured 6.5e-3 (class token) / 3.7e-3
     with torch.no_grad():                                                              # inference: the fused epilogues, no autograd nodes
         efm.eval()
         out2 = efm(images=images.to(DEV))
-    tol("no-grad path vs autograd path", rel_l2(out2, out), 2e-3)
+    tol("no-grad path vs autograd path", rel_l2(out2, out), 1e-5)                      # measured 0: the same rounding chain
 
 
 def test_transformer_block_final_norm_recompute_and_loss_run_on_the_library(megatron):
@@ -635,7 +635,7 @@ def test_transformer_block_final_norm_recompute_and_loss_run_on_the_library(mega
         for layer in ref_blk.layers:
             h, _ = layer(h, attention_mask=None, rotary_pos_emb=freqs)
         want = glue.rmsnorm(h.cpu(), pre.weight.cpu(), 1e-6)
-    tol("final_layernorm vs oracle RMSNorm", rel_l2(outs[0][0], want), 3e-3)
+    tol("final_layernorm vs oracle RMSNorm", rel_l2(outs[0][0], want), 1e-4)          # measured 0
 
     # ---- loss ----------------------------------------------------------------------------------------------------------------------
     tpm = sys.modules["megatron.core.tensor_parallel"]
@@ -651,7 +651,7 @@ def test_transformer_block_final_norm_recompute_and_loss_run_on_the_library(mega
     assert loss.shape == (n, 1) and loss.dtype == torch.float32
     (loss * gl.to(DEV)).sum().backward()
     tol("loss", rel_l2(loss, want), 1e-5)
-    tol("d logits", rel_l2(lh.grad, lo.grad), 3e-3)                                    # bf16 leaf: the fp32 gradient is rounded once
+    tol("d logits", rel_l2(lh.grad, lo.grad), 2.2e-3)                                    # bf16 leaf: the fp32 gradient is rounded once
     with pytest.raises(IndexError):
         tpm.vocab_parallel_cross_entropy(lh.float(), torch.full((n, 1), V, dtype=torch.int64, device=DEV))
 
