@@ -11,11 +11,17 @@ M/inference/text_generation/generation.py:123-205).  Context parallelism CP = N 
 total work fixed as N grows ("strong" scaling).  Synthetic data, seeded random bf16 weights of
 the real architecture; inputs are resident in HBM before the timed region.
 
-Prints ONE JSON line on rank 0 (contract in the task statement) with two extra objects:
+Prints ONE JSON line on rank 0 (contract in the task statement) with these extra objects:
   roofline      dominant kernel = flash-attention forward: algorithmic FLOPs per launch
                 (4*d*heads*visible (q,k) pairs on this rank) / mean launch time measured live with
                 HIP events on the launch stream, against the 2.5 PFLOP/s dense bf16 MFMA peak;
-  cpu_baseline  the CPU oracle ("port") timed on this host: a bounded sample of the same decoder.
+  cpu_baseline  the CPU oracle ("port") timed on this host: a bounded sample of the same decoder (rank 0, every N);
+  comm          (r04) what the exchange did, so that an N > 1 run can be read without a profiler: the communicator's backend and
+                rank count, K / V all-gather messages and bytes per layer, the time the attention's stream actually WAITED for a
+                gather (HIP events around every wait, mean per layer / total per prefill), the same all-gather timed alone after the
+                timed region (ms, GB/s received per rank), the logits gather;
+  cross_rank_check (N > 1) after the timed region: the logits of the 2 N positions the ranks marked (two per rank, sync_output's
+                rows) against the SAME prefill run by rank 0 alone at CP = 1 — rel-L2, max-abs, argmax agreement.
 """
 from __future__ import annotations
 
@@ -133,6 +139,83 @@ def cpu_baseline(seq: int, frames: int, fpt_workload: float):
             "hf_transformers_qwen2": hf}
 
 
+def comm_report(world: int, steps: int, cfg, seq: int, comm_log, dev, selftest: bool = False):
+    """The `comm` object of the line (module docstring).  Collective on every rank (the isolated all-gather is one).
+    selftest: `--dry-run` under torch.distributed.run with ONE rank walks the N > 1 code (a world of one) so that it has run somewhere
+    before the driver's multi-GPU node runs it."""
+    from long_vita_amd import ops, parallel_state as mpu
+    if world == 1 and not selftest:
+        return {"backend": None, "ranks": 1, "kv_messages_per_layer": 0, "kv_bytes_sent_per_layer_per_rank": 0,
+                "exposed_wait_ms_per_layer": 0.0, "exposed_wait_ms_per_prefill": 0.0,
+                "note": "one rank: no exchange on the path (the forced-CP parity pass runs outside the timed region)"}
+    group = mpu.get_context_parallel_group()
+    s_l = seq // world
+    n_msg = ops.cp_kv_split(cfg.kv_groups, cfg.heads, s_l)
+    waits = [e["wait"][0].elapsed_time(e["wait"][1]) for e in comm_log]
+    sent = sum(e["bytes"] for e in comm_log)
+    layers = max(cfg.num_layers * steps, 1)
+    msg_bytes = 2 * s_l * (cfg.kv_groups // n_msg) * cfg.head_dim * 2
+    # the same message timed alone: blocking all-gathers bracketed by HIP events on the stream they are ordered on
+    send = torch.empty(msg_bytes // 2, dtype=torch.bfloat16, device=dev).normal_()
+    recv = torch.empty(world * send.numel(), dtype=torch.bfloat16, device=dev)
+    for _ in range(2):
+        dist.all_gather_into_tensor(recv, send, group=group)
+    torch.cuda.synchronize()
+    reps = 10
+    a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    a.record()
+    for _ in range(reps):
+        dist.all_gather_into_tensor(recv, send, group=group)
+    b.record()
+    torch.cuda.synchronize()
+    iso_ms = a.elapsed_time(b) / reps
+    t = torch.tensor([iso_ms, sum(waits)], dtype=torch.float64, device=dev)
+    dist.all_reduce(t, op=dist.ReduceOp.MAX, group=group)
+    iso_max, wait_max = float(t[0]), float(t[1])
+    return {"backend": dist.get_backend(group), "ranks": dist.get_world_size(group), "kv_messages_per_layer": n_msg,
+            "kv_message_bytes": msg_bytes, "kv_bytes_sent_per_layer_per_rank": sent / layers,
+            "kv_bytes_received_per_layer_per_rank": (world - 1) * sent / layers,
+            "gathers_logged_rank0": len(comm_log),
+            "exposed_wait_ms_per_layer": sum(waits) / layers, "exposed_wait_ms_per_prefill": sum(waits) / max(steps, 1),
+            "exposed_wait_ms_per_prefill_max_over_ranks": wait_max / max(steps, 1),
+            "isolated_all_gather_ms": iso_ms, "isolated_all_gather_ms_max_over_ranks": iso_max,
+            "isolated_all_gather_gbps_received_per_rank": (world - 1) * msg_bytes / (iso_ms * 1e-3) / 1e9,
+            "how": "exposed wait = HIP events around each point where an attention stream waits for its K / V gather (rank 0); isolated = "
+                   f"{reps} blocking all_gather_into_tensor calls of one message, HIP events on the current stream, after the timed region"}
+
+
+def cross_rank_check(model, tokens, seq, ext, world, rank):
+    """N > 1, outside the timed region: the CP = N prefill's logits at the 2 N marked positions (row j of sync_output = global position
+    j * S / (2 N) + (S - 1) % (S / (2 N)) at context_length = S) against the same prefill run by rank 0 ALONE at CP = 1 on the same
+    inputs (the other ranks wait at a barrier)."""
+    from long_vita_amd import generation, parallel_state as mpu
+    position_ids = torch.arange(seq, dtype=torch.long, device=tokens.device).unsqueeze(0)
+    t2, p2, e2 = generation.get_batch_on_this_cp_rank(tokens, position_ids, ext)
+    mask, _ = generation.build_logit_mask(t2, seq, False)
+    rows = generation.sync_output(model(t2, p2, None, external_inputs=e2, logit_mask=mask))          # [1, 2 N, V]
+    half = seq // (2 * world)
+    pos = [j * half + (seq - 1) % half for j in range(2 * world)]
+    res = None
+    if rank == 0:
+        state = (mpu.get_context_parallel_world_size(), mpu.get_context_parallel_rank(), mpu.get_context_parallel_group())
+        try:
+            mpu.set_context_parallel_state(1, 0, None)
+            m1 = torch.zeros(1, seq, dtype=torch.bool, device=tokens.device)
+            m1[0, pos] = True
+            alone = model(tokens, position_ids, None, external_inputs=ext, logit_mask=m1)             # [1, 2 N, V]
+            a, b = rows.float(), alone.float()
+            res = {"what": f"logits at the {2 * world} marked positions: CP = {world} vs the same prefill on rank 0 alone (CP = 1)",
+                   "positions": pos, "rel_l2": float((a - b).norm() / b.norm()), "max_abs": float((a - b).abs().max()),
+                   "argmax_equal": int((a.argmax(-1) == b.argmax(-1)).sum()), "rows": 2 * world}
+        except Exception as e:  # noqa: BLE001 — the other ranks are waiting at the barrier below
+            res = {"error": f"{type(e).__name__}: {e}"}
+        finally:
+            mpu.set_context_parallel_state(*state)
+    model._ws = {}
+    dist.barrier()
+    return res
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -183,6 +266,8 @@ def main():
     for _ in range(args.warmup):
         step()
     model.attn_events = []
+    if world > 1:
+        model.core_attention.comm_log = []
     fence()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -194,6 +279,19 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
     assert torch.isfinite(out.float()).all()
+    comm_log = model.core_attention.comm_log or []
+    model.core_attention.comm_log = None
+    # diagnostics of the exchange: never allowed to cost the measured line (every rank takes the same path through the collectives)
+    try:
+        comm = comm_report(world, args.steps, cfg, seq, comm_log, dev, selftest=args.dry_run and dist.is_initialized())
+    except Exception as e:  # noqa: BLE001
+        comm = {"error": f"{type(e).__name__}: {e}"}
+    cross = None
+    if world > 1 and not args.no_parity_check:
+        try:
+            cross = cross_rank_check(model, tokens, seq, ext, world, rank)
+        except Exception as e:  # noqa: BLE001
+            cross = {"error": f"{type(e).__name__}: {e}"}
 
     # once, outside the timed region (N = 1): the same prefill through the context-parallel code path (K/V pack, all-gather
     # messages, zig-zag chunk tables, logits gather) must give the plain path's logits
@@ -253,8 +351,11 @@ def main():
     }
     if parity is not None:
         line["parity_check"] = parity
+    line["comm"] = comm
+    if cross is not None:
+        line["cross_rank_check"] = cross
     if rank == 0:
-        if world == 1 and not args.no_cpu_baseline:
+        if not args.no_cpu_baseline:
             try:
                 line["cpu_baseline"] = cpu_baseline(seq, frames, fpt)
             except Exception as e:  # noqa: BLE001 — a reported baseline must not cost the measured line

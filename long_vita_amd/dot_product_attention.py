@@ -97,6 +97,22 @@ class DotProductAttention:
         self.local_first = bool(int(os.environ.get("VITA_CP_LOCAL_FIRST", "1")))
         self._streams = []
         self.split_streams = bool(int(os.environ.get("VITA_CP_STREAMS", "1")))
+        # bench.py (N > 1): a list that receives, per K / V gather, {"bytes": message bytes this rank SENT, "wait": (event, event)} — the two
+        # HIP events bracket the point where the attention's stream waits for the gather, so their distance is the time the compute
+        # stream actually idled for the exchange (0 when the gather had landed under the previous launch)
+        self.comm_log = None
+
+    def _wait_gather(self, work, nbytes: int):
+        if work is None:
+            return
+        if self.comm_log is None:
+            work.wait()
+            return
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        work.wait()
+        e1.record()
+        self.comm_log.append({"bytes": nbytes, "wait": (e0, e1)})
 
     # -- Megatron calling convention: [s, b, heads, d] ---------------------------------------------
     def forward(self, query, key, value, attention_mask=None, attn_mask_type=None, packed_seq_params=None):
@@ -189,8 +205,7 @@ class DotProductAttention:
                     _, lse_a = ops.flash_attn(qj, kv_local[0, 0].unsqueeze(0), kv_local[0, 1].unsqueeze(0), causal=True,
                                               softmax_scale=self.softmax_scale, chunk_len=c, q_chunk_gid=own, kv_chunk_gid=own,
                                               kv_chunk_row=[0, c], out=oj, return_lse=True, lse_out=lj)
-                    if works[j] is not None:
-                        works[j].wait()
+                    self._wait_gather(works[j], kv_local[j].numel() * kv_local.element_size())
                     rem = [i for i in range(2 * cp) if i // 2 != r]
                     o_b = self._remote_buffer(oj)
                     _, lse_b = ops.flash_attn(qj, rows.unsqueeze(0), rows[s_l:].unsqueeze(0), causal=True,
@@ -199,8 +214,7 @@ class DotProductAttention:
                                               return_lse=True)
                     ops.attn_merge_(oj, lse_a, o_b, lse_b)
                 else:
-                    if works[j] is not None:
-                        works[j].wait()                             # this stream waits for gather j only
+                    self._wait_gather(works[j], kv_local[j].numel() * kv_local.element_size())     # this stream waits for gather j only
                     ops.flash_attn(qj, rows.unsqueeze(0), rows[s_l:].unsqueeze(0), causal=True, softmax_scale=self.softmax_scale,
                                    chunk_len=c, q_chunk_gid=own, kv_chunk_gid=kv_gid, kv_chunk_row=kv_row, out=oj, lse_out=lj)
                 if stream is not main:

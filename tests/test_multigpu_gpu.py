@@ -123,3 +123,7 @@ def test_bench_dry_run_goes_through_the_distributed_plumbing():
     import json
     line = json.loads([ln for ln in r.stdout.splitlines() if ln.startswith("{")][-1])
     assert line["n_gpus"] == 1 and line["value"] > 0 and line["config"]["dry_run"] is True
+    # r04: the `comm` object of an N > 1 line, walked here on a world of ONE real RCCL rank (selftest): communicator facts + the isolated all-gather
+    comm = line["comm"]
+    assert "error" not in comm, comm
+    assert comm["ranks"] == 1 and comm["backend"] == "nccl" and comm["isolated_all_gather_ms"] > 0 and comm["kv_messages_per_layer"] >= 1
