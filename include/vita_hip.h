@@ -432,6 +432,12 @@ typedef struct {
 } vita_attn_bwd_params;
 
 int vita_flash_attn_bwd(const vita_attn_bwd_params* p, void* stream);
+/* ABI 15: the two passes separately — VITA_ATTN_BWD_DKV (dK + dV of every key row: needs p->dk, p->dv) and VITA_ATTN_BWD_DQ
+ * (needs p->dq); with both bits dK / dV are launched first.  A context-parallel caller runs DKV, starts the reduce-scatter of
+ * dK / dV on its communication stream, then runs DQ under it (vita_cp_attn_bwd; TE's ring does the same with its P2P steps). */
+#define VITA_ATTN_BWD_DQ 1
+#define VITA_ATTN_BWD_DKV 2
+int vita_flash_attn_bwd_parts(const vita_attn_bwd_params* p, int parts, void* stream);
 
 /* Merge of two attention partials over DISJOINT key sets (their natural-log lse from vita_flash_attn_fwd), in place into the first:
  *   lse = log(exp(lse_a) + exp(lse_b)),  O_a = O_a exp(lse_a - lse) + O_b exp(lse_b - lse)      (a part that saw no key: lse = -inf).

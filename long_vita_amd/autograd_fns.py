@@ -457,23 +457,48 @@ class FlashAttnCPFn(torch.autograd.Function):
 
     @staticmethod
     def backward(ctx, d_o):
+        """r04: the exchange runs under the kernels — the K / V re-gather is asynchronous per kv-head split (gather j + 1 in flight under
+        split j's kernels), the dK + dV pass of a split runs BEFORE its dQ pass and its reduce-scatter is issued right behind it, so it
+        runs under the dQ pass (3 of the backward's 8 GEMM units) and the later splits; every collective is waited for at the end.
+        Through r03 this was: gather (sync) -> all kernels -> reduce-scatter (sync)."""
         q, k, v, o, lse = ctx.saved_tensors
         cp, r, group = ctx.cp, ctx.rank, ctx.group
         _, s_l, hq, d = q.shape
         hkv = k.shape[2]
-        kv_local = torch.stack([k[0], v[0]]).contiguous()                                   # [2, S_l, Hkv, D]
-        gathered = torch.empty(cp * kv_local.numel(), dtype=kv_local.dtype, device=kv_local.device)
-        dist.all_gather_into_tensor(gathered, kv_local.view(-1), group=group)
-        rows = gathered.view(cp * 2 * s_l, hkv, d)
-        d_rows = torch.empty_like(rows)                                                     # dK rows of rank p at p * 2 * S_l, dV at + S_l
+        n_split = ops.cp_kv_split(hkv, hq, s_l)
+        hg, qpg = hkv // n_split, hq // hkv
+        d_o = d_o.contiguous()
+        kv_local = torch.empty(n_split, 2, s_l, hg, d, dtype=q.dtype, device=q.device)        # the packed send buffers, one per split
+        kv_local[:, 0].copy_(k[0].reshape(s_l, n_split, hg, d).permute(1, 0, 2, 3))
+        kv_local[:, 1].copy_(v[0].reshape(s_l, n_split, hg, d).permute(1, 0, 2, 3))
+        gathered = torch.empty(n_split, cp * kv_local[0].numel(), dtype=q.dtype, device=q.device)
+        gathers = [dist.all_gather_into_tensor(gathered[j], kv_local[j].reshape(-1), group=group, async_op=True) for j in range(n_split)]
+        d_rows = torch.empty_like(gathered)                                                  # dK rows of rank p at p * 2 * S_l, dV at + S_l
+        dkv = torch.empty(n_split, kv_local[0].numel(), dtype=q.dtype, device=q.device)
         dq = torch.empty(q.shape, dtype=q.dtype, device=q.device)
-        ops.flash_attn_bwd(q, rows.unsqueeze(0), rows[s_l:].unsqueeze(0), o, d_o.contiguous(), lse, dq5=dq,
-                           dk=d_rows.unsqueeze(0), dv=d_rows[s_l:].unsqueeze(0), softmax_scale=ctx.softmax_scale,
-                           **zigzag_geometry(cp, r, s_l))
-        dkv = torch.empty(kv_local.numel(), dtype=kv_local.dtype, device=kv_local.device)
-        dist.reduce_scatter_tensor(dkv, d_rows.view(-1), group=group)
-        dkv = dkv.view(2, 1, s_l, hkv, d)
-        return dq, dkv[0], dkv[1], None
+        geo = zigzag_geometry(cp, r, s_l)
+        q5, dq5 = q.view(1, s_l, hkv, qpg, d), dq.view(1, s_l, hkv, qpg, d)
+        delta, reduces = None, []
+        for j in range(n_split):
+            if gathers[j] is not None:
+                gathers[j].wait()
+            rows, drows = gathered[j].view(cp * 2 * s_l, hg, d), d_rows[j].view(cp * 2 * s_l, hg, d)
+            hs = slice(j * hg * qpg, (j + 1) * hg * qpg)
+            args = (q5[:, :, j * hg:(j + 1) * hg], rows.unsqueeze(0), rows[s_l:].unsqueeze(0), o[:, :, hs], d_o[:, :, hs], lse[:, hs])
+            if delta is None:            # row sums of dO * O for ALL heads, once: every split's passes read their head slice of it
+                delta = torch.empty((hq, s_l), dtype=torch.float32, device=q.device)
+                ops.attn_delta(o, d_o, delta)
+            kw = dict(softmax_scale=ctx.softmax_scale, delta=delta[hs], **geo)
+            ops.flash_attn_bwd(*args, dk=drows.unsqueeze(0), dv=drows[s_l:].unsqueeze(0), parts=ops.ATTN_BWD_DKV, **kw)
+            reduces.append(dist.reduce_scatter_tensor(dkv[j], d_rows[j], group=group, async_op=True))
+            ops.flash_attn_bwd(*args, dq5=dq5[:, :, j * hg:(j + 1) * hg], parts=ops.ATTN_BWD_DQ, **kw)
+        for w in reduces:
+            if w is not None:
+                w.wait()
+        dkv = dkv.view(n_split, 2, s_l, hg, d)
+        dk = dkv[:, 0].permute(1, 0, 2, 3).reshape(1, s_l, hkv, d)
+        dv = dkv[:, 1].permute(1, 0, 2, 3).reshape(1, s_l, hkv, d)
+        return dq, dk, dv, None
 
 
 # ------------------------------------------------------------------------------------------------

@@ -241,6 +241,11 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
   f32x16 sb[2][2][2];                                // S^T[parity][qb][kb]: key 32 kb + (r & 3) + 8 (r >> 2) + 4 hi
   unsigned pk[2][2][4][4];                           // packed P^T[parity][qb][frag f][4 dwords]; frag f = regs 8 (f & 1) .. of kb = f >> 1
   float m_run[2] = {-1.0e30f, -1.0e30f}, l_run[2] = {0.f, 0.f}, m_neg[2], alpha[2] = {1.f, 1.f}, mxc[4];
+  // r04: the 32 probabilities a lane holds of a tile are summed into l_tile first and folded into l_run ONCE per tile.  Adding them one
+  // by one stagnates on very long rows: beyond ~2 M visible keys l_run's ulp reaches the size of a single p (p ~ 2^-8 of the row
+  // maximum, l_run ~ 5e4 -> ulp 4e-3), the small ones are rounded away and O / l comes out too large — 1.5e-2 at 13 M keys
+  // (tools/bench_maxseq.py: one CP = 8 rank at S = 16.8 M); a tile's partial sum is 32 x larger than its terms
+  float l_tile[2] = {0.f, 0.f};
   float ea = 0.f, eb = 0.f, mx0_keep = 0.f;
 
   constexpr SlotMap MAP1 = make_map1(), MAP2 = make_map2();
@@ -253,10 +258,14 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
       ea = __builtin_amdgcn_exp2f(fmaf(sb[par][qb][kb][r], scale_log2e, m_neg[qb]));
       eb = __builtin_amdgcn_exp2f(fmaf(sb[par][qb][kb][r + 1], scale_log2e, m_neg[qb]));
     } else {
-      l_run[qb] += ea;
-      l_run[qb] += eb;
+      l_tile[qb] += ea;
+      l_tile[qb] += eb;
       pk[par][qb][f][pr] = pack_bf16x2(ea, eb);
-      asm volatile("" :: "v"(pk[par][qb][f][pr]), "v"(l_run[qb]));              // computed HERE (no sinking past the phase)
+      if (h == 55 || h == 63) {                      // the last half-unit of block qb (fragments g = 6 / 7): fold the tile's sum
+        l_run[qb] += l_tile[qb];
+        l_tile[qb] = 0.f;
+      }
+      asm volatile("" :: "v"(pk[par][qb][f][pr]), "v"(l_tile[qb]), "v"(l_run[qb]));              // computed HERE (no sinking past the phase)
     }
   };
   // the running-maximum decision of a tile: unit 32 keeps block 0's maximum, unit 33 decides for both blocks with ONE

@@ -472,9 +472,18 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
 
 }  // namespace
 
+extern "C" int vita_flash_attn_bwd_parts(const vita_attn_bwd_params* p, int parts, void* stream);
+
 extern "C" int vita_flash_attn_bwd(const vita_attn_bwd_params* p, void* stream) {
-  if (!p || !p->q || !p->k || !p->v || !p->d_o || !p->lse || !p->delta || !p->dq || !p->dk || !p->dv)
-    return VITA_ERR_INVALID_ARG;
+  return vita_flash_attn_bwd_parts(p, VITA_ATTN_BWD_DQ | VITA_ATTN_BWD_DKV, stream);
+}
+
+// parts: VITA_ATTN_BWD_DKV (the dK + dV pass) and / or VITA_ATTN_BWD_DQ (the dQ pass); when both are asked for, dK / dV are launched
+// FIRST so that a context-parallel caller can start the reduce-scatter of dK / dV while the dQ pass runs (cp_attn.hip)
+extern "C" int vita_flash_attn_bwd_parts(const vita_attn_bwd_params* p, int parts, void* stream) {
+  if (!(parts & (VITA_ATTN_BWD_DQ | VITA_ATTN_BWD_DKV))) return VITA_ERR_INVALID_ARG;
+  if (!p || !p->q || !p->k || !p->v || !p->d_o || !p->lse || !p->delta) return VITA_ERR_INVALID_ARG;
+  if (((parts & VITA_ATTN_BWD_DQ) && !p->dq) || ((parts & VITA_ATTN_BWD_DKV) && (!p->dk || !p->dv))) return VITA_ERR_INVALID_ARG;
   if (p->head_dim != 128) return VITA_ERR_UNSUPPORTED;
   if (p->n_q_heads <= 0 || p->n_kv_heads <= 0 || p->n_q_heads % p->n_kv_heads) return VITA_ERR_INVALID_ARG;
   if (p->n_q_chunks <= 0 || p->n_kv_chunks <= 0 || p->n_q_chunks > kMaxChunks || p->n_kv_chunks > kMaxChunks)
@@ -521,20 +530,20 @@ extern "C" int vita_flash_attn_bwd(const vita_attn_bwd_params* p, void* stream) 
   const int64_t n_kv = (int64_t)p->n_kv_heads * p->n_kv_chunks * (p->chunk_len / KT_KV);
   if (n_dq > 0x7fffffff || n_kv > 0x7fffffff) return VITA_ERR_UNSUPPORTED;
   const char* only = vita_dev_getenv("VITA_ATTN_BWD_ONLY");     // developer measurement aid: "dq" / "dkv" launch one of the two kernels
-  if (!only || only[1] == 'q') {
-    if (vita_attn_bwd_dq64_eligible(a)) {            // causal whole 256-row tiles: 64 query rows per wave (attn_bwd64.hip)
-      const int rc = vita_attn_bwd_dq64_launch(a, st);
-      if (rc != VITA_OK) return rc;
-    } else {
-      hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)n_dq), dim3(256), lds_dq, st, a);
-    }
-  }
-  if (!only || only[1] == 'k') {
+  if ((parts & VITA_ATTN_BWD_DKV) && (!only || only[1] == 'k')) {
     if (vita_attn_bwd_kv64_eligible(a)) {            // whole 256-key tiles: 64 keys per wave, a dK and a dV launch (attn_bwd_kv64.hip)
       const int rc = vita_attn_bwd_kv64_launch(a, st);
       if (rc != VITA_OK) return rc;
     } else {
       hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)n_kv), dim3(256), lds_kv, st, a);
+    }
+  }
+  if ((parts & VITA_ATTN_BWD_DQ) && (!only || only[1] == 'q')) {
+    if (vita_attn_bwd_dq64_eligible(a)) {            // causal whole 256-row tiles: 64 query rows per wave (attn_bwd64.hip)
+      const int rc = vita_attn_bwd_dq64_launch(a, st);
+      if (rc != VITA_OK) return rc;
+    } else {
+      hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)n_dq), dim3(256), lds_dq, st, a);
     }
   }
   return vita_check_launch();

@@ -16,8 +16,9 @@
 //             tools/probe_comm_overlap.py, profiles/r03_hwprobe_comm_overlap.txt): a communication kernel enqueued under the
 //             attention gets whole CUs at the first workgroup turnover (<= 2.8 ms at the 128K / CP = 8 geometry, where the next
 //             gather is needed 5.6 ms later) and costs the attention <= 1.2 %.
-//   backward: vita_flash_attn_bwd writes dK / dV of every visible key in the gathered layout, ONE ncclReduceScatter (sum, bf16)
-//             per split returns each rank its shard.
+//   backward: vita_flash_attn_bwd_parts writes dK / dV of every visible key in the gathered layout (the dK + dV pass runs FIRST),
+//             ONE ncclReduceScatter (sum, bf16) per split returns each rank its shard — issued right behind that split's dK / dV
+//             pass, so it runs under the split's dQ pass (3 of the backward's 8 GEMM units) and under the later splits (r04).
 // RCCL is resolved at run time (dlsym): inside a PyTorch process that is the librccl torch already loaded, a plain C host gets
 // librccl.so from the ROCm installation.  No symbol of this file is needed by the single-GPU path.
 #include "vita_common.h"
@@ -26,7 +27,7 @@
 #include <string.h>
 
 extern "C" int vita_flash_attn_fwd(const vita_attn_params* p, void* stream);
-extern "C" int vita_flash_attn_bwd(const vita_attn_bwd_params* p, void* stream);
+extern "C" int vita_flash_attn_bwd_parts(const vita_attn_bwd_params* p, int parts, void* stream);
 extern "C" int vita_attn_merge(void* o_a, int64_t oa_row_stride, int64_t oa_head_stride, float* lse_a, const void* o_b,
                                int64_t ob_row_stride, int64_t ob_head_stride, const float* lse_b, int64_t rows, int heads,
                                int head_dim, void* stream);
@@ -266,15 +267,20 @@ extern "C" int vita_cp_attn_bwd(vita_cp_context* c, const vita_cp_attn_params* p
     b.chunk_len = s_l / 2; b.n_q_chunks = 2; b.n_kv_chunks = 2 * cp;
     b.q_chunk_gid = g.q_gid; b.kv_chunk_gid = g.kv_gid; b.kv_chunk_row = g.kv_row;
     b.softmax_scale = p->softmax_scale;
-    rc = vita_flash_attn_bwd(&b, stream);
+    // r04: dK / dV of split j first; its reduce-scatter goes out on the communication stream at once and runs under the dQ pass of
+    // this split and under everything of the later splits (through r03 every reduce-scatter waited for the last split's last kernel)
+    rc = vita_flash_attn_bwd_parts(&b, VITA_ATTN_BWD_DKV, stream);
+    if (rc != VITA_OK) return rc;
+    if (c->comm) {
+      if (hipEventRecord(c->gathered[j], st) != hipSuccess || hipStreamWaitEvent(c->comm_stream, c->gathered[j], 0) != hipSuccess)
+        return VITA_ERR_LAUNCH;
+      if (rccl().ReduceScatter(drows, (bf16_t*)dkv_packed + j * shard, shard, kNcclBfloat16, kNcclSum, c->comm, c->comm_stream) != 0)
+        return VITA_ERR_LAUNCH;
+    }
+    rc = vita_flash_attn_bwd_parts(&b, VITA_ATTN_BWD_DQ, stream);
     if (rc != VITA_OK) return rc;
   }
   if (!c->comm) return VITA_OK;        // external exchange: the caller reduces p->dkv_workspace ([split][rank][dK | dV][s_l][hg][d]) itself
-  if (hipEventRecord(c->ready, st) != hipSuccess || hipStreamWaitEvent(c->comm_stream, c->ready, 0) != hipSuccess) return VITA_ERR_LAUNCH;
-  for (int j = 0; j < p->n_split; ++j)
-    if (rccl().ReduceScatter(dws + (size_t)j * cp * shard, (bf16_t*)dkv_packed + j * shard, shard, kNcclBfloat16, kNcclSum, c->comm,
-                             c->comm_stream) != 0)
-      return VITA_ERR_LAUNCH;
   if (hipEventRecord(c->reduced, c->comm_stream) != hipSuccess || hipStreamWaitEvent(st, c->reduced, 0) != hipSuccess) return VITA_ERR_LAUNCH;
   return VITA_OK;
 }

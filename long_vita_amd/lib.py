@@ -172,6 +172,7 @@ PROTOTYPES = {
     "vita_row_scatter_add_f32": (_i, [_p, _p, _p, _l, _l, _i, _p, _p]),
     "vita_attn_delta": (_i, [_p, _p, _p, _l, _i, _i, _l, _l, _l, _l, _p]),
     "vita_flash_attn_bwd": (_i, [C.POINTER(AttnBwdParams), _p]),
+    "vita_flash_attn_bwd_parts": (_i, [C.POINTER(AttnBwdParams), _i, _p]),
     "vita_attn_merge": (_i, [_p, _l, _l, _p, _p, _l, _l, _p, _l, _i, _i, _p]),
     "vita_gemv_bf16": (_i, [_p, _p, _l, _p, _l, _l, _i, _p, _p, _p]),
     "vita_decode_attn_partial": (_i, [_p, _l, _l, _p, _p, _l, _l, _i, _p, _i, _i, _i, _i, _f, _p, _p, _p, _p]),

@@ -681,11 +681,25 @@ def row_scatter_add_f32_(dst: torch.Tensor, idx: torch.Tensor, src: torch.Tensor
     return dst
 
 
+ATTN_BWD_DQ, ATTN_BWD_DKV = 1, 2
+
+
+def attn_delta(o: torch.Tensor, d_o: torch.Tensor, delta: torch.Tensor) -> torch.Tensor:
+    """delta[h, row] = sum_d float(dO[row, h, d]) * float(O[row, h, d]) — the backward's pre-pass; o, d_o [1, Sq, Hq, D] views, delta fp32 [Hq, Sq]."""
+    _, Sq, Hq, D = o.shape
+    _L.check(_L.load().vita_attn_delta(_dev(o, "o", BF16), _dev(d_o, "d_o", BF16), _dev(delta, "delta", torch.float32), Sq, Hq, D,
+                                       o.stride(1), o.stride(2), d_o.stride(1), d_o.stride(2), _stream()), "vita_attn_delta")
+    return delta
+
+
 def flash_attn_bwd(q5, k, v, o, d_o, lse, *, chunk_len=None, q_chunk_gid=None, kv_chunk_gid=None, kv_chunk_row=None,
-                   softmax_scale=None, dq5=None, dk=None, dv=None, seg_start=None, seg_end=None):
+                   softmax_scale=None, dq5=None, dk=None, dv=None, seg_start=None, seg_end=None, parts=ATTN_BWD_DQ | ATTN_BWD_DKV,
+                   delta=None):
     """Backward of flash_attn(causal=True) at batch 1, head_dim 128 (seg_start / seg_end int32 [rows]: packed sequences).
     q5 [1, Sq, Hkv, G, D] (or [1, Sq, Hq, D]); k, v [1, Sk, Hkv, D] views; o, d_o [1, Sq, Hq, D];
-    lse [1, Hq, Sq].  Returns (dq like q5, dk, dv like k/v — dk/dv cover every row of k/v)."""
+    lse [1, Hq, Sq].  Returns (dq like q5, dk, dv like k/v — dk/dv cover every row of k/v).
+    parts: ATTN_BWD_DKV / ATTN_BWD_DQ run one pass only (a context-parallel caller starts the dK / dV reduce-scatter between them);
+    delta: the fp32 [Hq, Sq] row sums of dO * O from an earlier call of this function (returned as 4th value when parts is partial)."""
     if q5.dim() == 5:
         _, Sq, Hkv_q, G, D = q5.shape
         Hq = Hkv_q * G
@@ -698,26 +712,32 @@ def flash_attn_bwd(q5, k, v, o, d_o, lse, *, chunk_len=None, q_chunk_gid=None, k
         chunk_len, qg, kg, kr = Sq, [0], [0], [0]
     else:
         qg, kg, kr = list(q_chunk_gid), list(kv_chunk_gid), list(kv_chunk_row)
-    dq5 = torch.empty_like(q5) if dq5 is None else dq5
-    dk = torch.empty_like(k) if dk is None else dk
-    dv = torch.empty_like(v) if dv is None else dv
-    delta = torch.empty((Hq, Sq), dtype=torch.float32, device=q5.device)
+    both = parts == (ATTN_BWD_DQ | ATTN_BWD_DKV)
+    if parts & ATTN_BWD_DQ:
+        dq5 = torch.empty_like(q5) if dq5 is None else dq5
+    if parts & ATTN_BWD_DKV:
+        dk = torch.empty_like(k) if dk is None else dk
+        dv = torch.empty_like(v) if dv is None else dv
     h = _L.load()
-    _L.check(h.vita_attn_delta(_dev(o, "o", BF16), _dev(d_o, "d_o", BF16), _dev(delta, "delta"), Sq, Hq, D,
-                               o.stride(1), o.stride(2), d_o.stride(1), d_o.stride(2), _stream()), "vita_attn_delta")
+    if delta is None:
+        delta = torch.empty((Hq, Sq), dtype=torch.float32, device=q5.device)
+        _L.check(h.vita_attn_delta(_dev(o, "o", BF16), _dev(d_o, "d_o", BF16), _dev(delta, "delta"), Sq, Hq, D,
+                                   o.stride(1), o.stride(2), d_o.stride(1), d_o.stride(2), _stream()), "vita_attn_delta")
     p = _L.AttnBwdParams()
     p.q, p.q_row_stride, p.q_head_stride, p.q_group_stride = _dev(q5, "q", BF16), q_rs, q_hs, q_gs
     p.k, p.k_row_stride, p.k_head_stride = _dev(k, "k", BF16), k.stride(1), k.stride(2)
     p.v, p.v_row_stride, p.v_head_stride = _dev(v, "v", BF16), v.stride(1), v.stride(2)
     p.d_o, p.do_row_stride, p.do_head_stride = _dev(d_o, "d_o", BF16), d_o.stride(1), d_o.stride(2)
     p.lse, p.delta = _dev(lse, "lse", torch.float32), _dev(delta, "delta")
-    if dq5.dim() == 5:
-        p.dq, p.dq_row_stride, p.dq_group_stride, p.dq_head_stride = (_dev(dq5, "dq", BF16), dq5.stride(1),
-                                                                       dq5.stride(2), dq5.stride(3))
-    else:
-        p.dq, p.dq_row_stride, p.dq_head_stride, p.dq_group_stride = _dev(dq5, "dq", BF16), dq5.stride(1), dq5.stride(2), 0
-    p.dk, p.dk_row_stride, p.dk_head_stride = _dev(dk, "dk", BF16), dk.stride(1), dk.stride(2)
-    p.dv, p.dv_row_stride, p.dv_head_stride = _dev(dv, "dv", BF16), dv.stride(1), dv.stride(2)
+    if dq5 is not None:
+        if dq5.dim() == 5:
+            p.dq, p.dq_row_stride, p.dq_group_stride, p.dq_head_stride = (_dev(dq5, "dq", BF16), dq5.stride(1),
+                                                                           dq5.stride(2), dq5.stride(3))
+        else:
+            p.dq, p.dq_row_stride, p.dq_head_stride, p.dq_group_stride = _dev(dq5, "dq", BF16), dq5.stride(1), dq5.stride(2), 0
+    if dk is not None:
+        p.dk, p.dk_row_stride, p.dk_head_stride = _dev(dk, "dk", BF16), dk.stride(1), dk.stride(2)
+        p.dv, p.dv_row_stride, p.dv_head_stride = _dev(dv, "dv", BF16), dv.stride(1), dv.stride(2)
     p.n_q_heads, p.n_kv_heads, p.head_dim = Hq, Hkv, D
     p.chunk_len, p.n_q_chunks, p.n_kv_chunks = chunk_len, len(qg), len(kg)
     qg_a, kg_a, kr_a = (C.c_int32 * len(qg))(*qg), (C.c_int32 * len(kg))(*kg), (C.c_int64 * len(kr))(*kr)
@@ -725,8 +745,8 @@ def flash_attn_bwd(q5, k, v, o, d_o, lse, *, chunk_len=None, q_chunk_gid=None, k
     p.softmax_scale = float(softmax_scale if softmax_scale is not None else 1.0 / math.sqrt(D))
     if seg_start is not None:
         p.q_seg_start, p.k_seg_end = _dev(seg_start, "seg_start", torch.int32), _dev(seg_end, "seg_end", torch.int32)
-    _L.check(h.vita_flash_attn_bwd(C.byref(p), _stream()), "vita_flash_attn_bwd")
-    return dq5, dk, dv
+    _L.check(h.vita_flash_attn_bwd_parts(C.byref(p), int(parts), _stream()), "vita_flash_attn_bwd")
+    return (dq5, dk, dv) if both else (dq5, dk, dv, delta)
 
 
 # ------------------------------------------------------------------------------------------------

@@ -78,7 +78,8 @@ def main():
     t_vit = time.perf_counter() - t0
     ext["features"] = feats
     h = model.embedding(tokens, None, external_feature_dict=ext).view(s_l, cfg.hidden)
-    del feats
+    ext.clear()                                                           # the projected features (20 GiB here) die with the scatter,
+    del feats                                                             # as they do in GPTVLModel.forward
     emit(kind="maxseq_vit", frames=n_frames, seconds=t_vit, frames_per_s=n_frames / t_vit, after_embed_gb=torch.cuda.memory_allocated() / GB)
 
     # ---- the decoder workspace of the rank + the gathered K/V of one layer, as forward_cp holds them -----------------------------------
@@ -146,7 +147,7 @@ def main():
     fixed = weights_gb + 5.0                                             # weights + the ViT chunk buffers: what does not grow with S
     s_max = int(S * (0.95 * total_b / GB - fixed) / max(peak - fixed, 1e-9))
     emit(kind="maxseq_result", device_total_gb=total_b / GB, max_seq_at_95pct_by_the_measured_slope=s_max, S=S, s_local=s_l, cp=cp, rank=rank, frames_on_rank=n_frames, layers_run=n_layers_run,
-         peak_hbm_gb=peak, model_gb=(35e9 + 14e3 * S) / GB, hbm_gb=288e9 / GB, fits=peak < 288e9 / GB, logits_finite=bool(torch.isfinite(logits.float()).all()),
+         peak_hbm_gb=peak, model_gb=(35e9 + 14e3 * S) / GB, fits=peak < 0.95 * total_b / GB, logits_finite=bool(torch.isfinite(logits.float()).all()),
          attention_parity=checks,
          note="peak = every buffer one CP = 8 rank holds for a prefill at this S (48 layers of weights, workspace at S_l rows, gathered K/V of one layer "
               "for all 8 kv heads, the rank's frames, ViT chunk buffers); compute = ViT over the rank's frames + 2 decoder layers with one kv group's attention")
