@@ -91,7 +91,7 @@ struct TileIt {
 // starts at the (even) tile of its first row's segment, and a tile that begins before the segment of the wave's LAST row gets a
 // second arithmetic mask (key >= seg_start[row]); rows whose segment starts later see such tiles as all-masked: P = 0, the running
 // maximum stays at its initial -1e30 and the first visible tile rescales the (zero) state by exp2(-1e30 - m) = 0.
-template <int NSLOT, bool PACKED>
+template <int NSLOT, bool PACKED, bool LTILE = true>
 __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
   constexpr int LDS_V = NSLOT * TILEB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -258,14 +258,21 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
       ea = __builtin_amdgcn_exp2f(fmaf(sb[par][qb][kb][r], scale_log2e, m_neg[qb]));
       eb = __builtin_amdgcn_exp2f(fmaf(sb[par][qb][kb][r + 1], scale_log2e, m_neg[qb]));
     } else {
-      l_tile[qb] += ea;
-      l_tile[qb] += eb;
-      pk[par][qb][f][pr] = pack_bf16x2(ea, eb);
-      if (h == 55 || h == 63) {                      // the last half-unit of block qb (fragments g = 6 / 7): fold the tile's sum
-        l_run[qb] += l_tile[qb];
-        l_tile[qb] = 0.f;
+      if (LTILE) {
+        l_tile[qb] += ea;
+        l_tile[qb] += eb;
+        pk[par][qb][f][pr] = pack_bf16x2(ea, eb);
+        if (h == 55 || h == 63) {                    // the last half-unit of block qb (fragments g = 6 / 7): fold the tile's sum
+          l_run[qb] += l_tile[qb];
+          l_tile[qb] = 0.f;
+        }
+        asm volatile("" :: "v"(pk[par][qb][f][pr]), "v"(l_tile[qb]), "v"(l_run[qb]));            // computed HERE (no sinking past the phase)
+      } else {                                       // r02-r03 (VITA_ATTN64_LTILE=0 under VITA_DEBUG: A/B timing only)
+        l_run[qb] += ea;
+        l_run[qb] += eb;
+        pk[par][qb][f][pr] = pack_bf16x2(ea, eb);
+        asm volatile("" :: "v"(pk[par][qb][f][pr]), "v"(l_run[qb]));
       }
-      asm volatile("" :: "v"(pk[par][qb][f][pr]), "v"(l_tile[qb]), "v"(l_run[qb]));              // computed HERE (no sinking past the phase)
     }
   };
   // the running-maximum decision of a tile: unit 32 keeps block 0's maximum, unit 33 decides for both blocks with ONE
@@ -542,14 +549,18 @@ int vita_attn64_launch(const AttnArgs& a, int64_t nblocks, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd64_kernel<2, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILEB);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd64_kernel<2, true>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILEB);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd64_kernel<4, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 8 * TILEB);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&flash_fwd64_kernel<2, false, false>), hipFuncAttributeMaxDynamicSharedMemorySize, 4 * TILEB);
   });
   if (a.seg_start) {
     hipLaunchKernelGGL((flash_fwd64_kernel<2, true>), dim3((unsigned)nblocks), dim3(256), 4 * TILEB, st, a);
     return vita_check_launch();
   }
   const char* e = vita_dev_getenv("VITA_ATTN64_RING");           // developer A/B switch: 4 = four-slot rings, a barrier every two tiles
+  const char* lt = vita_dev_getenv("VITA_ATTN64_LTILE");         // developer A/B switch: 0 = the r03 row sum (one add per probability)
   if (e && e[0] == '4')
     hipLaunchKernelGGL((flash_fwd64_kernel<4, false>), dim3((unsigned)nblocks), dim3(256), 8 * TILEB, st, a);
+  else if (lt && lt[0] == '0')
+    hipLaunchKernelGGL((flash_fwd64_kernel<2, false, false>), dim3((unsigned)nblocks), dim3(256), 4 * TILEB, st, a);
   else
     hipLaunchKernelGGL((flash_fwd64_kernel<2, false>), dim3((unsigned)nblocks), dim3(256), 4 * TILEB, st, a);
   return vita_check_launch();

@@ -23,7 +23,10 @@
 namespace {
 
 constexpr int D = 128, KVT = 64, QTILE = 256, ROWB = D * 2, TILEB = KVT * ROWB;       // 16 KiB per image of a 64-key tile
-constexpr int LDS_KF = 0, LDS_VF = 3 * TILEB, LDS_KT = 6 * TILEB, LDS_BYTES = 8 * TILEB;   // K frag [3] | V frag [3] | K tr [2] = 128 KiB
+// r04: ONE image per K tile serves the fragment reads (S^T = K Q^T) and the transposed reads (dQ^T += K^T dS^T): 16-byte slots XOR-ed with
+// swz(row) = ((row & 3) << 2) | ((row >> 2) & 3) — conflict-free for both access patterns (attn_bwd_kv64.hip's header); r02-r03 staged
+// a second, differently swizzled K image (48 -> 32 KB of LDS-DMA per tile)
+constexpr int LDS_KF = 0, LDS_VF = 3 * TILEB, LDS_BYTES = 6 * TILEB;   // K [3] | V frag [3] = 96 KiB
 
 typedef __attribute__((address_space(3))) const bf16x8 lds_bf16x8;
 typedef __attribute__((address_space(3))) s16x4 lds_s16x4;
@@ -94,26 +97,26 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(BwdArgs p) {
   }
 
   // ---- LDS fragment offsets (attn.hip's layouts) -----------------------------------------------------------------------------------
-  unsigned koff[8], toff[4];
+  auto swz = [](int row) { return ((row & 3) << 2) | ((row >> 2) & 3); };
+  unsigned koff[8], toff[4], toff8[4];               // toff8: the second transposed read, 8 keys further down
 #pragma unroll
-  for (int ds = 0; ds < 8; ++ds) koff[ds] = l31 * ROWB + (((2 * ds + hi) ^ (l31 & 15)) << 4);       // + 32 kb rows: immediate
+  for (int ds = 0; ds < 8; ++ds) koff[ds] = l31 * ROWB + (((2 * ds + hi) ^ swz(l31 & 15)) << 4);       // + 32 kb rows: immediate
   {
     const int g16 = lane >> 4, i16 = lane & 15, key_l = 4 * (g16 >> 1) + (i16 >> 2);
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
       const int col = 32 * db + 16 * (g16 & 1) + 4 * (i16 & 3);
-      toff[db] = key_l * ROWB + (((col >> 4) ^ ((key_l & 3) << 1)) << 5) + (col & 15) * 2;
+      toff[db] = key_l * ROWB + (((col >> 3) ^ swz(key_l)) << 4) + (col & 7) * 2;
+      toff8[db] = (key_l + 8) * ROWB + (((col >> 3) ^ swz(key_l + 8)) << 4) + (col & 7) * 2;
     }
   }
   // ---- LDS-DMA: wave w moves pieces 4w .. 4w+3 (1 KiB = 4 rows) of each image; swizzles on the SOURCE address --------------------
-  unsigned off_kf[4], off_kt[4], off_vf[4];
+  unsigned off_kf[4], off_vf[4];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int row = (wave * 4 + q) * 4 + (lane >> 4), ps = lane & 15;
-    const int fs = ps ^ (row & 15);
-    const int ts = (((ps >> 1) ^ ((row & 3) << 1)) << 1) | (ps & 1);
+    const int fs = ps ^ swz(row & 15);
     off_kf[q] = (unsigned)((row * p.k_rs + fs * 8) * 2);
-    off_kt[q] = (unsigned)((row * p.k_rs + ts * 8) * 2);
     off_vf[q] = (unsigned)((row * p.v_rs + fs * 8) * 2);
   }
   const char* kbase = (const char*)(p.k + (int64_t)kvh * p.k_hs);
@@ -129,13 +132,6 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(BwdArgs p) {
       vita_lds_dma16(rk, off_kf[q], base + LDS_KF + q * 1024);
       vita_lds_dma16(rv, off_vf[q], base + LDS_VF + q * 1024);
     }
-  };
-  auto dma_kt = [&](const TileIt& t, int slot2) __attribute__((always_inline)) {                // K transposed-layout image
-    const vita_rsrc_t rk = vita_make_rsrc_uniform(t.kp);
-    unsigned base = lds_w + LDS_KT + slot2 * TILEB;
-    asm volatile("" : "+s"(base));
-#pragma unroll
-    for (int q = 0; q < 4; ++q) vita_lds_dma16(rk, off_kt[q], base + q * 1024);
   };
 
   // ---- tile iterator (as attn64.hip) ---------------------------------------------------------------------------------------------
@@ -198,9 +194,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(BwdArgs p) {
     return *(lds_bf16x8*)(uintptr_t)(slot_addr + koff[ds] + kb * 32 * ROWB);
   };
   auto tr_frag = [&](unsigned slot_addr, int t4, int db) __attribute__((always_inline)) {      // keys 16 t4 .. + 15, d block db
-    const unsigned va = slot_addr + toff[db] + 16 * t4 * ROWB;
-    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(va));
-    const s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(va + 8 * ROWB));
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(slot_addr + toff[db] + 16 * t4 * ROWB));
+    const s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(slot_addr + toff8[db] + 16 * t4 * ROWB));
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     const s16x8 ac = __builtin_shufflevector(a, c, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, ac);
@@ -303,7 +298,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(BwdArgs p) {
   advance(nx1);                                      // n_tiles >= 4
   TileIt nx2 = nx1;
   advance(nx2);
-  dma_kv(cur, 0); dma_kt(cur, 0); dma_kv(nx1, 1);
+  dma_kv(cur, 0); dma_kv(nx1, 1);
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
   sp_group(1, lds0 + LDS_KF, lds0 + LDS_VF, 0, false, needs_mask(cur), cur.j * KVT);           // -> buffers 0
@@ -316,8 +311,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(BwdArgs p) {
   // has1 / has2 (tile t+1 / t+2 exists) are compile-time constants of each call: no data-dependent branch inside the pipeline
   auto iteration = [&](const bool has1, const bool has2) __attribute__((always_inline)) {
     if (has2) dma_kv(nx2, s3nn);                     // that slot held tile t-1 (last read before the previous barrier)
-    if (has1) dma_kt(nx1, tpar ^ 1);
-    const unsigned kf = lds0 + LDS_KF + s3 * TILEB, vf = lds0 + LDS_VF + s3 * TILEB, kt = lds0 + LDS_KT + tpar * TILEB;
+    const unsigned kf = lds0 + LDS_KF + s3 * TILEB, vf = lds0 + LDS_VF + s3 * TILEB, kt = kf;      // K^T out of tile t's K image
     const unsigned kfn = lds0 + LDS_KF + s3n * TILEB, vfn = lds0 + LDS_VF + s3n * TILEB;
     // trip A: u = 2 t (buffers 0): next half = (tile t, kb 1)
     sp_group(0, kf, vf, 1, true, needs_mask(cur), cur.j * KVT + 32);

@@ -12,8 +12,12 @@
 //         trip u:  S(u+1) MFMAs || dS(u) / pack;   dP(u+1) MFMAs || P(u+1) = exp2(...);   gradient MFMAs of half u || rest of P(u+1)
 //   * lse / delta belong to the TILE's rows here (they vary along the accumulator registers, not along lanes): each tile's 64 + 64
 //     values are staged next to its images and read as 4-float vectors right before the half that needs them;
-//   * images per tile: Q fragment layout, dO fragment layout, Q transposed layout (IS_DK) / Q fragment layout, dO transposed (!IS_DK);
-//     rings of 3 (fragment images, statistics) and 2 (transposed image), all by LDS-DMA from inline asm, one barrier per tile.
+//   * images per tile (r04): IS_DK — Q and dO, ONE image each: the fragment reads (ds_read_b128, S and dP) and the transposed reads
+//     (ds_read_b64_tr_b16, dK^T += Q^T dS) of Q come from the same LDS image.  Its 16-byte slots are XOR-ed with
+//     swz(row) = ((row & 3) << 2) | ((row >> 2) & 3): 16 consecutive rows land in 16 different slots (fragment reads), and the
+//     four rows a 32-lane half of a transposed read touches land in four different 64-byte bank groups — both conflict-free, where
+//     r02-r03 staged a second, differently swizzled copy of the Q tile (48 -> 32 KB of LDS-DMA per tile, 8 -> 6 tiles of LDS);
+//     !IS_DK — Q fragment layout + dO transposed layout (two tensors).  Rings of 3 (2 for dO^T), LDS-DMA from inline asm, one barrier per tile.
 // Reference behaviour restated: the autograd of M/core/transformer/dot_product_attention.py:186-289 (flash-attn / TE backward).
 #include "attn_bwd_args.h"
 #include <stdlib.h>
@@ -42,8 +46,8 @@ struct QTileIt {
 // second arithmetic mask (row < seg_end[key] is visible).
 template <bool IS_DK, bool PACKED>
 __global__ __launch_bounds__(256, 1) void attn_bwd_kv64_kernel(BwdArgs p) {
-  // LDS: fragment-layout ring A [3] (Q) | fragment-layout ring B [3] (dO, IS_DK only) | transposed ring [2] (Q^T or dO^T) | stats [3] x 512 B
-  constexpr int LDS_FA = 0, LDS_FB = 3 * TILEB, LDS_TR = IS_DK ? 6 * TILEB : 3 * TILEB, LDS_ST = LDS_TR + 2 * TILEB;
+  // LDS: ring A [3] (Q) | IS_DK: ring B [3] (dO) / !IS_DK: transposed ring [2] (dO^T) | stats [3] x 512 B
+  constexpr int LDS_FA = 0, LDS_FB = 3 * TILEB, LDS_TR = 3 * TILEB, LDS_ST = IS_DK ? 6 * TILEB : 5 * TILEB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
   const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
@@ -90,15 +94,22 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv64_kernel(BwdArgs p) {
     }
 
   // ---- LDS fragment offsets (attn.hip's layouts) ---------------------------------------------------------------------------------------
-  unsigned foff[8], toff[4];
+  auto swz = [](int row) { return ((row & 3) << 2) | ((row >> 2) & 3); };      // the slot XOR of the dual-use image (header)
+  unsigned foff[8], toff[4], toff8[4];               // toff8: the second transposed read, 8 rows further down
 #pragma unroll
-  for (int ds = 0; ds < 8; ++ds) foff[ds] = l31 * ROWB + (((2 * ds + hi) ^ (l31 & 15)) << 4);       // + 32 qh rows: immediate
+  for (int ds = 0; ds < 8; ++ds) foff[ds] = l31 * ROWB + (((2 * ds + hi) ^ swz(l31 & 15)) << 4);       // + 32 qh rows: immediate
   {
     const int g16 = lane >> 4, i16 = lane & 15, row_l = 4 * (g16 >> 1) + (i16 >> 2);
 #pragma unroll
     for (int db = 0; db < 4; ++db) {
       const int col = 32 * db + 16 * (g16 & 1) + 4 * (i16 & 3);
-      toff[db] = row_l * ROWB + (((col >> 4) ^ ((row_l & 3) << 1)) << 5) + (col & 15) * 2;
+      if (IS_DK) {                                   // Q^T out of the fragment image
+        toff[db] = row_l * ROWB + (((col >> 3) ^ swz(row_l)) << 4) + (col & 7) * 2;
+        toff8[db] = (row_l + 8) * ROWB + (((col >> 3) ^ swz(row_l + 8)) << 4) + (col & 7) * 2;
+      } else {                                       // dO^T out of its own transposed-layout image (32-byte chunk ^ 2 (row & 3))
+        toff[db] = row_l * ROWB + (((col >> 4) ^ ((row_l & 3) << 1)) << 5) + (col & 15) * 2;
+        toff8[db] = toff[db] + 8 * ROWB;
+      }
     }
   }
   // ---- LDS-DMA: wave w moves pieces 4w .. 4w+3 (1 KiB = 4 rows) of each image; swizzles on the SOURCE address ------------------------
@@ -106,7 +117,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv64_kernel(BwdArgs p) {
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     const int row = (wave * 4 + q) * 4 + (lane >> 4), ps = lane & 15;
-    const int fs = ps ^ (row & 15);
+    const int fs = ps ^ swz(row & 15);
     const int ts = (((ps >> 1) ^ ((row & 3) << 1)) << 1) | (ps & 1);
     off_qf[q] = (unsigned)((row * p.q_rs + fs * 8) * 2);
     off_qt[q] = (unsigned)((row * p.q_rs + ts * 8) * 2);
@@ -129,12 +140,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv64_kernel(BwdArgs p) {
     if (wave == 0) vita_lds_dma4(vita_make_rsrc_uniform(t.lp), (unsigned)(lane * 4), lds0 + LDS_ST + slot3 * 512);
     if (IS_DK && wave == 1) vita_lds_dma4(vita_make_rsrc_uniform(t.dlp), (unsigned)(lane * 4), lds0 + LDS_ST + slot3 * 512 + 256);
   };
-  auto dma_tr = [&](const QTileIt& t, int slot2) __attribute__((always_inline)) {          // transposed-layout image (Q or dO)
-    const vita_rsrc_t r = vita_make_rsrc_uniform(IS_DK ? t.qp : t.dop);
+  auto dma_tr = [&](const QTileIt& t, int slot2) __attribute__((always_inline)) {          // !IS_DK: transposed-layout image of dO
+    if (IS_DK) return;
+    const vita_rsrc_t r = vita_make_rsrc_uniform(t.dop);
     unsigned base = lds_w + LDS_TR + slot2 * TILEB;
     asm volatile("" : "+s"(base));
 #pragma unroll
-    for (int q = 0; q < 4; ++q) vita_lds_dma16(r, IS_DK ? off_qt[q] : off_dt[q], base + q * 1024);
+    for (int q = 0; q < 4; ++q) vita_lds_dma16(r, off_dt[q], base + q * 1024);
   };
 
   // ---- iteration space: (query head of the group) x (query chunks that see this key block) x (64-row tiles) ---------------------------
@@ -237,9 +249,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv64_kernel(BwdArgs p) {
     return *(lds_bf16x8*)(uintptr_t)(slot_addr + foff[ds] + qh * 32 * ROWB);
   };
   auto tr_frag = [&](unsigned slot_addr, int t4, int db) __attribute__((always_inline)) {      // rows 16 t4 .. + 15, d block db
-    const unsigned va = slot_addr + toff[db] + 16 * t4 * ROWB;
-    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(va));
-    const s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(va + 8 * ROWB));
+    const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(slot_addr + toff[db] + 16 * t4 * ROWB));
+    const s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(slot_addr + toff8[db] + 16 * t4 * ROWB));
     typedef __attribute__((ext_vector_type(8))) short s16x8;
     const s16x8 ac = __builtin_shufflevector(a, c, 0, 1, 2, 3, 4, 5, 6, 7);
     return __builtin_bit_cast(bf16x8, ac);
@@ -363,7 +374,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv64_kernel(BwdArgs p) {
   auto iteration = [&](const bool has1, const bool has2) __attribute__((always_inline)) {
     if (has2) dma_frag(nx2, s3nn);                       // that slot held tile t-1 (last read before the previous barrier)
     if (has1) dma_tr(nx1, tpar ^ 1);
-    const unsigned trs = lds0 + LDS_TR + tpar * TILEB;
+    const unsigned trs = IS_DK ? lds0 + LDS_FA + s3 * TILEB : lds0 + LDS_TR + tpar * TILEB;        // IS_DK: Q^T out of tile t's Q image
     // trip A: u = 2 t (buffers 0): next half = (tile t, qh 1)
     sp_group(0, s3, 1, cur, true, s3, 0);
     g_group(0, trs, 0, true);
@@ -412,7 +423,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv64_kernel(BwdArgs p) {
 
 template <bool IS_DK, bool PACKED>
 int launch_kv64(const BwdArgs& a, hipStream_t st) {
-  constexpr int lds = (IS_DK ? 8 : 5) * TILEB + 3 * 512;
+  constexpr int lds = (IS_DK ? 6 : 5) * TILEB + 3 * 512;
   static std::atomic<unsigned long long> attr_set{0};
   vita_device_once(attr_set, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kv64_kernel<IS_DK, PACKED>), hipFuncAttributeMaxDynamicSharedMemorySize, lds);
