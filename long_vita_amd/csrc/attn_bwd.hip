@@ -531,7 +531,10 @@ extern "C" int vita_flash_attn_bwd_parts(const vita_attn_bwd_params* p, int part
   if (n_dq > 0x7fffffff || n_kv > 0x7fffffff) return VITA_ERR_UNSUPPORTED;
   const char* only = vita_dev_getenv("VITA_ATTN_BWD_ONLY");     // developer measurement aid: "dq" / "dkv" launch one of the two kernels
   if ((parts & VITA_ATTN_BWD_DKV) && (!only || only[1] == 'k')) {
-    if (vita_attn_bwd_kv64_eligible(a)) {            // whole 256-key tiles: 64 keys per wave, a dK and a dV launch (attn_bwd_kv64.hip)
+    if (vita_attn_bwd_kv64_eligible(a) && vita_attn_bwd_kvp_eligible(a)) {      // r04: both gradients in one launch, S computed once
+      const int rc = vita_attn_bwd_kvp_launch(a, st);
+      if (rc != VITA_OK) return rc;
+    } else if (vita_attn_bwd_kv64_eligible(a)) {            // whole 256-key tiles: 64 keys per wave, a dK and a dV launch (attn_bwd_kv64.hip)
       const int rc = vita_attn_bwd_kv64_launch(a, st);
       if (rc != VITA_OK) return rc;
     } else {

@@ -30,3 +30,7 @@ int vita_attn_bwd_dq64_launch(const BwdArgs& a, hipStream_t st);
 // attn_bwd_kv64.hip: dK and dV with 64 keys per wave, as two launches (causal, whole 256-key tiles)
 bool vita_attn_bwd_kv64_eligible(const BwdArgs& a);
 int vita_attn_bwd_kv64_launch(const BwdArgs& a, hipStream_t st);
+// attn_bwd_kvp.hip (r04): dK AND dV in ONE launch — wave pairs share 64 keys, one wave computes S / P / dV, its partner dP / dS / dK (4 GEMM
+// units instead of kv64's 5); causal, whole 128-key tiles, no packed samples
+bool vita_attn_bwd_kvp_eligible(const BwdArgs& a);
+int vita_attn_bwd_kvp_launch(const BwdArgs& a, hipStream_t st);
