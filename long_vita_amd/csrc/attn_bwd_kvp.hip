@@ -13,8 +13,11 @@
 // M/core/transformer/dot_product_attention.py:186-289); kv64 used the unrounded value there.
 // LDS images: ONE dual-use image per Q tile and per dO tile (slot XOR swz(row), attn_bwd_kv64.hip's header): A reads Q as fragments
 // and dO transposed, B reads dO as fragments and Q transposed — 32 KB of LDS-DMA per 64-row query tile, rings of three.
-// Pipeline per half u (32 query rows), both roles: [16 MFMAs producing S / dP of half u + 1] [16 gradient MFMAs of half u]; the VALU
-// work rides behind them: A — exp2 + bf16 pack of P(u + 1) behind the dV MFMAs, then the LDS hand-over; B — dS(u) behind the dP MFMAs.
+// Pipeline per half u (32 query rows):
+//     B: [16 dP MFMAs of half u + 1 || dS(u), bf16 pack]  [16 dK MFMAs of half u]
+//     A: [16 dV MFMAs of half u || first half of exp2(S(u + 1))]  [16 S MFMAs of half u + 2 || second half, bf16 pack]  hand-over of P(u + 1)
+// A runs its S two halves ahead: the 32 exp2 of a half (the transcendental unit takes ~9 cycles each) then sit behind 32 MFMAs instead
+// of 16 — with S only one half ahead A's second group was VALU-bound and B idled at the barrier (5.75 ms at 16K; this order: see DESIGN 5.1).
 #include "attn_bwd_args.h"
 #include <stdlib.h>
 
@@ -240,8 +243,8 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
       }
     }
   };
-  // 16 slots: X(next half: rows qh_n of the image at `img`) = rows x own fragments -> buffer par ^ 1   (A: S = Q K^T, B: dP = dO V^T);
-  // B with FILL: dS / pack of half `par` behind the MFMAs
+  // 16 slots: X(rows qh_n of the image at `img`) = rows x own fragments -> buffer par ^ 1   (A: S = Q K^T, B: dP = dO V^T);
+  // FILL works on buffer `par`: B — dS / pack of its 16 pairs; A — exp2 of pairs 8 .. 15 (even slots) and their bf16 pack (odd slots)
   auto x_group = [&](int par, unsigned img, int qh_n, bool fill) __attribute__((always_inline)) {
     bf16x8 fr[4];
     fr[0] = frag(img, 0, qh_n); fr[1] = frag(img, 1, qh_n);
@@ -258,12 +261,16 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
         xb[par ^ 1][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[ds & 3], wf[kb][ds], xb[par ^ 1][kb], 0, 0, 0);
       }
       if (ROLE_B && fill) ds_pair(par, s);
+      if (!ROLE_B && fill) {
+        if ((s & 1) == 0) exp_pair(par, 8 + (s >> 1));
+        else pack_pair(par, 8 + (s >> 1));
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
   };
   // 16 slots: gradient^T += X^T(half qh of the image at `img`, transposed reads) packed(par)   (A: dV^T += dO^T P, B: dK^T += Q^T dS);
-  // A with FILL: exp2 of pair s and bf16 pack of pair s - 1 of buffer par ^ 1 behind the MFMAs (an exp2 result is never consumed by
-  // the next instruction); the last pack and the LDS hand-over follow the group
+  // A with FILL: exp2 of pairs 0 .. 7 of buffer par ^ 1 (even slots) and their bf16 pack (odd slots: an exp2 result is never consumed
+  // by the next instruction) behind the MFMAs
   auto g_group = [&](int par, unsigned img, int qh, bool fill) __attribute__((always_inline)) {
     bf16x8 tr[4];
     tr[0] = tr_frag(img, 2 * qh, 0); tr[1] = tr_frag(img, 2 * qh, 1);
@@ -275,14 +282,10 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
       const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
       asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o[kb][db]) : "v"(tr[i & 3]), "v"(pf));
       if (!ROLE_B && fill) {
-        exp_pair(par ^ 1, s);
-        if (s > 0) pack_pair(par ^ 1, s - 1);
+        if ((s & 1) == 0) exp_pair(par ^ 1, s >> 1);
+        else pack_pair(par ^ 1, s >> 1);
       }
       __builtin_amdgcn_sched_barrier(0);
-    }
-    if (!ROLE_B && fill) {
-      pack_pair(par ^ 1, 15);
-      hand_over(par ^ 1);
     }
   };
   auto needs_mask = [&](const QTileIt& t) __attribute__((always_inline)) { return t.diag && t.j * QT < k_off_wg + KWG; };
@@ -320,19 +323,23 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
     for (int e = 0; e < 16; ++e) pack_pair(0, e);
     hand_over(0);
     settle(0);
+    x_group(0, lds0 + IMG_X, 1, false);                  // A runs two halves ahead: S(1) -> buffers 1 (tile 0 always has both halves)
+    if (needs_mask(cur)) mask_half(1, cur.j * QT + 32);
   }
   pair_barrier();
 
   // ---- main loop: one tile = two trips (half qh = buffer parity qh) ------------------------------------------------------------------------
   int s3 = 0, s3n = 1, s3nn = 2;                         // ring slots of tiles t, t+1, t+2
-  // one trip: half u = (tile in ring slot `sl`, half qh) in buffers `par`; next half = (tile `tn` in slot `sln`, half qh_n) if has_next
-  auto trip = [&](int par, int sl, int qh, const QTileIt& tn, int sln, int qh_n, const bool has_next) __attribute__((always_inline)) {
-    const unsigned img_x_n = lds0 + IMG_X + sln * TILEB, img_g = lds0 + IMG_G + sl * TILEB;
+  // one trip: half u = (tile in ring slot `sl`, half qh) in buffers `par`; half u + 1 = (tile `tn` in slot `sln`, half qh_n) if has_next;
+  // half u + 2 = (tile nx1 in slot s3n, half qh_2) if has_next2 (it always lies in tile t + 1)
+  auto trip = [&](int par, int sl, int qh, const QTileIt& tn, int sln, int qh_n, const bool has_next, int qh_2, const bool has_next2)
+      __attribute__((always_inline)) {
+    const unsigned img_g = lds0 + IMG_G + sl * TILEB;
     if (ROLE_B) {
       take_over(par);                                    // P(u), written by A before the last barrier
       load_stat(lds0 + LDS_ST + sl * 512, qh);           // delta of half u
       if (has_next) {
-        x_group(par, img_x_n, qh_n, true);               // dP(u + 1)  ||  dS(u)
+        x_group(par, lds0 + IMG_X + sln * TILEB, qh_n, true);               // dP(u + 1)  ||  dS(u)
       } else {
 #pragma unroll
         for (int e = 0; e < 16; ++e) ds_pair(par, e);
@@ -340,19 +347,28 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
       settle(par);
       g_group(par, img_g, qh, false);                    // dK^T += Q^T dS(u)
     } else {
+      // A holds P(u) packed in pk[par] and the raw (masked) S(u + 1) in buffers par ^ 1
+      if (has_next) load_stat(lds0 + LDS_ST + sln * 512, qh_n);             // lse of half u + 1
+      g_group(par, img_g, qh, has_next);                 // dV^T += dO^T P(u)  ||  exp2 / pack of pairs 0 .. 7 of S(u + 1)
       if (has_next) {
-        x_group(par, img_x_n, qh_n, false);              // S(u + 1)
-        if (needs_mask(tn)) mask_half(par ^ 1, tn.j * QT + 32 * qh_n);       // wave-uniform, diagonal tiles only
-        load_stat(lds0 + LDS_ST + sln * 512, qh_n);      // lse of half u + 1
+        if (has_next2) {
+          x_group(par ^ 1, lds0 + IMG_X + s3n * TILEB, qh_2, true);        // S(u + 2) -> buffers par  ||  pairs 8 .. 15 of S(u + 1)
+        } else {
+#pragma unroll
+          for (int e = 8; e < 16; ++e) exp_pair(par ^ 1, e);
+#pragma unroll
+          for (int e = 8; e < 16; ++e) pack_pair(par ^ 1, e);
+        }
+        hand_over(par ^ 1);                              // P(u + 1) -> the partner, before the barrier that ends this trip
+        if (has_next2 && needs_mask(nx1)) mask_half(par, nx1.j * QT + 32 * qh_2);       // wave-uniform, diagonal tiles only
       }
-      g_group(par, img_g, qh, has_next);                 // dV^T += dO^T P(u)  ||  P(u + 1) = exp2(...), pack; then the hand-over
     }
   };
   auto iteration = [&](const bool has1, const bool has2) __attribute__((always_inline)) {
     if (has2) dma_tile(nx2, s3nn);                       // that slot held tile t-1 (last read before the previous tile barrier)
-    trip(0, s3, 0, cur, s3, 1, true);                    // u = 2 t:     next half = (tile t, rows 32 ..)
+    trip(0, s3, 0, cur, s3, 1, true, 0, has1);           // u = 2 t:     u + 1 = (tile t, rows 32 ..),    u + 2 = (tile t + 1, rows 0 ..)
     pair_barrier();
-    trip(1, s3, 1, nx1, s3n, 0, has1);                   // u = 2 t + 1: next half = (tile t + 1, rows 0 ..)
+    trip(1, s3, 1, nx1, s3n, 0, has1, 1, has1);          // u = 2 t + 1: u + 1 = (tile t + 1, rows 0 ..), u + 2 = (tile t + 1, rows 32 ..)
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
     cur = nx1; nx1 = nx2;

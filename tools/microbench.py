@@ -64,7 +64,8 @@ def bench_attn(S, Hq=40, Hkv=8, D=128, causal=True, B=1, tag=""):
 def bench_attn_bwd(S, Hq=40, Hkv=8, D=128, tag=""):
     """Attention backward (dQ pass + dK / dV pass + the delta pre-pass) on a plain causal sequence; VITA_ATTN_BWD_ONLY=dq|dkv
     times one pass alone (developer switch in attn_bwd.hip).  flops: 5 GEMM units of the forward's 2 (algorithmic); the 64-rows-per-wave
-    kernels execute 8 (dQ: S, dP, dQ; dK: S, dP, dK; dV: S, dV), the general kernels (VITA_ATTN_BWD64=0) 7."""
+    kernels executed 8 through r03 (dQ: S, dP, dQ; dK: S, dP, dK; dV: S, dV) and execute 7 since r04 (attn_bwd_kvp.hip: dK + dV in one
+    launch, S once; VITA_ATTN_BWD_KVP=0 restores the two launches), the general kernels (VITA_ATTN_BWD64=0) 7."""
     q = torch.randn(1, S, Hq, D, device=DEV).bfloat16()
     k = torch.randn(1, S, Hkv, D, device=DEV).bfloat16()
     v = torch.randn(1, S, Hkv, D, device=DEV).bfloat16()
@@ -74,7 +75,8 @@ def bench_attn_bwd(S, Hq=40, Hkv=8, D=128, tag=""):
     pairs = S * (S + 1) / 2
     unit = 2.0 * D * Hq * pairs
     fast = os.environ.get("VITA_ATTN_BWD64", "1") != "0"
-    for only, units in (("", 8 if fast else 7), ("dq", 3), ("dkv", 5 if fast else 4)):
+    two_launches = fast and os.environ.get("VITA_ATTN_BWD_KVP", "1") == "0"
+    for only, units in (("", 8 if two_launches else 7), ("dq", 3), ("dkv", 5 if two_launches else 4)):
         if only:
             os.environ["VITA_ATTN_BWD_ONLY"] = only
         med, best = timeit(lambda: ops.flash_attn_bwd(q, k, v, o, d_o, lse, dq5=dq, dk=dk, dv=dv), warmup=1, iters=3)
