@@ -23,7 +23,10 @@
 namespace {
 
 constexpr int kMaxChunks = kBwdMaxChunks;
-constexpr int D = 128, ROWB = 256;     // bytes per row
+// r04: both kernels are templates on the head size HD = 128 (the decoder) or 64 (InternViT's attention: the ViT's backward through its
+// native head size instead of zero-padded d = 128 copies, stage 2 trains the encoder).  What depends on HD: bytes per row (ROWB), the
+// k-steps over d (HD / 16) and output blocks (HD / 32), rows per 1-KiB DMA piece, and the LDS swizzles below (a 128-byte row is half a
+// bank period, so the row bits that select the slot move up by one).
 
 typedef __attribute__((address_space(3))) char lds_char;
 typedef __attribute__((address_space(3))) const bf16x8 lds_bf16x8;
@@ -33,19 +36,23 @@ typedef __attribute__((address_space(1))) const void gvoid;
 typedef __attribute__((address_space(3))) void lvoid;
 typedef __attribute__((ext_vector_type(8))) short s16x8;
 
-__device__ __forceinline__ int frag_off(int row, int slot) { return row * ROWB + ((slot ^ (row & 15)) << 4); }
-__device__ __forceinline__ int tr_off(int row, int chunk, int b) { return row * ROWB + ((chunk ^ ((row & 3) << 1)) << 5) + b; }
+template <int HD> __device__ __forceinline__ int frag_key(int row) { return HD == 128 ? (row & 15) : ((row >> 1) & 7); }
+template <int HD> __device__ __forceinline__ int tr_key(int row) { return HD == 128 ? ((row & 3) << 1) : (((row >> 1) & 1) << 1); }
+template <int HD> __device__ __forceinline__ int frag_off(int row, int slot) { return row * (2 * HD) + ((slot ^ frag_key<HD>(row)) << 4); }
+template <int HD> __device__ __forceinline__ int tr_off(int row, int chunk, int b) { return row * (2 * HD) + ((chunk ^ tr_key<HD>(row)) << 5) + b; }
 
 // DMA one 1-KiB piece (4 rows x 256 B) of a [rows][128] bf16 tile into LDS; tile = descriptor of its first row (wave-uniform),
 // rows_valid = rows that exist (later ones are clamped, masked afterwards); lane -> (row piece*4 + lane/16, physical 16-B slot
 // lane%16); `tr` selects the layout (source-side swizzle).  Issued from inline asm (vita_lds_dma16, see vita_common.h): through the
 // builtin hipcc put an s_waitcnt vmcnt(0) in front of the first ds_read_b64_tr_b16 of every tile — the prefetch of the next tile was
 // a blocking load, the reason the round-1 kernels ran at 0.39 / 0.52 PFLOP/s.
+template <int HD>
 __device__ __forceinline__ void dma_piece(vita_rsrc_t tile, int64_t rs, int rows_valid, int piece, int lane, bool tr,
                                           unsigned lds_dst) {
-  int row = piece * 4 + (lane >> 4);
-  const int ps = lane & 15;
-  const int ls = tr ? ((((ps >> 1) ^ ((row & 3) << 1)) << 1) | (ps & 1)) : (ps ^ (row & 15));
+  constexpr int LPR = HD / 8;                              // lanes (16-byte slots) per row: a 1-KiB piece is 64 / LPR rows
+  int row = piece * (64 / LPR) + lane / LPR;
+  const int ps = lane % LPR;
+  const int ls = tr ? ((((ps >> 1) ^ tr_key<HD>(row)) << 1) | (ps & 1)) : (ps ^ frag_key<HD>(row));
   const int r = row < rows_valid ? row : rows_valid - 1;
   vita_lds_dma16(tile, (unsigned)(r * rs * 2 + ls * 16), (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_dst + piece * 1024)));
 }
@@ -54,17 +61,19 @@ __device__ __forceinline__ void dma_words32(vita_rsrc_t base, int lane, unsigned
   vita_lds_dma4(base, (unsigned)((lane & 31) * 4), (unsigned)__builtin_amdgcn_readfirstlane((int)lds_dst));
 }
 
+template <int HD>
 __device__ __forceinline__ bf16x8 read_frag(unsigned tile, int row, int slot) {
-  return *(lds_bf16x8*)(uintptr_t)(tile + frag_off(row, slot));
+  return *(lds_bf16x8*)(uintptr_t)(tile + frag_off<HD>(row, slot));
 }
 // transposed fragment: rows r0 + {0..3} and r0 + 8 + {0..3} (r0 already includes 4*(lane>>5) and the
 // lane's row inside its 16-lane group), 32 columns starting at 32*db
+template <int HD>
 __device__ __forceinline__ bf16x8 read_tr(unsigned tile, int lane, int row_base, int db) {
   const int g16 = lane >> 4, i16 = lane & 15;
   const int row = row_base + 4 * (g16 >> 1) + (i16 >> 2);
   const int col = 32 * db + 16 * (g16 & 1) + 4 * (i16 & 3);
-  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(tile + tr_off(row, col >> 4, (col & 15) * 2)));
-  const s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(tile + tr_off(row + 8, col >> 4, (col & 15) * 2)));
+  const s16x4 a = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(tile + tr_off<HD>(row, col >> 4, (col & 15) * 2)));
+  const s16x4 c = __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4*)(uintptr_t)(tile + tr_off<HD>(row + 8, col >> 4, (col & 15) * 2)));
   return __builtin_bit_cast(bf16x8, __builtin_shufflevector(a, c, 0, 1, 2, 3, 4, 5, 6, 7));
 }
 __device__ __forceinline__ bf16x8 pack8(const f32x16& s, int base) {
@@ -81,11 +90,14 @@ constexpr int QT_DQ = 128;      // query rows per workgroup
 constexpr int KT_DQ = 64;       // keys per tile
 // LDS per stage: K frag (16 KiB) | K tr (16 KiB) | V frag (16 KiB); a ring of three stages, tiles fetched two ahead (a tile of
 // 48 MFMAs per wave is ~0.7 us of work against 1-2 us of memory latency: with one tile in flight the kernel waited on every tile)
-constexpr int DQ_STAGE = 3 * KT_DQ * ROWB;
 constexpr int DQ_NSTAGE = 3;
-constexpr int DQ_DMA_PER_STAGE = 12;   // LDS-DMA instructions a wave issues per stage (3 images x 4 pieces)
 
+template <int HD>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
+  constexpr int ROWB = 2 * HD, NDS = HD / 16, NDB = HD / 32;
+  constexpr int DQ_STAGE = 3 * KT_DQ * ROWB;
+  constexpr int PPW = KT_DQ * ROWB / 1024 / 4;             // 1-KiB pieces of a 64-row image per wave (4 / 2)
+  constexpr int DQ_DMA_PER_STAGE = 3 * PPW;                // LDS-DMA instructions a wave issues per stage (3 images)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -113,12 +125,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
   const int wg_first_start = p.seg_start ? p.seg_start[(int64_t)qc * p.chunk_len + qti * QT_DQ] : 0;
   const int wg_last_start = p.seg_start ? p.seg_start[(int64_t)qc * p.chunk_len + q_last_wg] : 0;
 
-  bf16x8 qf[8], dof[8];
+  bf16x8 qf[NDS], dof[NDS];
   {
     const bf16_t* qp = p.q + q_row * p.q_rs + (int64_t)kvh * p.q_gs + (int64_t)hq * p.q_hs + hi * 8;
     const bf16_t* dp = p.d_o + q_row * p.do_rs + (int64_t)head * p.do_hs + hi * 8;
 #pragma unroll
-    for (int ds = 0; ds < 8; ++ds) {
+    for (int ds = 0; ds < NDS; ++ds) {
       qf[ds] = *reinterpret_cast<const bf16x8*>(qp + ds * 16);
       dof[ds] = *reinterpret_cast<const bf16x8*>(dp + ds * 16);
     }
@@ -128,12 +140,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
   // consume the loads here: the compiler then waits for them HERE and not at their first use inside the loop, where its
   // s_waitcnt vmcnt() would also wait for the LDS-DMA pieces in flight (issued from asm, it does not know about them)
 #pragma unroll
-  for (int ds = 0; ds < 8; ++ds) asm volatile("" :: "v"(qf[ds]), "v"(dof[ds]));
+  for (int ds = 0; ds < NDS; ++ds) asm volatile("" :: "v"(qf[ds]), "v"(dof[ds]));
   asm volatile("" :: "v"(lse2), "v"(dlt));
 
-  f32x16 dq_acc[4];
+  f32x16 dq_acc[NDB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NDB; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) dq_acc[i][r] = 0.f;
 
@@ -152,13 +164,13 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
     const int valid = p.chunk_len - j * KT_DQ;
     const vita_rsrc_t kt0 = vita_make_rsrc(kbase + row0 * p.k_rs);
     const vita_rsrc_t vt0 = vita_make_rsrc(vbase + row0 * p.v_rs);
-    // 16 pieces per 64-row image; 4 waves -> 4 pieces each per image
+    // 16 (HD = 64: 8) pieces per 64-row image; 4 waves -> PPW pieces each per image
 #pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      const int piece = wave * 4 + q;
-      dma_piece(kt0, p.k_rs, valid, piece, lane, false, sl);
-      dma_piece(kt0, p.k_rs, valid, piece, lane, true, sl + KT_DQ * ROWB);
-      dma_piece(vt0, p.v_rs, valid, piece, lane, false, sl + 2 * KT_DQ * ROWB);
+    for (int q = 0; q < PPW; ++q) {
+      const int piece = wave * PPW + q;
+      dma_piece<HD>(kt0, p.k_rs, valid, piece, lane, false, sl);
+      dma_piece<HD>(kt0, p.k_rs, valid, piece, lane, true, sl + KT_DQ * ROWB);
+      dma_piece<HD>(vt0, p.v_rs, valid, piece, lane, false, sl + 2 * KT_DQ * ROWB);
     }
   };
 
@@ -201,9 +213,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
 #pragma unroll
         for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-        for (int ds = 0; ds < 8; ++ds) {
-          const bf16x8 ka = read_frag(kf, 32 * h + l31, 2 * ds + hi);
-          const bf16x8 va = read_frag(vf, 32 * h + l31, 2 * ds + hi);
+        for (int ds = 0; ds < NDS; ++ds) {
+          const bf16x8 ka = read_frag<HD>(kf, 32 * h + l31, 2 * ds + hi);
+          const bf16x8 va = read_frag<HD>(vf, 32 * h + l31, 2 * ds + hi);
           s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ka, qf[ds], s, 0, 0, 0);       // S^T[key, q]
           dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(va, dof[ds], dp, 0, 0, 0);    // dP^T[key, q]
         }
@@ -227,8 +239,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
           // VALU result -> inline-asm MFMA operand: the compiler does not know the asm is an MFMA and inserts no wait states
           asm volatile("s_nop 4" : "+v"(dsf));
 #pragma unroll
-          for (int db = 0; db < 4; ++db) {
-            const bf16x8 ktf = read_tr(kt, lane, 32 * h + 16 * t, db);               // K^T[d, keys]
+          for (int db = 0; db < NDB; ++db) {
+            const bf16x8 ktf = read_tr<HD>(kt, lane, 32 * h + 16 * t, db);           // K^T[d, keys]
             asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(dq_acc[db]) : "v"(ktf), "v"(dsf));
           }
         }
@@ -243,10 +255,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
   }
 
   // the inline-asm MFMAs are invisible to the compiler's hazard tracking: wait for the matrix pipe, accumulators tied to the wait
-  asm volatile("s_nop 15\n\ts_nop 15" : "+a"(dq_acc[0]), "+a"(dq_acc[1]), "+a"(dq_acc[2]), "+a"(dq_acc[3]));
+  if constexpr (NDB == 4) asm volatile("s_nop 15\n\ts_nop 15" : "+a"(dq_acc[0]), "+a"(dq_acc[1]), "+a"(dq_acc[2]), "+a"(dq_acc[3]));
+  else asm volatile("s_nop 15\n\ts_nop 15" : "+a"(dq_acc[0]), "+a"(dq_acc[1]));
   bf16_t* op = p.dq + q_row * p.dq_rs + (int64_t)kvh * p.dq_gs + (int64_t)hq * p.dq_hs;
 #pragma unroll
-  for (int db = 0; db < 4; ++db)
+  for (int db = 0; db < NDB; ++db)
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
       const int d = 32 * db + 8 * rg + 4 * hi;
@@ -264,11 +277,14 @@ constexpr int QT_KV = 32;       // query rows per step
 // The workgroup's K / V fragments live in registers (they are the same for every step).  LDS: a ring of four stages of
 // [Q frag 8 KiB | Q tr 8 | dO frag 8 | dO tr 8 | lse, delta, segment starts of the 32 rows (2 KiB)], steps fetched three ahead:
 // a 32-row step is 32 MFMAs per wave (~0.45 us) against 1-2 us of memory latency.
-constexpr int KV_STAGE = 4 * QT_KV * ROWB + 2048;
 constexpr int KV_NSTAGE = 4;
-constexpr int KV_DMA_PER_STAGE = 10;   // LDS-DMA instructions a wave issues per stage (4 images x 2 pieces + two statistics pieces)
 
+template <int HD>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
+  constexpr int ROWB = 2 * HD, NDS = HD / 16, NDB = HD / 32;
+  constexpr int KV_STAGE = 4 * QT_KV * ROWB + 2048;
+  constexpr int PPW = QT_KV * ROWB / 1024 / 4;             // 1-KiB pieces of a 32-row image per wave (2 / 1)
+  constexpr int KV_DMA_PER_STAGE = 4 * PPW + 2;            // LDS-DMA instructions a wave issues per stage (4 images + two statistics pieces)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -287,23 +303,23 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
   const int64_t k_row0 = p.kv_row[kc] + k_off;
 
   // K / V fragments of this wave's 32 keys (MFMA B operand: lane -> key l31, k slot 2 ds + hi), straight from global memory
-  bf16x8 kfr[8], vfr[8];
+  bf16x8 kfr[NDS], vfr[NDS];
   {
     const bf16_t* kb = p.k + (int64_t)kvh * p.k_hs + (k_row0 + wave * 32 + l31) * p.k_rs + hi * 8;
     const bf16_t* vb = p.v + (int64_t)kvh * p.v_hs + (k_row0 + wave * 32 + l31) * p.v_rs + hi * 8;
 #pragma unroll
-    for (int ds = 0; ds < 8; ++ds) {
+    for (int ds = 0; ds < NDS; ++ds) {
       kfr[ds] = *reinterpret_cast<const bf16x8*>(kb + ds * 16);
       vfr[ds] = *reinterpret_cast<const bf16x8*>(vb + ds * 16);
     }
     // consume the loads here (see the dQ kernel): no compiler-placed vmcnt wait inside the loop
 #pragma unroll
-    for (int ds = 0; ds < 8; ++ds) asm volatile("" :: "v"(kfr[ds]), "v"(vfr[ds]));
+    for (int ds = 0; ds < NDS; ++ds) asm volatile("" :: "v"(kfr[ds]), "v"(vfr[ds]));
   }
 
-  f32x16 dk_acc[4], dv_acc[4];
+  f32x16 dk_acc[NDB], dv_acc[NDB];
 #pragma unroll
-  for (int i = 0; i < 4; ++i)
+  for (int i = 0; i < NDB; ++i)
 #pragma unroll
     for (int r = 0; r < 16; ++r) { dk_acc[i][r] = 0.f; dv_acc[i][r] = 0.f; }
 
@@ -321,14 +337,14 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
     const int64_t row0 = (int64_t)qc * p.chunk_len + qt * QT_KV;
     const vita_rsrc_t qb = vita_make_rsrc(p.q + (int64_t)kvh * p.q_gs + (int64_t)hq * p.q_hs + row0 * p.q_rs);
     const vita_rsrc_t db = vita_make_rsrc(p.d_o + (int64_t)head * p.do_hs + row0 * p.do_rs);
-    // 8 pieces per 32-row image: 4 waves x 2
+    // 8 (HD = 64: 4) pieces per 32-row image: 4 waves x PPW
 #pragma unroll
-    for (int q = 0; q < 2; ++q) {
-      const int piece = wave * 2 + q;
-      dma_piece(qb, p.q_rs, QT_KV, piece, lane, false, sl);
-      dma_piece(qb, p.q_rs, QT_KV, piece, lane, true, sl + QT_KV * ROWB);
-      dma_piece(db, p.do_rs, QT_KV, piece, lane, false, sl + 2 * QT_KV * ROWB);
-      dma_piece(db, p.do_rs, QT_KV, piece, lane, true, sl + 3 * QT_KV * ROWB);
+    for (int q = 0; q < PPW; ++q) {
+      const int piece = wave * PPW + q;
+      dma_piece<HD>(qb, p.q_rs, QT_KV, piece, lane, false, sl);
+      dma_piece<HD>(qb, p.q_rs, QT_KV, piece, lane, true, sl + QT_KV * ROWB);
+      dma_piece<HD>(db, p.do_rs, QT_KV, piece, lane, false, sl + 2 * QT_KV * ROWB);
+      dma_piece<HD>(db, p.do_rs, QT_KV, piece, lane, true, sl + 3 * QT_KV * ROWB);
     }
     // statistics of the 32 rows, by DMA as well (no register round trip, so nothing waits on it).  Every wave issues two pieces,
     // so that one counted vmcnt serves all waves: wave 0 the ones that are read (lse at +0, delta at +256), wave 1 the segment starts
@@ -393,9 +409,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
 #pragma unroll
       for (int r = 0; r < 16; ++r) { s[r] = 0.f; dp[r] = 0.f; }
 #pragma unroll
-      for (int ds = 0; ds < 8; ++ds) {
-        const bf16x8 qa = read_frag(qfr, l31, 2 * ds + hi);
-        const bf16x8 da = read_frag(dofr, l31, 2 * ds + hi);
+      for (int ds = 0; ds < NDS; ++ds) {
+        const bf16x8 qa = read_frag<HD>(qfr, l31, 2 * ds + hi);
+        const bf16x8 da = read_frag<HD>(dofr, l31, 2 * ds + hi);
         s = __builtin_amdgcn_mfma_f32_32x32x16_bf16(qa, kfr[ds], s, 0, 0, 0);       // S[q, key]
         dp = __builtin_amdgcn_mfma_f32_32x32x16_bf16(da, vfr[ds], dp, 0, 0, 0);     // dP[q, key]
       }
@@ -434,10 +450,10 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
         // VALU result -> inline-asm MFMA operand: the compiler does not know the asm is an MFMA and inserts no wait states
         asm volatile("s_nop 4" : "+v"(pf), "+v"(dsf));
 #pragma unroll
-        for (int db = 0; db < 4; ++db) {
-          const bf16x8 dot = read_tr(dotr, lane, 16 * t, db);                        // dO^T[d, q]
+        for (int db = 0; db < NDB; ++db) {
+          const bf16x8 dot = read_tr<HD>(dotr, lane, 16 * t, db);                    // dO^T[d, q]
           asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(dv_acc[db]) : "v"(dot), "v"(pf));
-          const bf16x8 qtf = read_tr(qtr, lane, 16 * t, db);                         // Q^T[d, q]
+          const bf16x8 qtf = read_tr<HD>(qtr, lane, 16 * t, db);                     // Q^T[d, q]
           asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(dk_acc[db]) : "v"(qtf), "v"(dsf));
         }
       }
@@ -451,13 +467,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
     normalize(hq_c, qc_c, qt_c);
   }
 
-  asm volatile("s_nop 15\n\ts_nop 15" : "+a"(dk_acc[0]), "+a"(dk_acc[1]), "+a"(dk_acc[2]), "+a"(dk_acc[3]), "+a"(dv_acc[0]),
-               "+a"(dv_acc[1]), "+a"(dv_acc[2]), "+a"(dv_acc[3]));
+  if constexpr (NDB == 4)
+    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(dk_acc[0]), "+a"(dk_acc[1]), "+a"(dk_acc[2]), "+a"(dk_acc[3]), "+a"(dv_acc[0]),
+                 "+a"(dv_acc[1]), "+a"(dv_acc[2]), "+a"(dv_acc[3]));
+  else asm volatile("s_nop 15\n\ts_nop 15" : "+a"(dk_acc[0]), "+a"(dk_acc[1]), "+a"(dv_acc[0]), "+a"(dv_acc[1]));
   const int64_t orow = k_row0 + wave * 32 + l31;
   bf16_t* okp = p.dk + orow * p.dk_rs + (int64_t)kvh * p.dk_hs;
   bf16_t* ovp = p.dv + orow * p.dv_rs + (int64_t)kvh * p.dv_hs;
 #pragma unroll
-  for (int db = 0; db < 4; ++db)
+  for (int db = 0; db < NDB; ++db)
 #pragma unroll
     for (int rg = 0; rg < 4; ++rg) {
       const int d = 32 * db + 8 * rg + 4 * hi;
@@ -484,7 +502,7 @@ extern "C" int vita_flash_attn_bwd_parts(const vita_attn_bwd_params* p, int part
   if (!(parts & (VITA_ATTN_BWD_DQ | VITA_ATTN_BWD_DKV))) return VITA_ERR_INVALID_ARG;
   if (!p || !p->q || !p->k || !p->v || !p->d_o || !p->lse || !p->delta) return VITA_ERR_INVALID_ARG;
   if (((parts & VITA_ATTN_BWD_DQ) && !p->dq) || ((parts & VITA_ATTN_BWD_DKV) && (!p->dk || !p->dv))) return VITA_ERR_INVALID_ARG;
-  if (p->head_dim != 128) return VITA_ERR_UNSUPPORTED;
+  if (p->head_dim != 128 && p->head_dim != 64) return VITA_ERR_UNSUPPORTED;
   if (p->n_q_heads <= 0 || p->n_kv_heads <= 0 || p->n_q_heads % p->n_kv_heads) return VITA_ERR_INVALID_ARG;
   if (p->n_q_chunks <= 0 || p->n_kv_chunks <= 0 || p->n_q_chunks > kMaxChunks || p->n_kv_chunks > kMaxChunks)
     return VITA_ERR_UNSUPPORTED;
@@ -507,7 +525,7 @@ extern "C" int vita_flash_attn_bwd_parts(const vita_attn_bwd_params* p, int part
   a.dq_gs = p->dq_group_stride ? p->dq_group_stride : p->dq_head_stride * G;
   a.dk = (bf16_t*)p->dk; a.dk_rs = p->dk_row_stride; a.dk_hs = p->dk_head_stride;
   a.dv = (bf16_t*)p->dv; a.dv_rs = p->dv_row_stride; a.dv_hs = p->dv_head_stride;
-  a.n_q_heads = p->n_q_heads; a.n_kv_heads = p->n_kv_heads;
+  a.n_q_heads = p->n_q_heads; a.n_kv_heads = p->n_kv_heads; a.head_dim = p->head_dim;
   a.chunk_len = (int)p->chunk_len; a.n_q_chunks = p->n_q_chunks; a.n_kv_chunks = p->n_kv_chunks;
   a.n_q_rows = (int)(p->n_q_chunks * p->chunk_len);
   a.scale = p->softmax_scale; a.scale_log2e = p->softmax_scale * 1.44269504088896340736f;
@@ -519,12 +537,12 @@ extern "C" int vita_flash_attn_bwd_parts(const vita_attn_bwd_params* p, int part
 
   hipStream_t st = (hipStream_t)stream;
   static std::atomic<unsigned long long> attr_set{0};
-  constexpr int lds_dq = DQ_NSTAGE * DQ_STAGE, lds_kv = KV_NSTAGE * KV_STAGE;
+  constexpr int lds_dq = DQ_NSTAGE * 3 * KT_DQ * 256, lds_kv = KV_NSTAGE * (4 * QT_KV * 256 + 2048);        // the HD = 128 sizes (HD = 64 needs less)
   vita_device_once(attr_set, [&] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_dq);
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel),
-                              hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_dq);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_dq);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
   });
   const int64_t n_dq = (int64_t)p->n_q_heads * p->n_q_chunks * (p->chunk_len / QT_DQ);
   const int64_t n_kv = (int64_t)p->n_kv_heads * p->n_kv_chunks * (p->chunk_len / KT_KV);
@@ -537,16 +555,20 @@ extern "C" int vita_flash_attn_bwd_parts(const vita_attn_bwd_params* p, int part
     } else if (vita_attn_bwd_kv64_eligible(a)) {            // whole 256-key tiles: 64 keys per wave, a dK and a dV launch (attn_bwd_kv64.hip)
       const int rc = vita_attn_bwd_kv64_launch(a, st);
       if (rc != VITA_OK) return rc;
+    } else if (p->head_dim == 64) {
+      hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, dim3((unsigned)n_kv), dim3(256), lds_kv, st, a);
     } else {
-      hipLaunchKernelGGL(attn_bwd_dkv_kernel, dim3((unsigned)n_kv), dim3(256), lds_kv, st, a);
+      hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, dim3((unsigned)n_kv), dim3(256), lds_kv, st, a);
     }
   }
   if ((parts & VITA_ATTN_BWD_DQ) && (!only || only[1] == 'q')) {
     if (vita_attn_bwd_dq64_eligible(a)) {            // causal whole 256-row tiles: 64 query rows per wave (attn_bwd64.hip)
       const int rc = vita_attn_bwd_dq64_launch(a, st);
       if (rc != VITA_OK) return rc;
+    } else if (p->head_dim == 64) {
+      hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, dim3((unsigned)n_dq), dim3(256), lds_dq, st, a);
     } else {
-      hipLaunchKernelGGL(attn_bwd_dq_kernel, dim3((unsigned)n_dq), dim3(256), lds_dq, st, a);
+      hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, dim3((unsigned)n_dq), dim3(256), lds_dq, st, a);
     }
   }
   return vita_check_launch();

@@ -361,6 +361,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(BwdArgs p) {
 }  // namespace
 
 bool vita_attn_bwd_dq64_eligible(const BwdArgs& a) {
+  if (a.head_dim != 128) return false;                       // the 64-rows-per-wave kernels are built for d = 128
   if (a.chunk_len % QTILE) return false;
   if (a.seg_start && (a.n_q_chunks != 1 || a.n_kv_chunks != 1)) return false;      // packed samples: one chunk
   for (int i = 0; i < a.n_q_chunks; ++i) {           // every query chunk meets its own keys (the diagonal) in this launch

@@ -14,7 +14,7 @@ struct BwdArgs {
   bf16_t* dq; int64_t dq_rs, dq_hs, dq_gs;
   bf16_t* dk; int64_t dk_rs, dk_hs;                   // same row space as k / v
   bf16_t* dv; int64_t dv_rs, dv_hs;
-  int n_q_heads, n_kv_heads;
+  int n_q_heads, n_kv_heads, head_dim;
   int chunk_len, n_q_chunks, n_kv_chunks, n_q_rows;
   float scale, scale_log2e;
   const int* seg_start;   // packed sequences (single chunk): first row of each query row's segment, or null

@@ -437,6 +437,7 @@ int launch_kv64(const BwdArgs& a, hipStream_t st) {
 }  // namespace
 
 bool vita_attn_bwd_kv64_eligible(const BwdArgs& a) {
+  if (a.head_dim != 128) return false;                       // the 64-rows-per-wave kernels are built for d = 128
   if (a.chunk_len % KTILE) return false;                    // (a key chunk sees whole chunks, its own from the diagonal on, or nothing)
   if (a.seg_start && (a.n_q_chunks != 1 || a.n_kv_chunks != 1)) return false;      // packed samples: one chunk
   if ((int64_t)QT * a.q_rs * 2 > 0x7fffffffLL || (int64_t)QT * a.do_rs * 2 > 0x7fffffffLL) return false;
