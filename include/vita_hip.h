@@ -183,6 +183,17 @@ int vita_gemm_bf16_tn(const void* At, int64_t lda, const void* Wt, int64_t ldw, 
 /* Skinny-M GEMM for the logits-masked LM head (n_sel rows, M <= 16):
  *   logits[M, N] fp32-accumulated, stored bf16 (out_f32 == 0) or fp32 (out_f32 != 0).
  * Replaces torch.matmul on the masked rows, M/core/tensor_parallel/layers.py:402-409. */
+/* ABI 15: vita_gemm_bf16_tn with the contraction cut into `splits` ranges — for weight gradients whose output is only a few 256 x 256
+ * tiles over a long token contraction (the ViT's linears; the decoder's narrow qkv / proj gradients).  Every (split, tile) workgroup
+ * writes an fp32 partial to `workspace` ([splits][M][N] floats, vita_gemm_tn_splitk_workspace_bytes), a second kernel sums the splits and
+ * rounds once to bf16.  splits <= 1: vita_gemm_bf16_tn.  K / 64 K-tiles are dealt ceil(K / 64 / splits) per split. */
+size_t vita_gemm_tn_splitk_workspace_bytes(int64_t M, int64_t N, int splits);
+int vita_gemm_bf16_tn_splitk(const void* At, int64_t lda, const void* Wt, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N,
+                             int64_t K, int splits, void* workspace, void* stream);
+/* ABI 15: out[c] += sum over rows of float(x[r][c]) — grad_bias = grad_output.sum(dim=0) (M/core/tensor_parallel/layers.py:524) in one
+ * pass over grad_output.  out: fp32 [cols], zeroed by the caller; cols % 4 == 0. */
+int vita_colsum_bf16(const void* x, int64_t ldx, float* out, int64_t rows, int cols, void* stream);
+
 int vita_gemm_skinny_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C,
                           int64_t ldc, int M, int64_t N, int64_t K, int out_f32, void* stream);
 

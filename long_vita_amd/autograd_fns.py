@@ -42,10 +42,14 @@ def wgrad(dy_t: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
     return ops.gemm(dy_t, transpose(x))
 
 
-def bias_grad(dy_t: torch.Tensor) -> torch.Tensor:
-    """grad_bias = grad_output.sum(dim=0) (layers.py:524) as a GEMM against a block of ones: dy_t [N, M] -> [N]."""
-    ones = torch.ones(4, dy_t.shape[1], dtype=dy_t.dtype, device=dy_t.device)
-    return ops.gemm(dy_t, ones)[:, 0].contiguous()
+def bias_grad(dy: torch.Tensor) -> torch.Tensor:
+    """grad_bias = grad_output.sum(dim=0) (layers.py:524): dy [rows, N] -> [N], one pass over dy (vita_colsum_bf16, fp32 sums; through
+    r03 a GEMM against a block of ones: a whole-sequence contraction on N / 256 workgroups)."""
+    if dy.shape[1] % 4 or dy.stride(1) != 1:
+        dy = dy.contiguous()
+        if dy.shape[1] % 4:
+            return dy.float().sum(dim=0).to(dy.dtype)        # odd widths (test-sized layers only)
+    return ops.colsum(dy).to(dy.dtype)
 
 
 def _tp():
@@ -65,19 +69,14 @@ def weight_bias_grads(go: torch.Tensor, x: torch.Tensor, need_weight: bool, need
         return grad_weight, grad_bias
     if not (need_weight or need_bias):
         return None, None
-    go_p, x_p = pad_rows(go), pad_rows(x.contiguous())
-    if ops.gemm_tn_ok(go_p, x_p):                # both operands contraction-major as they are: no transposed copies
-        if need_weight:
+    if need_bias:
+        grad_bias = bias_grad(go).to(dtype)                                               # :524
+    if need_weight:
+        go_p, x_p = pad_rows(go), pad_rows(x.contiguous())
+        if ops.gemm_tn_ok(go_p, x_p):            # both operands contraction-major as they are: no transposed copies
             grad_weight = ops.gemm_tn(go_p, x_p)                                          # :522-523
-        if need_bias:
-            ones = torch.ones(go_p.shape[0], 256, dtype=go_p.dtype, device=go_p.device)
-            grad_bias = ops.gemm_tn(go_p, ones)[:, 0].contiguous()                        # :524
-    else:
-        go_t = transpose(go_p)
-        if need_weight:
-            grad_weight = wgrad(go_t, x_p)
-        if need_bias:
-            grad_bias = bias_grad(go_t)
+        else:
+            grad_weight = wgrad(transpose(go_p), x_p)
     return grad_weight, grad_bias
 
 

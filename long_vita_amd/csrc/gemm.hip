@@ -40,7 +40,10 @@ struct GemmArgs {
   const bf16_t* R; int64_t ldr;
   int tiles_m, tiles_n;
   int stagger;            // K-loop start offset policy (see gemm_bf16_kernel)
+  int splits = 1;         // r04, TN mode only: the contraction is cut into `splits` ranges of `k_tiles_per_split` K tiles (the last may be
+  int k_tiles_per_split = 0;   // shorter); workgroup (split, tile) writes its fp32 partial tile to ((float*)C)[split][M][N]
 };
+constexpr int VITA_EPI_F32_PARTIAL = 100;       // internal: the split-K epilogue of the TN kernel (never passed through the C ABI)
 
 __device__ __forceinline__ float gelu_tanh(float x) {       // F.gelu(x, approximate="tanh")
   return 0.5f * x * (1.0f + tanhf(0.79788456080286535588f * (x + 0.044715f * x * x * x)));
@@ -380,12 +383,16 @@ __global__ __launch_bounds__(256, 1) void gemm4_kernel(GemmArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
 
-  const int nwg = p.tiles_m * p.tiles_n;
+  constexpr bool SPLITK = EPI == VITA_EPI_F32_PARTIAL;
+  const int nwg = p.tiles_m * p.tiles_n * (SPLITK ? p.splits : 1);
   int pid;
   {
     const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
+  // split-K: the split is the SLOW index, so that the workgroups an XCD runs side by side are tiles of one K range sharing operand panels
+  const int split = SPLITK ? pid / (p.tiles_m * p.tiles_n) : 0;
+  if (SPLITK) pid -= split * (p.tiles_m * p.tiles_n);
   constexpr int GROUP_M = 4;
   const int per_group = GROUP_M * p.tiles_n;
   const int group = pid / per_group;
@@ -573,12 +580,16 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
 
-  const int nwg = p.tiles_m * p.tiles_n;
+  constexpr bool SPLITK = EPI == VITA_EPI_F32_PARTIAL;
+  const int nwg = p.tiles_m * p.tiles_n * (SPLITK ? p.splits : 1);
   int pid;
   {
     const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
+  // split-K: the split is the SLOW index, so that the workgroups an XCD runs side by side are tiles of one K range sharing operand panels
+  const int split = SPLITK ? pid / (p.tiles_m * p.tiles_n) : 0;
+  if (SPLITK) pid -= split * (p.tiles_m * p.tiles_n);
   constexpr int GROUP_M = 4;
   const int per_group = GROUP_M * p.tiles_n;
   const int group = pid / per_group;
@@ -589,7 +600,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   const int tn = in_group / gsz;
   const int64_t m0 = (int64_t)tm * 256;
   const int64_t n0 = (int64_t)tn * (EPI == VITA_EPI_SWIGLU ? 128 : 256);
-  const int nk = (int)(p.K / BK);
+  const int nk_all = (int)(p.K / BK);
+  const int nk = SPLITK ? min(p.k_tiles_per_split, nk_all - split * p.k_tiles_per_split) : nk_all;
 
   // ---- DMA geometry: wave w fills lines (h = w >> 1, r16 = (w & 1) * 8 + i), i = 0..7, of both operands; per-lane byte offsets of
   // the eight pieces relative to the tile's first row (clamped rows for ragged edges; SwiGLU: 16-row blocks alternate gate / up) ------
@@ -630,8 +642,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   };
   const char* const ap = uniform_ptr(TN ? p.A + m0 : p.A + m0 * p.lda);
   const char* const wp = uniform_ptr(TN ? p.W + n0 : p.W + n0 * p.ldw);
-  int64_t koff_a = 0, koff_w = 0;                                                           // byte offsets of the K tile fetched next
   const int64_t kstep_a = TN ? (int64_t)BK * p.lda * 2 : BK * 2, kstep_w = TN ? (int64_t)BK * p.ldw * 2 : BK * 2;
+  int64_t koff_a = SPLITK ? (int64_t)split * p.k_tiles_per_split * kstep_a : 0;            // byte offsets of the K tile fetched next
+  int64_t koff_w = SPLITK ? (int64_t)split * p.k_tiles_per_split * kstep_w : 0;
   auto dma_piece = [&](unsigned stage, int j) __attribute__((always_inline)) {              // j = 0..7: A lines, 8..15: W lines
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(j < 8 ? ap + koff_a : wp + koff_w), 0, 0x7fffffff, 0x00020000);
     const int i = j & 7;
@@ -766,6 +779,19 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   // block (nb, mb): lane holds C[m][n .. n+3], m = .. + (lane & 15), n = .. + 4 * (lane >> 4)
   const int64_t mrow = m0 + wm * 128 + (lane & 15);
   const int64_t ncol = n0 + wn * (EPI == VITA_EPI_SWIGLU ? 64 : 128) + 4 * (lane >> 4);
+  if (SPLITK) {
+    // split-K partial: the raw fp32 accumulators of this (split, tile) -> ((float*)C)[split][m][n .. n+3]; vita_splitk_reduce sums the splits
+    float* const cf = reinterpret_cast<float*>(p.C) + (int64_t)split * p.M * p.N;
+#pragma unroll
+    for (int mb = 0; mb < 8; ++mb) {
+      pin_row_block(mb);
+      float* crow = cf + (mrow + mb * 16) * p.N + ncol;
+#pragma unroll
+      for (int nb = 0; nb < 8; ++nb) *reinterpret_cast<f32x4*>(crow + nb * 16) = acc[nb][mb];
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    return;
+  }
   if (INTERIOR) {
     // whole tiles only (all decoder shapes): no masks.  With one workgroup per CU nothing else runs while a wave waits
     // for memory, so the bias / LayerScale / residual operands of one row block are loaded ahead of the previous block's arithmetic
@@ -1062,6 +1088,91 @@ extern "C" int vita_gemm_bf16_tn(const void* At, int64_t lda, const void* Wt, in
                               hipFuncAttributeMaxDynamicSharedMemorySize, w4::LDS_BYTES);
   });
   hipLaunchKernelGGL((gemm_w4_kernel<VITA_EPI_NONE, true, true>), dim3((unsigned)(tm * tn)), dim3(256), w4::LDS_BYTES, (hipStream_t)stream, a);
+  return vita_check_launch();
+}
+
+namespace {
+// C[m][n] = bf16(sum over the splits of part[s][m][n]); one thread per four columns
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(const float* __restrict__ part, bf16_t* __restrict__ C, int64_t ldc, int64_t M,
+                                                            int64_t N, int splits) {
+  const int64_t quads = M * (N / 4);
+  for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < quads; i += (int64_t)gridDim.x * blockDim.x) {
+    const int64_t m = i / (N / 4), n = (i - m * (N / 4)) * 4;
+    f32x4 s = *reinterpret_cast<const f32x4*>(part + m * N + n);
+    for (int k = 1; k < splits; ++k) {
+      const f32x4 t = *reinterpret_cast<const f32x4*>(part + ((int64_t)k * M + m) * N + n);
+      s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+    }
+    const u32x2 w = {pack_bf16x2(s[0], s[1]), pack_bf16x2(s[2], s[3])};
+    *reinterpret_cast<u32x2*>(C + m * ldc + n) = w;
+  }
+}
+
+// out[c] += sum over rows of float(x[r][c]) (fp32, atomics: the caller zeroes `out`); one thread per four columns of a row block
+__global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ x, int64_t ldx, float* __restrict__ out, int64_t rows, int cols,
+                                                     int rows_per_block) {
+  const int c4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c4 >= cols) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  float a0 = 0.f, a1 = 0.f, a2 = 0.f, a3 = 0.f;
+  for (int64_t r = r0; r < r1; ++r) {
+    const u32x2 v = *reinterpret_cast<const u32x2*>(x + r * ldx + c4);
+    a0 += bf16lo_to_f32(v[0]); a1 += bf16hi_to_f32(v[0]); a2 += bf16lo_to_f32(v[1]); a3 += bf16hi_to_f32(v[1]);
+  }
+  atomicAdd(out + c4, a0); atomicAdd(out + c4 + 1, a1); atomicAdd(out + c4 + 2, a2); atomicAdd(out + c4 + 3, a3);
+}
+}  // namespace
+
+// The same product with the contraction cut into `splits` ranges (r04): a weight gradient whose output is a handful of 256 x 256 tiles
+// (the ViT's linears: 16 - 64 tiles for 256 CUs; the decoder's qkv / proj at config 5: 1.1 rounds of the chip) over a contraction of
+// 16 K - 260 K token rows.  workspace: fp32 [splits][M][N].  splits = 1 is vita_gemm_bf16_tn.
+extern "C" size_t vita_gemm_tn_splitk_workspace_bytes(int64_t M, int64_t N, int splits) {
+  return splits > 1 ? (size_t)splits * (size_t)M * (size_t)N * sizeof(float) : 0;
+}
+
+extern "C" int vita_gemm_bf16_tn_splitk(const void* At, int64_t lda, const void* Wt, int64_t ldw, void* C, int64_t ldc, int64_t M,
+                                        int64_t N, int64_t K, int splits, void* workspace, void* stream) {
+  if (splits <= 1) return vita_gemm_bf16_tn(At, lda, Wt, ldw, C, ldc, M, N, K, stream);
+  if (!At || !Wt || !C || !workspace || M <= 0 || N <= 0 || K <= 0) return VITA_ERR_INVALID_ARG;
+  if ((M % 256) || (N % 256) || (K % BK) || (lda & 7) || (ldw & 7) || (ldc & 3)) return VITA_ERR_UNSUPPORTED;
+  if (BK * lda * 2 + 512 >= 0x7fff0000LL || BK * ldw * 2 + 512 >= 0x7fff0000LL) return VITA_ERR_UNSUPPORTED;
+  const int64_t nk = K / BK;
+  const int64_t per = (nk + splits - 1) / splits;
+  if (per < 2 || nk - per * (splits - 1) < 1) return VITA_ERR_INVALID_ARG;            // every split gets at least one K tile
+  GemmArgs a;
+  a.A = (const bf16_t*)At; a.lda = lda; a.W = (const bf16_t*)Wt; a.ldw = ldw;
+  a.C = (bf16_t*)workspace; a.ldc = N; a.M = M; a.N = N; a.K = K;
+  a.bias = nullptr; a.scale = nullptr; a.R = nullptr; a.ldr = 0; a.stagger = 0;
+  a.splits = splits; a.k_tiles_per_split = (int)per;
+  const int64_t tm = M / 256, tn = N / 256;
+  if (tm * tn * splits > 0x7fffffff) return VITA_ERR_UNSUPPORTED;
+  a.tiles_m = (int)tm; a.tiles_n = (int)tn;
+  static std::atomic<unsigned long long> attr_set{0};
+  vita_device_once(attr_set, [&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<VITA_EPI_F32_PARTIAL, true, true>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, w4::LDS_BYTES);
+  });
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL((gemm_w4_kernel<VITA_EPI_F32_PARTIAL, true, true>), dim3((unsigned)(tm * tn * splits)), dim3(256), w4::LDS_BYTES, st, a);
+  const int64_t quads = M * (N / 4);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256 < 8192 ? (quads + 255) / 256 : 8192)), dim3(256), 0, st,
+                     (const float*)workspace, (bf16_t*)C, ldc, M, N, splits);
+  return vita_check_launch();
+}
+
+// out[c] += sum_r float(x[r][c]): the bias gradient grad_output.sum(dim = 0) (M/core/tensor_parallel/layers.py:524) as ONE pass over
+// grad_output — through r03 it was a GEMM against a block of ones (a 259 K-row contraction on 4 - 16 workgroups: 5 ms per ViT linear).
+// out fp32 [cols], zeroed by the caller; cols % 4 == 0.
+extern "C" int vita_colsum_bf16(const void* x, int64_t ldx, float* out, int64_t rows, int cols, void* stream) {
+  if (!x || !out || rows < 0 || cols <= 0) return VITA_ERR_INVALID_ARG;
+  if ((cols & 3) || (ldx & 3)) return VITA_ERR_UNSUPPORTED;
+  if (rows == 0) return VITA_OK;
+  const int gx = (cols / 4 + 255) / 256;
+  int64_t rpb = (rows + 1023) / 1024;                    // <= 1024 row blocks: enough workgroups to stream at HBM speed, few atomics
+  if (rpb < 32) rpb = 32;
+  const int64_t gy = (rows + rpb - 1) / rpb;
+  hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, out, rows,
+                     cols, (int)rpb);
   return vita_check_launch();
 }
 

@@ -212,7 +212,7 @@ class BiasAddFn(torch.autograd.Function):
     @staticmethod
     def backward(ctx, g):
         g2 = g.reshape(-1, g.shape[-1]).contiguous()
-        return g, F_.bias_grad(F_.transpose(F_.pad_rows(g2)))
+        return g, F_.bias_grad(g2)
 
 
 class RMSNorm(torch.nn.Module):

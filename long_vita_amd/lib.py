@@ -144,6 +144,9 @@ PROTOTYPES = {
     "vita_cp_src_tgt": (_i, [_p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "vita_gemm_bf16": (_i, [_p, _l, _p, _l, _p, _l, _l, _l, _l, _i, _p, _p, _p, _l, _p]),
     "vita_gemm_bf16_tn": (_i, [_p, _l, _p, _l, _p, _l, _l, _l, _l, _p]),
+    "vita_gemm_tn_splitk_workspace_bytes": (C.c_size_t, [_l, _l, _i]),
+    "vita_gemm_bf16_tn_splitk": (_i, [_p, _l, _p, _l, _p, _l, _l, _l, _l, _i, _p, _p]),
+    "vita_colsum_bf16": (_i, [_p, _l, _p, _l, _i, _p]),
     "vita_gemm_skinny_bf16": (_i, [_p, _l, _p, _l, _p, _l, _i, _l, _l, _i, _p]),
     "vita_flash_attn_fwd": (_i, [C.POINTER(AttnParams), _p]),
     "vita_patchify14": (_i, [_p, _p, _l, _i, _i, _i, _p]),

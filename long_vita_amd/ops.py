@@ -325,15 +325,58 @@ def gemm_tn_ok(a_t: torch.Tensor, w_t: torch.Tensor) -> bool:
             and w_t.stride(0) % 8 == 0 and a_t.shape[0] > 0)
 
 
-def gemm_tn(a_t: torch.Tensor, w_t: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+def tn_splits(M: int, N: int, K: int) -> int:
+    """How many ranges to cut the contraction of a TN (weight-gradient) GEMM into.  The kernel gives one 256 x 256 output tile to one
+    workgroup; a gradient whose output is a few tiles (ViT linears: 16 - 64 tiles, the decoder's qkv / proj at config 5's TP-halved widths:
+    200 - 280) leaves most of the 256 CUs idle or runs a nearly empty last round.  Cost model in units of one K tile of one round
+    (~1.5 us): rounds(tiles x S) x K tiles per split + the fp32 partial write / read of the reduction at ~3 TB/s; split only for >= 10 %."""
+    tiles, nk = (M // 256) * (N // 256), K // 64
+    unit = 1.5e-6
+
+    def cost(S):
+        per = -(-nk // S)
+        red = 0.0 if S == 1 else (S * M * N * 8 + M * N * 2) / 3e12 / unit + 4
+        return -(-tiles * S // 256) * per + red
+    best_s, best = 1, cost(1)
+    for S in (2, 3, 4, 6, 8, 12, 16):
+        per = -(-nk // S)
+        if per < 8 or nk - per * (S - 1) < 1 or S * M * N * 4 > (2 << 30):
+            continue
+        c = cost(S)
+        if c < 0.9 * best and c < 0.9 * cost(1):
+            best_s, best = S, c
+    return best_s
+
+
+def gemm_tn(a_t: torch.Tensor, w_t: torch.Tensor, out: Optional[torch.Tensor] = None, splits: Optional[int] = None) -> torch.Tensor:
     """out[M, N] = a_t[K, M]^T @ w_t[K, N] — both operands contraction-major (the wgrad GEMM: a_t = grad_output [tokens, out],
-    w_t = total_input [tokens, in]; M/core/tensor_parallel/layers.py:522-523) with no transposed copies."""
+    w_t = total_input [tokens, in]; M/core/tensor_parallel/layers.py:522-523) with no transposed copies.  splits: None = tn_splits'
+    choice (r04: split-K for gradients with few output tiles), 1 = one workgroup per tile over the whole contraction."""
     K, M = a_t.shape
     N = w_t.shape[1]
     y = torch.empty((M, N), dtype=BF16, device=a_t.device) if out is None else out
-    _L.check(_L.load().vita_gemm_bf16_tn(_dev(a_t, "a_t", BF16), a_t.stride(0), _dev(w_t, "w_t", BF16), w_t.stride(0),
-                                         _dev(y, "out", BF16), y.stride(0), M, N, K, _stream()), "vita_gemm_bf16_tn")
+    S = tn_splits(M, N, K) if splits is None else int(splits)
+    if S <= 1:
+        _L.check(_L.load().vita_gemm_bf16_tn(_dev(a_t, "a_t", BF16), a_t.stride(0), _dev(w_t, "w_t", BF16), w_t.stride(0),
+                                             _dev(y, "out", BF16), y.stride(0), M, N, K, _stream()), "vita_gemm_bf16_tn")
+        return y
+    ws = torch.empty((S, M, N), dtype=torch.float32, device=a_t.device)
+    _L.check(_L.load().vita_gemm_bf16_tn_splitk(_dev(a_t, "a_t", BF16), a_t.stride(0), _dev(w_t, "w_t", BF16), w_t.stride(0),
+                                                _dev(y, "out", BF16), y.stride(0), M, N, K, S, _dev(ws, "workspace", torch.float32),
+                                                _stream()), "vita_gemm_bf16_tn_splitk")
     return y
+
+
+def colsum(x: torch.Tensor) -> torch.Tensor:
+    """fp32 [cols] = sum over the rows of x [rows, cols] bf16 (row stride allowed): grad_bias = grad_output.sum(dim=0) (layers.py:524)."""
+    if x.dim() != 2 or x.stride(1) != 1:
+        raise ValueError("x must be 2-D with a unit inner stride")
+    rows, cols = x.shape
+    out = torch.zeros(cols, dtype=torch.float32, device=x.device)
+    if rows:
+        _L.check(_L.load().vita_colsum_bf16(_dev(x, "x", BF16), x.stride(0), _dev(out, "out", torch.float32), rows, cols, _stream()),
+                 "vita_colsum_bf16")
+    return out
 
 
 def gemm_skinny(a: torch.Tensor, w: torch.Tensor, out_f32: bool = False) -> torch.Tensor:

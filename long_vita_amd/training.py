@@ -58,13 +58,8 @@ def _wgrad_tn(dy: torch.Tensor, x: torch.Tensor) -> torch.Tensor:
 
 
 def _colsum(dy: torch.Tensor) -> torch.Tensor:
-    """grad_bias = grad_output.sum(dim=0) (layers.py:524) as a GEMM against a block of ones: dy [M, N] -> [N]."""
-    m = dy.shape[0]
-    if dy.shape[1] % 256 == 0 and m % 64 == 0 and dy.stride(1) == 1 and dy.stride(0) % 8 == 0:
-        ones = torch.ones(m, 256, dtype=dy.dtype, device=dy.device)
-        return ops.gemm_tn(dy, ones)[:, 0].contiguous()
-    ones = torch.ones(4, m, dtype=dy.dtype, device=dy.device)
-    return ops.gemm(_t(dy), ones)[:, 0].contiguous()
+    """grad_bias = grad_output.sum(dim=0) (layers.py:524): dy [M, N] -> [N] in one pass (vita_colsum_bf16; r03: a GEMM against ones)."""
+    return ops.colsum(dy).to(dy.dtype)
 
 
 def _tp_sum(t: torch.Tensor) -> torch.Tensor:

@@ -601,7 +601,7 @@ def test_gemm_tn_both_operands_contraction_major(ops, M, N, K):
     ref = (a_t.float().t() @ w_t.float()).bfloat16()
     ad, wd = a_t.to(DEV), w_t.to(DEV)
     assert ops.gemm_tn_ok(ad, wd)
-    out = ops.gemm_tn(ad, wd)
+    out = ops.gemm_tn(ad, wd, splits=1)
     tol("vs fp32 math", rel_l2(out, ref), 2e-3)
     nt = ops.gemm(ops.transpose(ad), ops.transpose(wd))
     assert torch.equal(out, nt)
@@ -610,10 +610,42 @@ def test_gemm_tn_both_operands_contraction_major(ops, M, N, K):
     big_a[:, 32:32 + M] = ad
     big_w = torch.zeros(K, N + 512, dtype=torch.bfloat16, device=DEV)
     big_w[:, 256:256 + N] = wd
-    assert torch.equal(ops.gemm_tn(big_a[:, 32:32 + M], big_w[:, 256:256 + N]), out)
+    assert torch.equal(ops.gemm_tn(big_a[:, 32:32 + M], big_w[:, 256:256 + N], splits=1), out)
     if K >= 256 and M == 256:
         eye_t = torch.zeros(K, M, dtype=torch.bfloat16)
         eye_t[:M] = torch.eye(M)                                       # A_t^T = [I | 0]: C = the first M rows of W_t
         wa = (torch.arange(K * N).reshape(K, N) % 251 - 125).float().bfloat16()
-        assert torch.equal(ops.gemm_tn(eye_t.to(DEV), wa.to(DEV)).cpu(), wa[:M])
+        assert torch.equal(ops.gemm_tn(eye_t.to(DEV), wa.to(DEV), splits=1).cpu(), wa[:M])
     assert not ops.gemm_tn_ok(ad[:, :M - 8], wd) and not ops.gemm_tn_ok(ad[:K - 8], wd[:K - 8])
+
+
+@pytest.mark.parametrize("M,N,K,S", [(256, 256, 4096, 4), (512, 256, 8320, 13), (1024, 1024, 66 * 64, 3), (256, 512, 130 * 64, 8)])
+def test_gemm_tn_split_k(ops, M, N, K, S):
+    """r04: vita_gemm_bf16_tn_splitk — the contraction cut into S ranges (uneven when K / 64 is not a multiple of S), fp32 partials,
+    one rounding after the sum — vs fp32 math and vs the one-pass kernel (same products, a different fp32 summation order: within one
+    bf16 ulp of each other); the automatic choice (ops.tn_splits) takes the split path for few output tiles over a long contraction."""
+    a_t = (torch.randn(K, M, generator=g(300)) * 0.5).bfloat16()
+    w_t = (torch.randn(K, N, generator=g(301)) * (1.0 / math.sqrt(K))).bfloat16()
+    ref = (a_t.float().t() @ w_t.float())
+    ad, wd = a_t.to(DEV), w_t.to(DEV)
+    one = ops.gemm_tn(ad, wd, splits=1)
+    out = ops.gemm_tn(ad, wd, splits=S)
+    tol("split-K vs fp32 math", rel_l2(out, ref), 2e-3)
+    tol("split-K vs one pass", rel_l2(out, one), 2.5e-3)
+    assert float((out.float() - one.float()).abs().max()) <= float(one.float().abs().max()) * 2 ** -7
+    auto = ops.gemm_tn(ad, wd)
+    assert ops.tn_splits(M, N, K) > 1
+    tol("automatic split vs fp32 math", rel_l2(auto, ref), 2e-3)
+
+
+def test_colsum_is_the_bias_gradient(ops):
+    """r04: vita_colsum_bf16 = grad_output.sum(dim=0) (M/core/tensor_parallel/layers.py:524) in fp32, rows not a multiple of anything,
+    a strided view included."""
+    x = torch.randn(25933, 1024, generator=g(310)).bfloat16()
+    ref = x.float().sum(dim=0)
+    out = ops.colsum(x.to(DEV))
+    tol("colsum", rel_l2(out, ref), 1e-5)
+    big = torch.zeros(4099, 3072 + 64, dtype=torch.bfloat16)
+    big[:, 32:32 + 3072] = torch.randn(4099, 3072, generator=g(311)).bfloat16()
+    tol("strided colsum", rel_l2(ops.colsum(big.to(DEV)[:, 32:32 + 3072]), big[:, 32:32 + 3072].float().sum(dim=0)), 1e-5)
+    assert float(ops.colsum(torch.zeros(0, 256, dtype=torch.bfloat16, device=DEV)).abs().sum()) == 0.0
