@@ -65,6 +65,15 @@ def test_layernorm(ops, rows, cols, eps):
     assert (out.cpu() == ref).float().mean() > 0.99
 
 
+def _rope_ref(t, c2, s2):
+    """`t * cos + rotate_half(t) * sin` in bf16 (apply_rotary_pos_emb_bshd, rotary_pos_embedding.py:200-204) spelled out as fp32 products
+    rounded to bf16, summed in fp32, rounded — what torch's bf16 kernels compute, without depending on the host CPU's bf16 code path
+    (one GPU box of r04 disagreed with the others in exactly these two bit-exact comparisons; its host ran torch's bf16 ops differently)."""
+    a = (t.float() * c2.float()).bfloat16().float()
+    b = (glue.rotate_half(t).float() * s2.float()).bfloat16().float()
+    return (a + b).bfloat16()
+
+
 def test_rope_table_and_apply(ops):
     inv = glue.rope_inv_freq(128, 1e6)
     assert torch.equal(ops.rope_inv_freq(128, 1e6, "cpu"), inv)
@@ -79,7 +88,7 @@ def test_rope_table_and_apply(ops):
     emb_cos, emb_sin = cos.cpu(), sin.cpu()
     c2 = torch.cat([emb_cos, emb_cos], -1)[:, None, :]
     s2 = torch.cat([emb_sin, emb_sin], -1)[:, None, :]
-    ref = t * c2 + glue.rotate_half(t) * s2
+    ref = _rope_ref(t, c2, s2)
     out = ops.rope_apply_(t.to(DEV).clone(), cos, sin)
     assert torch.equal(out.cpu(), ref)
     # strided view + backward sign: R(-theta) R(theta) x ~= x
@@ -102,7 +111,7 @@ def test_rope_qkv_fused(ops):
     m = mixed.view(rows, ng, qpg + 2, d)
     ref = m.clone()
     for h in range(qpg + 1):
-        ref[:, :, h] = m[:, :, h] * c2 + glue.rotate_half(m[:, :, h]) * s2
+        ref[:, :, h] = _rope_ref(m[:, :, h], c2, s2)
     md = mixed.to(DEV).clone()
     kv = torch.empty(2, rows, ng, d, dtype=torch.bfloat16, device=DEV)
     ops.rope_qkv_(md, ng, qpg, d, cos, sin, kv)
