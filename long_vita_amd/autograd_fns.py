@@ -546,3 +546,7 @@ class EmbeddingScatterFn(torch.autograd.Function):
             rows = ops.row_gather(g, tgt)
             ops.row_scatter_(d_feats, src if src is not None else torch.arange(tgt.numel(), device=g.device), rows)
         return d_weight, None, d_feats, None, None
+
+
+from . import tracing as _tracing                                   # noqa: E402
+_tracing.instrument_functions(globals())                            # roctx ranges per Function under VITA_DEBUG (no-op otherwise)

@@ -18,7 +18,7 @@ from typing import Optional
 
 import torch
 
-from . import ops, parallel_state as mpu, training_utils
+from . import ops, parallel_state as mpu, tracing, training_utils
 from .dot_product_attention import DotProductAttention
 from .language_model_embedding import LanguageModelEmbedding
 from .layers import ColumnParallelLinear
@@ -185,7 +185,8 @@ class GPTVLModel:
             return self._decode_forward(input_ids, position_ids, ip)
         if decoder_input is None:                                                         # :252-277
             if external_inputs:
-                feats = self.external_feature_model(**external_inputs)                   # :267
+                with tracing.range("prefill: vision tower"):
+                    feats = self.external_feature_model(**external_inputs)               # :267
                 efd = {"features": feats}
                 for k in external_inputs:
                     if "indices" in k or k == "pre_len":
@@ -204,9 +205,11 @@ class GPTVLModel:
         if ip is not None:
             self._allocate_cache(ip, s, h.device)
         for li, lp in enumerate(self.p["layers"]):                                        # self.decoder(...) :299
-            self.decoder_layer(h, lp, cos, sin, ws, None if ip is None else ip.key_value_memory_dict[li + 1])
+            with tracing.range(f"prefill: layer {li}"):
+                self.decoder_layer(h, lp, cos, sin, ws, None if ip is None else ip.key_value_memory_dict[li + 1])
         if ip is not None:
             self._compact_cache(ip, s)
+        tracing.push("prefill: final norm + masked head")
         # final RMSNorm is per-row, so norm only the rows the masked head keeps
         if logit_mask is not None:
             idx = ops.mask_to_index(logit_mask.transpose(0, 1).reshape(-1))
@@ -219,7 +222,9 @@ class GPTVLModel:
         logits = self._gather_vocab_parallel(logits)
         ops.logit_postprocess_(logits, self.cfg.output_multiplier_scale, self.cfg.output_logit_softcapping)   # :349-355
         if bool(torch.isnan(logits.float().sum())):                                       # :393-396
+            tracing.pop()
             raise ValueError("found NaN in local forward logits calculation")
+        tracing.pop()
         return logits.transpose(0, 1).contiguous()                                        # [s b v] -> [b s v] :370
 
     @staticmethod

@@ -30,7 +30,7 @@ from typing import Optional
 import torch
 import torch.distributed as dist
 
-from . import ops, parallel_state as mpu, training_utils
+from . import ops, parallel_state as mpu, tracing, training_utils
 from .gpt_vl_model import GPTVLModel
 
 
@@ -249,6 +249,7 @@ class TrainStep:
         s = tok.shape[1]
 
         # ---- forward -------------------------------------------------------------------------------
+        tracing.push("train: vision + embedding")
         proj = None
         efd = None
         # A CP rank whose two zig-zag chunks hold text only gets no src / tgt indices from get_batch_on_this_cp_rank
@@ -273,7 +274,9 @@ class TrainStep:
         saved, kept = [], []
         n_layers = len(m.p["layers"])
         n_rec = n_layers if self.recompute_num_layers is None else max(0, min(n_layers, int(self.recompute_num_layers)))
+        tracing.pop()
         for li, lp in enumerate(m.p["layers"]):
+            tracing.push(f"train: fwd layer {li}")
             if li < n_rec:                                   # recompute block: keep the input only, fused fast path
                 saved.append(h.clone())
                 kept.append(None)
@@ -282,6 +285,8 @@ class TrainStep:
                 saved.append(h)
                 h, keep = self._layer_forward_keep(h, lp, cos, sin)
                 kept.append(keep)
+            tracing.pop()
+        tracing.push("train: head + loss")
         idx = ops.mask_to_index(logit_mask.transpose(0, 1).reshape(-1))
         n_sel = idx.numel()
         tp, tp_rank = mpu.get_tensor_model_parallel_world_size(), mpu.get_tensor_model_parallel_rank()
@@ -316,6 +321,7 @@ class TrainStep:
         if cp > 1:
             dist.all_reduce(stats, group=mpu.get_context_parallel_group())     # loss_func :801-803
         loss = stats[0] / stats[1].clamp(min=1.0)
+        tracing.pop()
 
         # ---- backward ------------------------------------------------------------------------------
         grads = {"layers": [dict() for _ in m.p["layers"]]}
@@ -335,9 +341,12 @@ class TrainStep:
             grads["lm_head"] = torch.zeros_like(m.p["lm_head"])
             grads["final_ln"] = torch.zeros(c.hidden, dtype=torch.float32, device=h.device)
         for li in range(len(m.p["layers"]) - 1, -1, -1):
+            tracing.push(f"train: bwd layer {li}" + ("" if kept[li] is not None else " (recompute)"))
             dh = self._layer_backward(dh, saved[li], m.p["layers"][li], cos, sin, grads["layers"][li], kept[li])
             saved[li] = None
             kept[li] = None
+            tracing.pop()
+        tracing.push("train: embedding + projector + vision backward")
         # ---- embedding / visual-token scatter backward ---------------------------------------------
         tok_idx = tok.reshape(-1).clone()
         d_embed = torch.zeros(m.p["embed"].shape, dtype=torch.float32, device=h.device)
@@ -362,6 +371,7 @@ class TrainStep:
                                   "proj_ln_b": torch.zeros(vp["proj_ln_b"].numel(), dtype=torch.float32, device=h.device)}
         ops.row_scatter_add_f32_(d_embed, tok_idx, dh)
         grads["embed"] = d_embed
+        tracing.pop()
         return loss, grads
 
     # ------------------------------------------------------------------------------------------

@@ -670,3 +670,35 @@ def test_output_layer_with_a_logit_mask_that_selects_nothing(megatron):
     out.sum().backward()
     assert x.grad.shape == x.shape and float(x.grad.abs().sum()) == 0.0
     assert float(lin.weight.grad.abs().sum()) == 0.0 and float(lin.bias.grad.abs().sum()) == 0.0
+
+
+def test_functions_wrapped_in_roctx_ranges_compute_the_same_under_vita_debug():
+    """VITA_DEBUG=1 wraps every autograd Function's forward / backward in a roctx range (long_vita_amd/tracing.py): a linear + RMSNorm +
+    SwiGLU chain gives bit-identical outputs and gradients with and without the wrappers (run in child processes: the switch is read at
+    import)."""
+    import os, subprocess, textwrap
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    code = textwrap.dedent("""
+        import torch, hashlib
+        from long_vita_amd import autograd_fns as F, tracing
+        torch.manual_seed(3)
+        x = (torch.randn(256, 512, device="cuda") * 0.5).bfloat16().requires_grad_(True)
+        w = (torch.randn(1024, 512, device="cuda") * 0.05).bfloat16().requires_grad_(True)
+        g = torch.ones(512, device="cuda", dtype=torch.bfloat16)           # (its gradient is an atomic sum: not hashed)
+        with tracing.range("test chain"):
+            y = F.SwiGLUFn.apply(F.LinearFn.apply(F.RMSNormFn.apply(x, g, 1e-6), w, None, False, False, None))
+            y.float().square().sum().backward()
+        torch.cuda.synchronize()
+        h = hashlib.sha256()
+        for t in (y, x.grad, w.grad):
+            h.update(t.detach().float().cpu().numpy().tobytes())
+        print("WRAPPED" if hasattr(F.LinearFn.forward, "__wrapped__") else "PLAIN", h.hexdigest())
+    """)
+    outs = {}
+    for flag in ("0", "1"):
+        r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=root, timeout=600,
+                           env=dict(os.environ, VITA_DEBUG=flag))
+        assert r.returncode == 0, r.stderr[-2000:]
+        outs[flag] = r.stdout.strip().split()
+    assert outs["0"][0] == "PLAIN" and outs["1"][0] == "WRAPPED"
+    assert outs["0"][1] == outs["1"][1]

@@ -1058,3 +1058,32 @@ def test_vit_layer_specs_construct_on_cpu_with_the_references_parameter_names():
     finally:
         dm.uninstall(names)
         aspm.patches_info = {}
+
+
+def test_roctx_ranges_are_off_by_default_and_nest_under_vita_debug():
+    """long_vita_amd/tracing.py: null contexts without VITA_DEBUG; with it, libroctx64's push / pop nest (return the depth) and every
+    autograd Function's forward / backward is wrapped in a range (SURVEY.md §5 tracing)."""
+    import subprocess, sys, textwrap
+    from long_vita_amd import tracing
+    if not tracing.ENABLED:
+        import contextlib
+        assert isinstance(tracing.range("x"), contextlib.nullcontext)
+    code = textwrap.dedent("""
+        import torch
+        from long_vita_amd import tracing, autograd_fns
+        assert tracing.ENABLED
+        lib = tracing._load()
+        if lib is None:
+            print("NOLIB"); raise SystemExit(0)
+        d0 = lib.roctxRangePushA(b"outer"); d1 = lib.roctxRangePushA(b"inner")
+        assert d1 == d0 + 1, (d0, d1)
+        assert lib.roctxRangePop() == d1 and lib.roctxRangePop() == d0
+        with tracing.range("layer 0"):
+            tracing.mark("m")
+        assert autograd_fns.LinearFn.forward.__wrapped__ is not None and autograd_fns.FlashAttnFn.backward.__wrapped__ is not None
+        print("OK")
+    """)
+    env = dict(os.environ, VITA_DEBUG="1")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert "OK" in r.stdout or "NOLIB" in r.stdout
