@@ -143,6 +143,110 @@ def _gather_sequence(x: torch.Tensor, tp=None, group=None) -> torch.Tensor:
     return out
 
 
+def _reduce_dgrad(grad_total: torch.Tensor, like: torch.Tensor, tp: int, group, allreduce_dgrad: bool, sequence_parallel: bool):
+    """The communication half of a column-parallel linear's input gradient (layers.py:475-494)."""
+    if allreduce_dgrad and tp > 1:
+        dist.all_reduce(grad_total, group=group)
+    if sequence_parallel:
+        sub = torch.empty(like.shape, dtype=like.dtype, device=like.device)
+        dist.reduce_scatter_tensor(sub, grad_total.contiguous(), group=group)
+        return sub
+    return grad_total
+
+
+class NormLinearFn(torch.autograd.Function):
+    """RMSNorm -> column-parallel linear as ONE autograd node (TELayerNormColumnParallelLinear's fusion, gpt_layer_specs.py:41): what is
+    kept for the backward is the layer's own input x (the residual stream already holds it) instead of a second, normed [s, b, c]
+    tensor per linear; the backward re-derives the normed rows with one vita_rmsnorm_fwd (HBM-bound, ~1 % of the layer).  Same kernels,
+    same order, same bits as RMSNormFn followed by LinearFn."""
+
+    @staticmethod
+    def forward(ctx, x, ln_weight, weight, bias, eps, allreduce_dgrad, sequence_parallel):
+        ctx.save_for_backward(x, ln_weight, weight)
+        ctx.use_bias, ctx.eps = bias is not None, eps
+        ctx.allreduce_dgrad, ctx.sequence_parallel = allreduce_dgrad, sequence_parallel
+        ctx.tp, ctx.group = _tp()
+        xn = ops.rmsnorm(x, ln_weight, eps)
+        total = _gather_sequence(xn, ctx.tp, ctx.group) if sequence_parallel else xn
+        s, b, c = total.shape
+        out = ops.gemm(total.reshape(s * b, c), weight, ops.EPI_BIAS if bias is not None else ops.EPI_NONE, bias)
+        return out.view(s, b, out.shape[-1])
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        x, ln_weight, weight = ctx.saved_tensors
+        tp, group = ctx.tp, ctx.group
+        xc = x.contiguous()
+        xn = ops.rmsnorm(xc, ln_weight, ctx.eps)
+        total = _gather_sequence(xn, tp, group) if ctx.sequence_parallel else xn
+        s, b, c = total.shape
+        go = grad_output.reshape(-1, grad_output.shape[-1]).contiguous()
+        grad_total = dgrad(go, weight).view(s, b, c)
+        d_xn = _reduce_dgrad(grad_total, x, tp, group, ctx.allreduce_dgrad, ctx.sequence_parallel)
+        grad_weight, grad_bias = weight_bias_grads(go, total.reshape(s * b, c), ctx.needs_input_grad[2], ctx.use_bias,
+                                                   weight.shape[0], weight.dtype)
+        del total, xn
+        d_lnw = torch.zeros(ln_weight.numel(), dtype=torch.float32, device=x.device)
+        dx = ops.rmsnorm_bwd(d_xn.contiguous(), xc, ln_weight, ctx.eps, d_lnw)
+        return dx.view_as(x), d_lnw.to(ln_weight.dtype), grad_weight, grad_bias, None, None, None
+
+
+class GatedMLPFn(torch.autograd.Function):
+    """The decoder's whole MLP — [RMSNorm ->] fc1 -> silu(gate) * up -> fc2 [-> TP reduction] — as ONE autograd node (Megatron MLP.forward,
+    megatron/core/transformer/mlp.py, under stage 3's `--swiglu --disable-bias-linear`).  Kept for the backward: the input x (already
+    held by the residual stream) and the fc1 product y [s, b, 2 ffn / TP]; the normed rows and the gated activation [s, b, ffn / TP] are
+    re-derived (vita_rmsnorm_fwd, vita_swiglu_fwd: two HBM-bound passes, ~2 % of the layer's backward) — what training.TrainStep keeps
+    for a layer outside the recompute block.  ln_weight None = the local spec (the norm is a separate module)."""
+
+    @staticmethod
+    def forward(ctx, x, ln_weight, w1, w2, eps, sequence_parallel):
+        ctx.eps, ctx.sequence_parallel = eps, sequence_parallel
+        ctx.has_norm = ln_weight is not None
+        ctx.tp, ctx.group = _tp()
+        xn = ops.rmsnorm(x, ln_weight, eps) if ctx.has_norm else x
+        total = _gather_sequence(xn, ctx.tp, ctx.group) if sequence_parallel else xn
+        s, b, c = total.shape
+        y = ops.gemm(total.reshape(s * b, c), w1)
+        act = ops.swiglu(y)
+        out = ops.gemm(act, w2).view(s, b, w2.shape[0])
+        del act
+        if sequence_parallel:                                                  # RowParallelLinear :1095 / :1097
+            sub = torch.empty((s // ctx.tp, b, w2.shape[0]), dtype=out.dtype, device=out.device)
+            dist.reduce_scatter_tensor(sub, out, group=ctx.group)
+            out = sub
+        elif ctx.tp > 1:
+            dist.all_reduce(out, group=ctx.group)
+        ctx.save_for_backward(x, ln_weight, w1, w2, y)
+        return out
+
+    @staticmethod
+    def backward(ctx, grad_output):
+        x, ln_weight, w1, w2, y = ctx.saved_tensors
+        tp, group, sp = ctx.tp, ctx.group, ctx.sequence_parallel
+        go = _gather_sequence(grad_output.contiguous(), tp, group) if sp else grad_output          # ReduceScatterToSP / ReduceFromTP bwd
+        go = go.reshape(-1, go.shape[-1]).contiguous()
+        act = ops.swiglu(y)
+        grad_w2, _ = weight_bias_grads(go, act, ctx.needs_input_grad[3], False, w2.shape[0], w2.dtype)
+        del act
+        d_act = dgrad(go, w2)
+        dy = ops.swiglu_bwd(y, d_act)
+        del d_act
+        xc = x.contiguous()
+        xn = ops.rmsnorm(xc, ln_weight, ctx.eps) if ctx.has_norm else xc
+        total = _gather_sequence(xn, tp, group) if sp else xn
+        s, b, c = total.shape
+        grad_w1, _ = weight_bias_grads(dy, total.reshape(s * b, c), ctx.needs_input_grad[2], False, w1.shape[0], w1.dtype)
+        del total, xn
+        grad_total = dgrad(dy, w1).view(s, b, c)
+        del dy
+        d_xn = _reduce_dgrad(grad_total, x, tp, group, not sp, sp)
+        if not ctx.has_norm:
+            return d_xn.view_as(x), None, grad_w1, grad_w2, None, None
+        d_lnw = torch.zeros(ln_weight.numel(), dtype=torch.float32, device=x.device)
+        dx = ops.rmsnorm_bwd(d_xn.contiguous(), xc, ln_weight, ctx.eps, d_lnw)
+        return dx.view_as(x), d_lnw.to(ln_weight.dtype), grad_w1, grad_w2, None, None
+
+
 class ReduceFromTP(torch.autograd.Function):
     """reduce_from_tensor_model_parallel_region: all-reduce forward, identity backward (RowParallelLinear.forward :1097)."""
 

@@ -14,12 +14,19 @@ tensor-parallel group (RCCL), the row-parallel linears reduce-scatter their outp
 """
 from __future__ import annotations
 
+import os
 from typing import Callable, Optional
 
 import torch
 from torch.nn import Parameter
 
 from . import autograd_fns as F_, ops, parallel_state as mpu
+
+
+# One autograd node per fused module (NormLinearFn, GatedMLPFn) instead of one per kernel: the same kernels in the same order, but the
+# normed rows and the gated activation are re-derived in the backward instead of kept (0.8 GB less per 16K layer).  VITA_MODULE_UNFUSED=1
+# restores the node-per-kernel graph (A / B and bit-identity tests).
+FUSE_AUTOGRAD_NODES = os.environ.get("VITA_MODULE_UNFUSED", "0") in ("", "0")
 
 
 def _divide(n: int, d: int) -> int:
@@ -286,7 +293,18 @@ class LayerNormColumnParallelLinear(ColumnParallelLinear):
             return F_.LayerNormFn.apply(x, self.layer_norm_weight, self.layer_norm_bias, self.eps)
         return ops.layernorm(x, self.layer_norm_weight, self.layer_norm_bias, self.eps)
 
+    def _one_node(self, x: torch.Tensor) -> bool:
+        """RMSNorm + linear as one autograd node (NormLinearFn keeps x, not the normed copy): the decoder's qkv / fc1 under autograd."""
+        return (FUSE_AUTOGRAD_NODES and self.normalization == "RMSNorm" and self.weight is not None and not self.disable_grad_reduce
+                and torch.is_grad_enabled()
+                and (x.requires_grad or self.weight.requires_grad or self.layer_norm_weight.requires_grad))
+
     def forward(self, x: torch.Tensor):
+        if self._one_node(x):
+            fuse_bias = not self.skip_bias_add
+            out = F_.NormLinearFn.apply(x, self.layer_norm_weight, self.weight, self.bias if fuse_bias else None, self.eps,
+                                        self.allreduce_dgrad, self.sequence_parallel)
+            return out, (None if fuse_bias else self.bias)
         return super().forward(self._norm(x))
 
     def forward_fused_bias(self, x: torch.Tensor):
@@ -378,6 +396,12 @@ class GatedMLP(torch.nn.Module):
             x = fc1._norm(hidden_states) if isinstance(fc1, LayerNormColumnParallelLinear) else hidden_states
             s, b, h = x.shape
             a = ops.gemm(x.reshape(s * b, h), fc1.weight, ops.EPI_SWIGLU).view(s, b, -1)
+        elif FUSE_AUTOGRAD_NODES and not (isinstance(fc1, LayerNormColumnParallelLinear) and fc1.normalization != "RMSNorm"):
+            # one autograd node for [norm ->] fc1 -> SwiGLU -> fc2 [-> TP reduction]: keeps x and the fc1 product only (GatedMLPFn)
+            ln_w = fc1.layer_norm_weight if isinstance(fc1, LayerNormColumnParallelLinear) else None
+            out = F_.GatedMLPFn.apply(hidden_states, ln_w, fc1.weight, self.linear_fc2.weight,
+                                      getattr(fc1, "eps", 0.0), fc1.sequence_parallel)
+            return out, None
         else:
             y, _ = fc1(hidden_states)
             a = F_.SwiGLUFn.apply(y)

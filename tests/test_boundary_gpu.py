@@ -682,7 +682,7 @@ def test_functions_wrapped_in_roctx_ranges_compute_the_same_under_vita_debug():
         import torch, hashlib
         from long_vita_amd import autograd_fns as F, tracing
         torch.manual_seed(3)
-        x = (torch.randn(256, 512, device="cuda") * 0.5).bfloat16().requires_grad_(True)
+        x = (torch.randn(256, 1, 512, device="cuda") * 0.5).bfloat16().requires_grad_(True)      # [s, b, c]
         w = (torch.randn(1024, 512, device="cuda") * 0.05).bfloat16().requires_grad_(True)
         g = torch.ones(512, device="cuda", dtype=torch.bfloat16)           # (its gradient is an atomic sum: not hashed)
         with tracing.range("test chain"):
@@ -702,3 +702,46 @@ def test_functions_wrapped_in_roctx_ranges_compute_the_same_under_vita_debug():
         outs[flag] = r.stdout.strip().split()
     assert outs["0"][0] == "PLAIN" and outs["1"][0] == "WRAPPED"
     assert outs["0"][1] == outs["1"][1]
+
+
+@pytest.mark.parametrize("spec", ["te", "local"])
+def test_one_node_per_fused_module_is_bit_identical_and_keeps_less(megatron, monkeypatch, spec):
+    """NormLinearFn / GatedMLPFn (one autograd node for norm -> linear and for the whole gated MLP; layers.FUSE_AUTOGRAD_NODES) run
+    the same kernels in the same order as the node-per-kernel graph: output, input gradient and every matrix gradient bit-identical
+    (the norm-weight gradients are fp32 atomic sums: tolerance), with fewer bytes alive between forward and backward."""
+    from long_vita_amd import layers
+    S = 1024
+    ocfg = ollm.LLMConfig(**CFG)
+    lp = ollm.init_llm_params(ocfg, seed=77)["layers"][0]
+    mcfg = dm.TransformerConfig(hidden_size=CFG["hidden"], num_attention_heads=CFG["heads"], num_query_groups=CFG["kv_groups"],
+                                kv_channels=CFG["head_dim"], ffn_hidden_size=CFG["ffn"])
+    builder = megatron.get_gpt_layer_with_transformer_engine_spec if spec == "te" else megatron.get_gpt_layer_local_spec
+    g = torch.Generator().manual_seed(78)
+    x = (torch.randn(S, 1, CFG["hidden"], generator=g) * 0.5).bfloat16().to(DEV)
+    go = torch.randn(S, 1, CFG["hidden"], generator=g).bfloat16().to(DEV)
+    freqs = glue.rope_emb(S, glue.rope_inv_freq(ocfg.head_dim, ocfg.rope_theta)).to(DEV)
+    res = {}
+    for fused in (False, True):
+        monkeypatch.setattr(layers, "FUSE_AUTOGRAD_NODES", fused)
+        layer = dm.build_module(builder(), config=mcfg, layer_number=1)
+        _load(layer, lp, spec == "te")
+        xh = x.clone().requires_grad_(True)
+        torch.cuda.synchronize()
+        base = torch.cuda.memory_allocated()
+        out, _ = layer(xh, attention_mask=None, rotary_pos_emb=freqs)
+        torch.cuda.synchronize()
+        kept = torch.cuda.memory_allocated() - base
+        out.backward(go)
+        grads = {n: q.grad.clone() for n, q in layer.named_parameters()}
+        res[fused] = (out.detach().clone(), xh.grad.clone(), grads, kept)
+        del layer, out, xh
+    (o0, dx0, g0, kept0), (o1, dx1, g1, kept1) = res[False], res[True]
+    assert torch.equal(o0, o1) and torch.equal(dx0, dx1)
+    for n in g0:
+        if "norm" in n:
+            tol(n, rel_l2(g1[n], g0[n]), 1e-2)
+        else:
+            assert torch.equal(g0[n], g1[n]), n
+    # the gated activation [S, ffn] (and, TE spec, the two normed copies [S, hidden]) are no longer kept
+    saved = S * CFG["ffn"] * 2 + (2 * S * CFG["hidden"] * 2 if spec == "te" else 0)
+    assert kept0 - kept1 >= 0.9 * saved, (kept0, kept1, saved)
