@@ -13,11 +13,16 @@
 // M/core/transformer/dot_product_attention.py:186-289); kv64 used the unrounded value there.
 // LDS images: ONE dual-use image per Q tile and per dO tile (slot XOR swz(row), attn_bwd_kv64.hip's header): A reads Q as fragments
 // and dO transposed, B reads dO as fragments and Q transposed — 32 KB of LDS-DMA per 64-row query tile, rings of three.
-// Pipeline per half u (32 query rows):
-//     B: [16 dP MFMAs of half u + 1 || dS(u), bf16 pack]  [16 dK MFMAs of half u]
-//     A: [16 dV MFMAs of half u || first half of exp2(S(u + 1))]  [16 S MFMAs of half u + 2 || second half, bf16 pack]  hand-over of P(u + 1)
-// A runs its S two halves ahead: the 32 exp2 of a half (the transcendental unit takes ~9 cycles each) then sit behind 32 MFMAs instead
-// of 16 — with S only one half ahead A's second group was VALU-bound and B idled at the barrier (5.75 ms at 16K; this order: see DESIGN 5.1).
+// Pipeline per half u (32 query rows), 16-MFMA groups, one MFMA + its share of the arithmetic per slot:
+//     B: [16 dP MFMAs of half u + 1 || dS(u), k-step 0 (8 pairs, every other slot)]  [16 dK MFMAs of half u || dS(u), k-step 1 under the first 8]
+//     A: [16 dV MFMAs of half u || exp2 of elements 0 .. 15 of S(u + 1)]  [16 S MFMAs of half u + 2 || elements 16 .. 31]  hand-over of P(u + 1)
+// A runs its S two halves ahead: the 32 exp2 of a half (the transcendental unit takes ~16 issue cycles each) then sit behind 32 MFMAs, ONE
+// per slot — with S only one half ahead A's second group was VALU-bound and B idled at the barrier (5.75 ms at 16K), with two exp2 in
+// every other slot 5.5 ms, one per slot 5.3-5.4 ms.  Every group starts from fragments its predecessor read at slot 12 and the lse / delta of
+// a half are fetched a trip ahead, so no group waits for an LDS round trip before its first MFMA (that alone: +- 0: same-box A/B).
+// Timing-only ablations (KVP_ABL, same box, whole backward 8.84 ms): no barriers 8.90, no exp2 8.38, no softmax / dS arithmetic at all 7.9 —
+// the barriers are free, and what the arithmetic costs it costs in power, not in issue slots: 1.25 PFLOP/s executed without it is the
+// chip's ceiling for an LDS-fed MFMA stream on random data (MI355X_MICROARCH.md, DVFS; the forward runs 1.20-1.24).
 #include "attn_bwd_args.h"
 #include <stdlib.h>
 
@@ -26,6 +31,13 @@ namespace {
 constexpr int D = 128, QT = 64, KWG = 128, ROWB = D * 2, TILEB = QT * ROWB;             // 16 KiB per image of a 64-row query tile
 constexpr int LDS_Q = 0, LDS_DO = 3 * TILEB, LDS_ST = 6 * TILEB, LDS_X = LDS_ST + 3 * 512, LDS_TOTAL = LDS_X + 2 * 2 * 4096;
 constexpr float LOG2E = 1.44269504088896340736f;
+constexpr int PF_NONE = 0, PF_FRAG = 1, PF_TR = 2;
+// timing-only ablations (WRONG results; never in libvita_hip.so): -DKVP_ABL=1 no barrier between the two trips of a tile, 2 no exp2,
+// 3 no barrier at all, 5 no softmax / dS arithmetic at all (MFMAs + LDS traffic only), 6 = 5 + 3
+#ifndef KVP_ABL
+#define KVP_ABL 0
+#endif
+constexpr int ABL = KVP_ABL;
 
 typedef __attribute__((address_space(3))) const bf16x8 lds_bf16x8;
 typedef __attribute__((address_space(3))) const f32x4 lds_f32x4;
@@ -176,29 +188,44 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
   unsigned pk[2][2][2][4];                               // A: packed P, B: packed dS  [parity][kb][k-step t'][4 dwords]
   u32x4 pin[2][2];                                       // B: the pair's packed P of the current half, as A wrote it  [kb][t']
   float rstat[16];                                       // A: lse * log2e, B: delta * scale of the 16 rows of a half this lane sees
+  f32x4 stat_raw[4];                                     // ... of the NEXT half, as read from LDS before the barrier (stat_finish scales it)
+  bf16x8 fr_pre[2];                                      // the first two fragments of the NEXT 16-MFMA group, read under the current one
   const unsigned xaddr = lds0 + LDS_X + pair * 4096 + lane * 16;     // + parity * 8192 + (kb * 2 + t') * 1024
 
-  auto load_stat = [&](unsigned st, int qh) __attribute__((always_inline)) {
+  auto stat_fetch = [&](unsigned st, int qh) __attribute__((always_inline)) {     // LDS reads only: issued a group ahead of their use
 #pragma unroll
-    for (int rg = 0; rg < 4; ++rg) {
-      const f32x4 v4 = *(lds_f32x4*)(uintptr_t)(st + (ROLE_B ? 256 : 0) + (32 * qh + 8 * rg + 4 * hi) * 4);
-#pragma unroll
-      for (int j = 0; j < 4; ++j) rstat[rg * 4 + j] = v4[j] * (ROLE_B ? scale : LOG2E);
-    }
+    for (int rg = 0; rg < 4; ++rg) stat_raw[rg] = *(lds_f32x4*)(uintptr_t)(st + (ROLE_B ? 256 : 0) + (32 * qh + 8 * rg + 4 * hi) * 4);
   };
+  auto stat_finish = [&]() __attribute__((always_inline)) {
+#pragma unroll
+    for (int rg = 0; rg < 4; ++rg)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) rstat[rg * 4 + j] = stat_raw[rg][j] * (ROLE_B ? scale : LOG2E);
+  };
+  auto load_stat = [&](unsigned st, int qh) __attribute__((always_inline)) { stat_fetch(st, qh); stat_finish(); };
   // A: P of pair e (kb = e >> 3, registers 2 (e & 7), +1) of buffer `par`, in place
   auto exp_pair = [&](int par, int e) __attribute__((always_inline)) {
+    if (ABL == 2 || ABL >= 5) return;
     const int kb = e >> 3, r = 2 * (e & 7);
     xb[par][kb][r] = __builtin_amdgcn_exp2f(fmaf(xb[par][kb][r], scale_log2e, -rstat[r]));
     xb[par][kb][r + 1] = __builtin_amdgcn_exp2f(fmaf(xb[par][kb][r + 1], scale_log2e, -rstat[r + 1]));
   };
+  // A: P of ONE element (el = 16 kb + r) — one transcendental per MFMA slot: two in one slot (r04 first form) took 40 cycles of issue
+  // against the MFMA's 32 and left the next slot half empty (timing ablations: the softmax arithmetic cost 17 % of the kernel)
+  auto exp_one = [&](int par, int el) __attribute__((always_inline)) {
+    if (ABL == 2 || ABL >= 5) return;
+    const int kb = el >> 4, r = el & 15;
+    xb[par][kb][r] = __builtin_amdgcn_exp2f(fmaf(xb[par][kb][r], scale_log2e, -rstat[r]));
+  };
   auto pack_pair = [&](int par, int e) __attribute__((always_inline)) {          // A: bf16 pair of P
     const int kb = e >> 3, pr = e & 7, r = 2 * pr;
+    if (ABL >= 5) { pk[par][kb][pr >> 2][pr & 3] = __builtin_bit_cast(unsigned, xb[par][kb][r]); return; }
     pk[par][kb][pr >> 2][pr & 3] = pack_bf16x2(xb[par][kb][r], xb[par][kb][r + 1]);
     asm volatile("" :: "v"(pk[par][kb][pr >> 2][pr & 3]));                       // computed HERE (no sinking past the phase)
   };
   auto ds_pair = [&](int par, int e) __attribute__((always_inline)) {            // B: dS = P o (dP scale - delta scale), packed
     const int kb = e >> 3, pr = e & 7, r = 2 * pr;
+    if (ABL >= 5) { pk[par][kb][pr >> 2][pr & 3] = pin[kb][pr >> 2][pr & 3] ^ __builtin_bit_cast(unsigned, xb[par][kb][r]); return; }
     const unsigned w = pin[kb][pr >> 2][pr & 3];
     const float a = bf16lo_to_f32(w) * fmaf(xb[par][kb][r], scale, -rstat[r]);
     const float b = bf16hi_to_f32(w) * fmaf(xb[par][kb][r + 1], scale, -rstat[r + 1]);
@@ -245,13 +272,23 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
   };
   // 16 slots: X(rows qh_n of the image at `img`) = rows x own fragments -> buffer par ^ 1   (A: S = Q K^T, B: dP = dO V^T);
   // FILL works on buffer `par`: B — dS / pack of its 16 pairs; A — exp2 of pairs 8 .. 15 (even slots) and their bf16 pack (odd slots)
-  auto x_group = [&](int par, unsigned img, int qh_n, bool fill) __attribute__((always_inline)) {
+  // PF_NONE | PF_FRAG (the next group is an x_group: rows pf_qh of the image at pf_img) | PF_TR (a g_group: half pf_qh of pf_img): the
+  // group's own fragment reads end at slot 10; at slot 12 it reads the first two fragments of the NEXT group into fr_pre, so that the
+  // group after a barrier (or after this one) starts its MFMAs at once instead of behind an LDS round trip.  use_pre: take them.
+  auto prefetch = [&](int pf, unsigned pf_img, int pf_qh) __attribute__((always_inline)) {
+    if (pf == PF_FRAG) { fr_pre[0] = frag(pf_img, 0, pf_qh); fr_pre[1] = frag(pf_img, 1, pf_qh); }
+    if (pf == PF_TR) { fr_pre[0] = tr_frag(pf_img, 2 * pf_qh, 0); fr_pre[1] = tr_frag(pf_img, 2 * pf_qh, 1); }
+  };
+  auto x_group = [&](int par, unsigned img, int qh_n, bool fill, bool use_pre, int pf, unsigned pf_img, int pf_qh, bool pf_stat,
+                     unsigned pf_st, int pf_st_qh) __attribute__((always_inline)) {
     bf16x8 fr[4];
-    fr[0] = frag(img, 0, qh_n); fr[1] = frag(img, 1, qh_n);
+    if (use_pre) { fr[0] = fr_pre[0]; fr[1] = fr_pre[1]; }
+    else { fr[0] = frag(img, 0, qh_n); fr[1] = frag(img, 1, qh_n); }
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int ds = s >> 1, kb = s & 1;
       if (kb == 0 && ds + 2 < 8) fr[(ds + 2) & 3] = frag(img, ds + 2, qh_n);
+      if (s == 12) { prefetch(pf, pf_img, pf_qh); if (pf_stat) stat_fetch(pf_st, pf_st_qh); }
       if (ds == 0) {
         f32x16 z;
 #pragma unroll
@@ -260,33 +297,45 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
       } else {
         xb[par ^ 1][kb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[ds & 3], wf[kb][ds], xb[par ^ 1][kb], 0, 0, 0);
       }
-      if (ROLE_B && fill) ds_pair(par, s);
-      if (!ROLE_B && fill) {
-        if ((s & 1) == 0) exp_pair(par, 8 + (s >> 1));
-        else pack_pair(par, 8 + (s >> 1));
+      if (ROLE_B && fill && s >= 2 && ((s & 1) == 0 || s == 15)) {
+        // B: the eight dS pairs the dK group's FIRST eight MFMAs read (k-step 0: pairs 0 .. 3 of both key blocks), every other slot,
+        // from slot 2 on (P was read after the barrier); the other eight are formed under those MFMAs (g_group)
+        const int i = s == 15 ? 7 : (s - 2) >> 1;
+        ds_pair(par, (i >> 2) * 8 + (i & 3));
+      }
+      if (!ROLE_B && fill) {                                  // A: elements 16 .. 31 of S(u + 1), one exp2 per slot; a pair is packed a slot late
+        exp_one(par, 16 + s);
+        if (s >= 2 && (s & 1) == 0) pack_pair(par, 8 + ((s - 2) >> 1));
       }
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (!ROLE_B && fill) pack_pair(par, 15);
   };
   // 16 slots: gradient^T += X^T(half qh of the image at `img`, transposed reads) packed(par)   (A: dV^T += dO^T P, B: dK^T += Q^T dS);
   // A with FILL: exp2 of pairs 0 .. 7 of buffer par ^ 1 (even slots) and their bf16 pack (odd slots: an exp2 result is never consumed
   // by the next instruction) behind the MFMAs
-  auto g_group = [&](int par, unsigned img, int qh, bool fill) __attribute__((always_inline)) {
+  auto g_group = [&](int par, unsigned img, int qh, bool fill, bool use_pre, int pf, unsigned pf_img, int pf_qh, bool pf_stat,
+                     unsigned pf_st, int pf_st_qh) __attribute__((always_inline)) {
     bf16x8 tr[4];
-    tr[0] = tr_frag(img, 2 * qh, 0); tr[1] = tr_frag(img, 2 * qh, 1);
+    if (use_pre) { tr[0] = fr_pre[0]; tr[1] = fr_pre[1]; }
+    else { tr[0] = tr_frag(img, 2 * qh, 0); tr[1] = tr_frag(img, 2 * qh, 1); }
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int i = s >> 1, kb = s & 1, t2 = i >> 2, db = i & 3;
       if (kb == 0 && i + 2 < 8) tr[(i + 2) & 3] = tr_frag(img, 2 * qh + ((i + 2) >> 2), (i + 2) & 3);
+      if (s == 12) { prefetch(pf, pf_img, pf_qh); if (pf_stat) stat_fetch(pf_st, pf_st_qh); }
       const u32x4 pw = {pk[par][kb][t2][0], pk[par][kb][t2][1], pk[par][kb][t2][2], pk[par][kb][t2][3]};
-      const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
-      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o[kb][db]) : "v"(tr[i & 3]), "v"(pf));
-      if (!ROLE_B && fill) {
-        if ((s & 1) == 0) exp_pair(par ^ 1, s >> 1);
-        else pack_pair(par ^ 1, s >> 1);
+      const bf16x8 pf8 = __builtin_bit_cast(bf16x8, pw);
+      asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o[kb][db]) : "v"(tr[i & 3]), "v"(pf8));
+      if (!ROLE_B && fill) {                                  // A: elements 0 .. 15 of S(u + 1)
+        exp_one(par ^ 1, s);
+        if (s >= 2 && (s & 1) == 0) pack_pair(par ^ 1, (s - 2) >> 1);
       }
+      // B: dS pairs 4 .. 7 (k-step 1) of key block 0 under slots 0 .. 3, of key block 1 under slots 4 .. 7; first read by slots 8 / 9
+      if (ROLE_B && fill && s < 8) ds_pair(par, (s >> 2) * 8 + 4 + (s & 3));
       __builtin_amdgcn_sched_barrier(0);
     }
+    if (!ROLE_B && fill) pack_pair(par ^ 1, 7);
   };
   auto needs_mask = [&](const QTileIt& t) __attribute__((always_inline)) { return t.diag && t.j * QT < k_off_wg + KWG; };
   // VALU result -> inline-asm MFMA operand: wait states the compiler does not know are needed, tied to the operands
@@ -296,6 +345,7 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
   };
   auto pair_barrier = [&]() __attribute__((always_inline)) {       // LDS hand-over visible to the partner (whole workgroup: one barrier kind)
     asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (ABL == 3 || ABL == 6) return;
     __builtin_amdgcn_s_barrier();
   };
 
@@ -313,7 +363,8 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
   __syncthreads();
   const unsigned IMG_X = ROLE_B ? LDS_DO : LDS_Q;        // the image this role reads as fragments (dO for dP, Q for S)
   const unsigned IMG_G = ROLE_B ? LDS_Q : LDS_DO;        // ... and transposed (Q^T for dK, dO^T for dV)
-  x_group(1, lds0 + IMG_X, 0, false);                    // -> buffers 0
+  // B: dP(0) -> buffers 0, and under it the first fragments of trip 0's x_group (dO rows 32 ..) + delta of half 0
+  x_group(1, lds0 + IMG_X, 0, false, false, ROLE_B ? PF_FRAG : PF_NONE, lds0 + IMG_X, 1, ROLE_B, lds0 + LDS_ST, 0);
   if (!ROLE_B) {
     if (needs_mask(cur)) mask_half(0, cur.j * QT);
     load_stat(lds0 + LDS_ST, 0);
@@ -323,54 +374,69 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
     for (int e = 0; e < 16; ++e) pack_pair(0, e);
     hand_over(0);
     settle(0);
-    x_group(0, lds0 + IMG_X, 1, false);                  // A runs two halves ahead: S(1) -> buffers 1 (tile 0 always has both halves)
+    // A runs two halves ahead: S(1) -> buffers 1 (tile 0 always has both halves); under it the first dO^T fragments of trip 0's g_group
+    // and the lse of half 1
+    x_group(0, lds0 + IMG_X, 1, false, false, PF_TR, lds0 + IMG_G, 0, true, lds0 + LDS_ST, 1);
     if (needs_mask(cur)) mask_half(1, cur.j * QT + 32);
   }
   pair_barrier();
 
   // ---- main loop: one tile = two trips (half qh = buffer parity qh) ------------------------------------------------------------------------
+  // Every 16-MFMA group starts from fragments its predecessor read at slot 12 (fr_pre) and the statistics of a half are fetched a trip
+  // ahead (stat_raw), so that neither the group after a barrier nor the second group of a trip waits for an LDS round trip before its
+  // first MFMA (r04 first form: 11 ds_reads and an s_waitcnt between s_barrier and the first MFMA of every trip).
   int s3 = 0, s3n = 1, s3nn = 2;                         // ring slots of tiles t, t+1, t+2
-  // one trip: half u = (tile in ring slot `sl`, half qh) in buffers `par`; half u + 1 = (tile `tn` in slot `sln`, half qh_n) if has_next;
-  // half u + 2 = (tile nx1 in slot s3n, half qh_2) if has_next2 (it always lies in tile t + 1)
-  auto trip = [&](int par, int sl, int qh, const QTileIt& tn, int sln, int qh_n, const bool has_next, int qh_2, const bool has_next2)
-      __attribute__((always_inline)) {
-    const unsigned img_g = lds0 + IMG_G + sl * TILEB;
-    if (ROLE_B) {
-      take_over(par);                                    // P(u), written by A before the last barrier
-      load_stat(lds0 + LDS_ST + sl * 512, qh);           // delta of half u
-      if (has_next) {
-        x_group(par, lds0 + IMG_X + sln * TILEB, qh_n, true);               // dP(u + 1)  ||  dS(u)
-      } else {
-#pragma unroll
-        for (int e = 0; e < 16; ++e) ds_pair(par, e);
-      }
-      settle(par);
-      g_group(par, img_g, qh, false);                    // dK^T += Q^T dS(u)
-    } else {
-      // A holds P(u) packed in pk[par] and the raw (masked) S(u + 1) in buffers par ^ 1
-      if (has_next) load_stat(lds0 + LDS_ST + sln * 512, qh_n);             // lse of half u + 1
-      g_group(par, img_g, qh, has_next);                 // dV^T += dO^T P(u)  ||  exp2 / pack of pairs 0 .. 7 of S(u + 1)
-      if (has_next) {
-        if (has_next2) {
-          x_group(par ^ 1, lds0 + IMG_X + s3n * TILEB, qh_2, true);        // S(u + 2) -> buffers par  ||  pairs 8 .. 15 of S(u + 1)
-        } else {
-#pragma unroll
-          for (int e = 8; e < 16; ++e) exp_pair(par ^ 1, e);
-#pragma unroll
-          for (int e = 8; e < 16; ++e) pack_pair(par ^ 1, e);
-        }
-        hand_over(par ^ 1);                              // P(u + 1) -> the partner, before the barrier that ends this trip
-        if (has_next2 && needs_mask(nx1)) mask_half(par, nx1.j * QT + 32 * qh_2);       // wave-uniform, diagonal tiles only
-      }
-    }
-  };
   auto iteration = [&](const bool has1, const bool has2) __attribute__((always_inline)) {
     if (has2) dma_tile(nx2, s3nn);                       // that slot held tile t-1 (last read before the previous tile barrier)
-    trip(0, s3, 0, cur, s3, 1, true, 0, has1);           // u = 2 t:     u + 1 = (tile t, rows 32 ..),    u + 2 = (tile t + 1, rows 0 ..)
-    pair_barrier();
-    trip(1, s3, 1, nx1, s3n, 0, has1, 1, has1);          // u = 2 t + 1: u + 1 = (tile t + 1, rows 0 ..), u + 2 = (tile t + 1, rows 32 ..)
+    const unsigned x_cur = lds0 + IMG_X + s3 * TILEB, x_nxt = lds0 + IMG_X + s3n * TILEB;
+    const unsigned g_cur = lds0 + IMG_G + s3 * TILEB, g_nxt = lds0 + IMG_G + s3n * TILEB;
+    const unsigned st_cur = lds0 + LDS_ST + s3 * 512, st_nxt = lds0 + LDS_ST + s3n * 512;
+    // ---- trip 0: half u = (tile t, rows 0 ..) in buffers 0; u + 1 = (tile t, rows 32 ..); u + 2 = (tile t + 1, rows 0 ..) if has1 ---------
+    if (ROLE_B) {
+      take_over(0);                                      // P(u), written by A before the last barrier
+      stat_finish();                                     // delta of half u (fetched under the previous trip's dK group)
+      x_group(0, x_cur, 1, true, true, PF_TR, g_cur, 0, false, 0, 0);                              // dP(u + 1)  ||  dS(u)
+      settle(0);
+      g_group(0, g_cur, 0, true, true, has1 ? PF_FRAG : PF_TR, has1 ? x_nxt : g_cur, has1 ? 0 : 1, true, st_cur, 1);   // dK^T += Q^T dS(u)  ||  dS(u), k-step 1
+    } else {
+      // A holds P(u) packed in pk[0] and the raw (masked) S(u + 1) in buffers 1
+      stat_finish();                                     // lse of half u + 1
+      g_group(0, g_cur, 0, true, true, has1 ? PF_FRAG : PF_TR, has1 ? x_nxt : g_cur, has1 ? 0 : 1, false, 0, 0);   // dV^T += dO^T P(u) || exp2 0 .. 7 of S(u + 1)
+      if (has1) {
+        x_group(1, x_nxt, 0, true, true, PF_TR, g_cur, 1, true, st_nxt, 0);                      // S(u + 2) -> buffers 0  ||  pairs 8 .. 15 of S(u + 1)
+      } else {
+#pragma unroll
+        for (int e = 8; e < 16; ++e) exp_pair(1, e);
+#pragma unroll
+        for (int e = 8; e < 16; ++e) pack_pair(1, e);
+      }
+      hand_over(1);                                      // P(u + 1) -> the partner, before the barrier that ends this trip
+      if (has1 && needs_mask(nx1)) mask_half(0, nx1.j * QT);                                       // wave-uniform, diagonal tiles only
+    }
+    if (ABL != 1) pair_barrier();
+    // ---- trip 1: half u = (tile t, rows 32 ..) in buffers 1; u + 1, u + 2 = the two halves of tile t + 1 if has1 ---------------------------
+    if (ROLE_B) {
+      take_over(1);
+      stat_finish();
+      if (has1) {
+        x_group(1, x_nxt, 0, true, true, PF_TR, g_cur, 1, false, 0, 0);                            // dP(u + 1)  ||  dS(u)
+      } else {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) ds_pair(1, e);
+      }
+      settle(1);
+      g_group(1, g_cur, 1, has1, true, has1 ? PF_FRAG : PF_NONE, x_nxt, 1, has1, st_nxt, 0);       // next: trip 0 of tile t + 1 (dO rows 32 .., delta of rows 0 ..)
+    } else {
+      if (has1) stat_finish();                           // lse of (tile t + 1, rows 0 ..)
+      g_group(1, g_cur, 1, has1, true, has1 ? PF_FRAG : PF_NONE, x_nxt, 1, false, 0, 0);
+      if (has1) {
+        x_group(0, x_nxt, 1, true, true, PF_TR, g_nxt, 0, true, st_nxt, 1);                      // S(u + 2) -> buffers 1; next: trip 0 of tile t + 1
+        hand_over(0);
+        if (needs_mask(nx1)) mask_half(1, nx1.j * QT + 32);
+      }
+    }
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __syncthreads();
+    if (ABL != 3 && ABL != 6) __syncthreads();
     cur = nx1; nx1 = nx2;
     if (has2) advance(nx2);
     const int tmp = s3; s3 = s3n; s3n = s3nn; s3nn = tmp;

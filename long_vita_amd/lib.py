@@ -19,6 +19,8 @@ import threading
 _HERE = os.path.dirname(os.path.abspath(__file__))
 CSRC_DIR = os.path.join(_HERE, "csrc")
 LIB_PATH = os.path.join(CSRC_DIR, "libvita_hip.so")
+if os.environ.get("VITA_HIP_LIB"):                    # developer A / B switch: another build of the SAME library (tools/microbench.py, same box)
+    LIB_PATH = os.path.abspath(os.environ["VITA_HIP_LIB"])
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "vita_hip.h")
 
 ABI_VERSION = 15
