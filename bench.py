@@ -319,12 +319,15 @@ def main():
     # HBM traffic of that kernel: PMC counters cannot be read from inside this process; when a
     # rocprofv3 --pmc measurement of the same launch shape is committed under profiles/, report it
     traffic, traffic_src = None, None
-    try:
-        pmc = json.load(open(os.path.join(ROOT, "profiles", "r03_attn128k_pmc.json")))
-        if pmc["seq"] == seq and pmc["n_gpus"] == world:
-            traffic, traffic_src = pmc["hbm_bytes_per_launch"], "profiles/r03_attn128k_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, offline)"
-    except (OSError, KeyError, ValueError):
-        pass
+    for tag in ("r04", "r03"):                      # the newest committed measurement of this launch shape
+        try:
+            pmc = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_attn128k_pmc.json")))
+            if pmc["seq"] == seq and pmc["n_gpus"] == world:
+                traffic = pmc["hbm_bytes_per_launch"]
+                traffic_src = f"profiles/{tag}_attn128k_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, offline)"
+                break
+        except (OSError, KeyError, ValueError):
+            continue
 
     ms_per_step = dt / args.steps * 1e3
     value = seq / (dt / args.steps)
