@@ -2,7 +2,7 @@
 M/training/training.py `timers(...)`; on this path the marks are roctx ranges that `rocprofv3 --marker-trace --kernel-trace` lines up with
 the kernels).
 
-Off (the default) every call is one attribute test; on, `libroctx64.so` is loaded from the ROCm the process already uses — it is a
+Off (the default) every call is one attribute test; on, `librocprofiler-sdk-roctx.so` (else `libroctx64.so`) is loaded from the ROCm the process already uses — it is a
 tracing dependency only, nothing on the compute path touches it, and a missing library turns the ranges into no-ops with one warning.
 
     VITA_DEBUG=1 rocprofv3 --marker-trace --kernel-trace --stats -d out -- python bench.py --steps 1 --warmup 0
@@ -24,7 +24,9 @@ def _load():
     if _tried:
         return _lib
     _tried = True
-    for name in ("libroctx64.so", "libroctx64.so.4", "/opt/rocm/lib/libroctx64.so"):
+    # rocprofv3 records the ranges of rocprofiler-sdk's roctx library; the roctracer-era libroctx64 is the fallback (older tools)
+    for name in ("librocprofiler-sdk-roctx.so", "/opt/rocm/lib/librocprofiler-sdk-roctx.so", "libroctx64.so", "libroctx64.so.4",
+                 "/opt/rocm/lib/libroctx64.so"):
         try:
             lib = ctypes.CDLL(name)
             lib.roctxRangePushA.argtypes = [ctypes.c_char_p]

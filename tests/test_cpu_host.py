@@ -1087,3 +1087,21 @@ def test_roctx_ranges_are_off_by_default_and_nest_under_vita_debug():
     r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, env=env, cwd=ROOT, timeout=300)
     assert r.returncode == 0, r.stderr[-2000:]
     assert "OK" in r.stdout or "NOLIB" in r.stdout
+
+
+def test_tn_split_choice_never_leaves_an_empty_range_and_keeps_big_gradients_unsplit():
+    """ops.tn_splits (host cost model of vita_gemm_bf16_tn_splitk): every range of the contraction is non-empty (the C side rejects an
+    empty last range), the fp32 partials stay under 2 GiB, the decoder's wide gradients at 16K keep the one-pass kernel, the ViT's
+    few-tile gradients and config 5's TP-halved qkv gradient are split."""
+    from long_vita_amd import ops
+    import itertools
+    for M, N, K in itertools.product((256, 1024, 3584, 5120, 13824, 27648), (256, 1024, 4096, 5120), (512, 4096, 16384, 65600, 131072)):
+        S = ops.tn_splits(M, N, K)
+        nk = K // 64
+        per = -(-nk // S)
+        assert S >= 1 and nk - per * (S - 1) >= 1, (M, N, K, S)
+        assert S == 1 or S * M * N * 4 <= (2 << 30), (M, N, K, S)
+    assert ops.tn_splits(27648, 5120, 16384) == 1            # fc1 at 16K: 2160 tiles
+    assert ops.tn_splits(13824, 5120, 16384) == 1
+    assert ops.tn_splits(1024, 1024, 253 * 1025 // 64 * 64) > 1          # a ViT projection over 253 frames: 16 tiles
+    assert ops.tn_splits(3584, 5120, 32768) > 1                # config 5: qkv at TP = 2
