@@ -643,15 +643,21 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   const char* const ap = uniform_ptr(TN ? p.A + m0 : p.A + m0 * p.lda);
   const char* const wp = uniform_ptr(TN ? p.W + n0 : p.W + n0 * p.ldw);
   const int64_t kstep_a = TN ? (int64_t)BK * p.lda * 2 : BK * 2, kstep_w = TN ? (int64_t)BK * p.ldw * 2 : BK * 2;
-  int64_t koff_a = SPLITK ? (int64_t)split * p.k_tiles_per_split * kstep_a : 0;            // byte offsets of the K tile fetched next
-  int64_t koff_w = SPLITK ? (int64_t)split * p.k_tiles_per_split * kstep_w : 0;
+  // developer aid VITA_GEMM_STAGGER=1 (NT, no split): XCD x starts its K loop at tile x nk / 8 and wraps, so that the eight XCDs do not
+  // pull the same K range of their panels through the fabric at the same time (the accumulation order of a tile then depends on its XCD)
+  int kt_fetch = (!TN && !SPLITK && p.stagger == 1) ? (int)(((int64_t)(blockIdx.x & 7) * nk) >> 3) : 0;
+  int64_t koff_a = SPLITK ? (int64_t)split * p.k_tiles_per_split * kstep_a : kt_fetch * kstep_a;     // byte offsets of the K tile fetched next
+  int64_t koff_w = SPLITK ? (int64_t)split * p.k_tiles_per_split * kstep_w : kt_fetch * kstep_w;
   auto dma_piece = [&](unsigned stage, int j) __attribute__((always_inline)) {              // j = 0..7: A lines, 8..15: W lines
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(j < 8 ? ap + koff_a : wp + koff_w), 0, 0x7fffffff, 0x00020000);
     const int i = j & 7;
     __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(uintptr_t)(stage + (j < 8 ? 0 : OPBS) + d_line0 + i * PIECE), 16,
                                              j < 8 ? voff_a[i] : voff_w[i], 0, 0, 0);
   };
-  auto next_tile = [&]() __attribute__((always_inline)) { koff_a += kstep_a; koff_w += kstep_w; };
+  auto next_tile = [&]() __attribute__((always_inline)) {
+    koff_a += kstep_a; koff_w += kstep_w;
+    if (!TN && !SPLITK && ++kt_fetch == nk) { kt_fetch = 0; koff_a = 0; koff_w = 0; }
+  };
 
   // ---- fragment reads: lane -> (row lane % 16) * LINE + (k chunk lane / 16) * 16, + row block * 128 + k half * 64 ------------------
   const unsigned rd_a = (unsigned)(wm * HALF + (lane & 15) * LINE + (lane >> 4) * 16);
