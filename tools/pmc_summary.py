@@ -5,7 +5,11 @@ def main(root):
     for f in glob.glob(root + "/**/*counter_collection.csv", recursive=True):
         for row in csv.DictReader(open(f)):
             k = row["Kernel_Name"]
-            if "flash_fwd64" in k: k = "flash_fwd64"
+            if "attn_bwd_kvp" in k: k = "attn_bwd_kvp (dK + dV)"
+            elif "attn_bwd_dq64" in k: k = "attn_bwd_dq64 (dQ)"
+            elif "attn_delta" in k: k = "attn_delta (pre-pass)"
+            elif "attn_bwd" in k: k = k.split("::")[-1].split("(")[0][:60]
+            elif "flash_fwd64" in k: k = "flash_fwd64"
             elif "flash_fwd" in k: k = "flash_fwd<" + ("128" if "128" in k else "64") + ">"
             elif "gemm_bf16" in k: k = "gemm_bf16<" + k.split("<")[1].split(">")[0] + ">"
             elif "gemm_w4" in k: k = "gemm_w4<" + k.split("<")[1].split(">")[0] + ">"
