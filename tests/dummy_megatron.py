@@ -15,8 +15,9 @@ not vendor) that BUILD and CALL the modules this repo replaces — test infrastr
     M/core/transformer/transformer_block.py:16-18,201 imports and calls it; `--recompute-granularity full --recompute-method block
     --recompute-num-layers N` through `tensor_parallel.checkpoint`), tensor_parallel.checkpoint itself (CheckpointFunction of
     megatron/core/tensor_parallel/random.py restated: forward under no_grad keeping the inputs and the RNG states, backward = the
-    function re-run with autograd on — the way Megatron RE-ENTERS this package's autograd Functions), a `GPTVLModel` shell that
-    builds `external_feature_model` the way the reference's does (gpt_vl_model.py:110-113), and `MegatronVisionModel`: the class
+    function re-run with autograd on — the way Megatron RE-ENTERS this package's autograd Functions), `GPTVLModel`: the reference's
+    `__init__` (gpt_vl_model.py:73-180) and the training branch of its `forward` (:233-416) restated over the names it imports, with
+    `forward_step` / `loss_func` of the entry script (pretrain_long_vita.py:778-869) and Megatron's RotaryEmbedding (angle table), and `MegatronVisionModel`: the class
     of the reference's ENTRY SCRIPT (M/pretrain_long_vita.py:310-520) restated as plain torch — constructor wiring, forward_once /
     forward_chunk / forward, the torch pixel_shuffle and torch.nn.LayerNorm the drop-in has to displace.
 No arithmetic lives here except the SwiGLU of Megatron's MLP (`F.silu(gate) * up`, computed through the product's SwiGLUFn so
@@ -360,16 +361,137 @@ class TransformerBlock(torch.nn.Module):
         return hidden_states
 
 
+class RotaryEmbedding(torch.nn.Module):
+    """megatron.core.models.common.embeddings.rotary_pos_embedding.RotaryEmbedding (the reference leaves it unpatched,
+    M/megatron_adaptor.py:102-103): the fp32 ANGLE tensor [s, 1, 1, dim] every layer's apply_rotary_pos_emb receives.  CP = 1 here."""
+
+    def __init__(self, kv_channels, rotary_percent=1.0, rotary_interleaved=False, seq_len_interpolation_factor=None, rotary_base=10000):
+        super().__init__()
+        dim = kv_channels if rotary_percent >= 1.0 else int(kv_channels * rotary_percent)
+        self.inv_freq = 1.0 / (rotary_base ** (torch.arange(0, dim, 2, dtype=torch.float32) / dim))
+
+    def forward(self, max_seq_len, offset=0):
+        seq = torch.arange(max_seq_len, dtype=torch.float32) + offset
+        freqs = torch.outer(seq, self.inv_freq)
+        return torch.cat((freqs, freqs), dim=-1)[:, None, None, :]
+
+    def get_rotary_seq_len(self, inference_params, transformer, transformer_input, transformer_config):
+        return transformer_input.size(0) if transformer_input is not None else transformer.input_tensor.size(0)
+
+
+ARGS = types.SimpleNamespace(output_multiplier_scale=None, output_logit_softcapping=None, is_instruction_dataset=True,
+                             context_parallel_size=1)           # what get_args() returns to GPTVLModel.forward / loss_func
+
+
 class GPTVLModel(torch.nn.Module):
-    """The part of long_vita_megatron.core.models.multimodal.gpt_vl_model.GPTVLModel.__init__ the vision drop-in hangs on (:110-113):
-    `self.external_feature_model = external_feature_model_provider(config, *external_args)`."""
+    """long_vita_megatron.core.models.multimodal.gpt_vl_model.GPTVLModel restated: `__init__` (:73-180 — external_feature_model from
+    its provider (:110-113), LanguageModelEmbedding, RotaryEmbedding, TransformerBlock, the ColumnParallelLinear output layer, `unused`)
+    and the training branch of `forward` (:233-416).  Every class it instantiates is looked up under the dotted name the reference
+    imports it from, i.e. it is whatever the adaptors left there.  transformer_layer_spec = None keeps the r04 shell (vision tests):
+    only the external feature model is built."""
 
     def __init__(self, config, transformer_layer_spec=None, vocab_size=0, max_sequence_length=0, pre_process=True, post_process=True,
-                 external_feature_model_provider=None, external_args=(), **kwargs):
+                 fp16_lm_cross_entropy=False, parallel_output=True, share_embeddings_and_output_weights=False,
+                 position_embedding_type="learned_absolute", rotary_percent=1.0, rotary_base=10000, seq_len_interpolation_factor=None,
+                 external_feature_model_provider=None, external_args=(), allow_missing_keys=(), **kwargs):
         super().__init__()
         self.config, self.pre_process, self.post_process = config, pre_process, post_process
+        self.vocab_size, self.max_sequence_length = vocab_size, max_sequence_length
+        self.position_embedding_type, self.share_embeddings_and_output_weights = position_embedding_type, share_embeddings_and_output_weights
         if pre_process:
-            self.external_feature_model = external_feature_model_provider(config, *external_args)
+            self.external_feature_model = external_feature_model_provider(config, *external_args)                     # :110-113
+        if transformer_layer_spec is None:
+            return
+        if pre_process:
+            emb = sys.modules["megatron.core.models.common.embeddings.language_model_embedding"].LanguageModelEmbedding
+            self.embedding = emb(config=config, vocab_size=vocab_size, max_sequence_length=max_sequence_length,
+                                 position_embedding_type=position_embedding_type)                                      # :115-120
+        if position_embedding_type == "rope":
+            self.rotary_pos_emb = RotaryEmbedding(kv_channels=config.kv_channels, rotary_percent=rotary_percent,
+                                                  rotary_interleaved=config.rotary_interleaved,
+                                                  seq_len_interpolation_factor=seq_len_interpolation_factor, rotary_base=rotary_base)
+        block = sys.modules["megatron.core.transformer.transformer_block"].TransformerBlock
+        self.decoder = block(config=config, spec=transformer_layer_spec, pre_process=pre_process, post_process=post_process)   # :132-137
+        if post_process:
+            # `tensor_parallel.ColumnParallelLinear`: the package re-exports megatron.core.tensor_parallel.layers' class (:156-167)
+            cpl = sys.modules["megatron.core.tensor_parallel.layers"].ColumnParallelLinear
+            self.output_layer = cpl(config.hidden_size, vocab_size, config=config, init_method=config.init_method, bias=False,
+                                    skip_bias_add=False, gather_output=not parallel_output,
+                                    skip_weight_param_allocation=pre_process and share_embeddings_and_output_weights,
+                                    embedding_activation_buffer=None, grad_output_buffer=None)
+        self.unused = torch.nn.Parameter(0.01 * torch.ones(config.hidden_size))                                         # :180
+
+    def compute_language_model_loss(self, labels, logits):
+        """megatron.core.models.common.language_module.LanguageModule.compute_language_model_loss."""
+        labels = labels.transpose(0, 1).contiguous()                                     # [b s] => [s b]
+        loss = sys.modules["megatron.core.tensor_parallel"].vocab_parallel_cross_entropy(logits.float(), labels)
+        return loss.transpose(0, 1).contiguous()                                         # [s b] => [b s]
+
+    def forward(self, input_ids, position_ids, attention_mask, decoder_input=None, labels=None, inference_params=None,
+                packed_seq_params=None, extra_block_kwargs=None, external_inputs={}, tokentype_ids=None, logit_mask=None):
+        args = ARGS
+        if decoder_input is not None:
+            pass
+        elif self.pre_process:
+            if external_inputs:                                                           # :264-272
+                external_feature = self.external_feature_model(**external_inputs)
+                external_feature_dict = {"features": external_feature}
+                for k in external_inputs:
+                    if "indices" in k or "pre_len" == k:
+                        external_feature_dict[k] = external_inputs[k]
+                decoder_input = self.embedding(input_ids=input_ids, position_ids=position_ids, external_feature_dict=external_feature_dict)
+            else:
+                decoder_input = self.embedding(input_ids=input_ids, position_ids=position_ids)
+        rotary_pos_emb = None
+        if self.position_embedding_type == "rope":                                        # :287-295
+            rotary_seq_len = self.rotary_pos_emb.get_rotary_seq_len(inference_params, self.decoder, decoder_input, self.config)
+            rotary_pos_emb = self.rotary_pos_emb(rotary_seq_len).to(decoder_input.device)
+        hidden_states = self.decoder(hidden_states=decoder_input, attention_mask=attention_mask, inference_params=inference_params,
+                                     rotary_pos_emb=rotary_pos_emb, packed_seq_params=packed_seq_params, **(extra_block_kwargs or {}))
+        hidden_states = hidden_states.clone()                                             # :310-311
+        hidden_states += 0.0 * self.unused
+        if not self.post_process:
+            return hidden_states
+        logits, _ = self.output_layer(hidden_states, weight=None, logit_mask=logit_mask)   # :339
+        if args.output_multiplier_scale:                                                  # :349-355
+            logits = logits * args.output_multiplier_scale
+        if args.output_logit_softcapping:
+            logits = logits / args.output_logit_softcapping
+            logits = torch.tanh(logits)
+            logits = logits * args.output_logit_softcapping
+        if labels is None:
+            return logits.transpose(0, 1).contiguous()                                    # :370
+        if logit_mask is not None:                                                        # :372-384
+            b = logit_mask.size(0)
+            assert b == 1
+            with torch.no_grad():
+                labels = torch.masked_select(labels, logit_mask).reshape(b, -1)
+        if args.is_instruction_dataset:                                                   # :389-391
+            labels = labels[:, 1:].contiguous()
+            logits = logits[:-1, :, :].contiguous()
+        if logits.sum().isnan():
+            raise ValueError("found NaN in local forward logits calculation.")
+        return self.compute_language_model_loss(labels, logits)                           # :414
+
+
+def loss_func(loss_mask, output_tensor):
+    """M/pretrain_long_vita.py:778-839 without its logging: (sum of the masked losses x CP, number of tokens)."""
+    args = ARGS
+    losses = output_tensor.float()
+    loss_mask = loss_mask[..., 1:].reshape(-1).float() if args.is_instruction_dataset else loss_mask.reshape(-1).float()
+    total_tokens = loss_mask.sum()
+    loss = torch.cat([torch.sum(losses.view(-1) * loss_mask).view(1), total_tokens.view(1)])
+    return loss[0] * args.context_parallel_size, loss[1].clone().detach().to(torch.int)
+
+
+def forward_step(batch, model, use_logit_mask=True):
+    """M/pretrain_long_vita.py:841-869: (tokens, labels, loss_mask, attention_mask, position_ids, external_inputs) -> (output, loss_func)."""
+    tokens, labels, loss_mask, attention_mask, position_ids, external_inputs = batch
+    logit_mask = loss_mask.bool() if use_logit_mask else None                            # args.logit_mask (:858-860)
+    output_tensor = model(tokens, position_ids, attention_mask, labels=labels, external_inputs=external_inputs, logit_mask=logit_mask)
+    if use_logit_mask:                                                                    # :866-867
+        loss_mask = torch.ones(output_tensor.size(0), output_tensor.size(1) + 1, dtype=output_tensor.dtype, device=output_tensor.device)
+    return output_tensor, (lambda out: loss_func(loss_mask, out))
 
 
 class MegatronVisionModel(torch.nn.Module):

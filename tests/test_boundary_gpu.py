@@ -464,7 +464,7 @@ def test_siglip_layer_built_by_megatron_at_its_real_sizes(megatron):
 # r04 — the rest of the path under the reference's entry classes (VERDICT r3 "missing" 1): ViT front end, downsample + projector,
 # final norm, loss; activation recompute re-entering the autograd Functions
 # ---------------------------------------------------------------------------------------------------------------------------------
-def _vision_model(ovit, vcfg, vp, args_over=None, vit_grad=True):
+def _vision_model(ovit, vcfg, vp, args_over=None, vit_grad=True, llm_cfg=None, gpt_kwargs=None):
     """MegatronVisionModel (the entry script's class: tests/dummy_megatron.py restates it in plain torch) constructed through the
     PATCHED names — InternViTModel, the ViT layer spec, MultimodalProjector — inside a GPTVLModel whose __init__ the adaptor wrapped."""
     import types
@@ -482,7 +482,8 @@ def _vision_model(ovit, vcfg, vp, args_over=None, vit_grad=True):
     a.update(args_over or {})
     args = types.SimpleNamespace(**a)
     gpt_cls = sys.modules["long_vita_megatron.core.models.multimodal.gpt_vl_model"].GPTVLModel
-    model = gpt_cls(proj_cfg, external_feature_model_provider=lambda cfg: dm.MegatronVisionModel(args, vit_cfg, proj_cfg).to(DEV).bfloat16())   # Float16Module
+    model = gpt_cls(llm_cfg or proj_cfg, external_feature_model_provider=lambda cfg: dm.MegatronVisionModel(args, vit_cfg, proj_cfg).to(DEV).bfloat16(),
+                    **(gpt_kwargs or {}))                                            # Float16Module
     efm = model.external_feature_model
     sd = {"vit.conv1.weight": vp["conv_w"], "vit.conv1.bias": vp["conv_b"], "vit.class_token": vp["cls"],
           "vit.position_embeddings.weight": vp["pos"], "pre_proj_layernorm.weight": vp["proj_ln_w"],
@@ -502,6 +503,8 @@ def _vision_model(ovit, vcfg, vp, args_over=None, vit_grad=True):
         for k, q in efm.named_parameters():
             if k.startswith("vit."):
                 q.requires_grad = False                                               # GPTVLModel.vision_model_freeze (:186-195)
+    if gpt_kwargs:
+        return efm, sd, model
     return efm, sd
 
 
@@ -745,3 +748,105 @@ def test_one_node_per_fused_module_is_bit_identical_and_keeps_less(megatron, mon
     # the gated activation [S, ffn] (and, TE spec, the two normed copies [S, hidden]) are no longer kept
     saved = S * CFG["ffn"] * 2 + (2 * S * CFG["hidden"] * 2 if spec == "te" else 0)
     assert kept0 - kept1 >= 0.9 * saved, (kept0, kept1, saved)
+
+
+def test_whole_model_under_the_reference_forward_and_loss_func_trains_like_the_oracle(megatron):
+    """The composition `pretrain_long_vita.py` runs — forward_step (:841-869) -> GPTVLModel.forward with labels and a logit_mask
+    (gpt_vl_model.py:233-416: vision tower -> embedding + visual-token scatter -> RotaryEmbedding -> TransformerBlock -> `unused` ->
+    logits-masked output layer -> instruction shift -> vocab-parallel CE) -> loss_func (:778-839) -> autograd — restated in
+    tests/dummy_megatron.py with every class looked up under the name the reference imports it from, i.e. built from what the adaptor
+    registered: loss and EVERY gradient (embedding table, two full decoder layers, final norm, output layer, projector + its LayerNorm;
+    ViT frozen as in stage 3) against the CPU oracle's autograd on the same weights, and against training.TrainStep's explicit sweep."""
+    from oracle import train as otrain, vit as ovit
+    from long_vita_amd import gpt_vl_model as G, synthetic, training, vision as V
+    cfgd = dict(num_layers=2, hidden=1024, heads=8, kv_groups=2, head_dim=128, ffn=2816, vocab=1024)
+    ocfg = ollm.LLMConfig(**cfgd)
+    p = ollm.init_llm_params(ocfg, seed=8)
+    gen = torch.Generator().manual_seed(4)
+    p["final_ln"] = (1 + 0.1 * torch.randn(p["final_ln"].shape, generator=gen)).to(p["final_ln"].dtype)
+    vcfg = ovit.ViTConfig(num_layers=1, llm_hidden=cfgd["hidden"])
+    vp = _randomised_vit_params(ovit, vcfg, seed=9)
+    S, n_frames = 768, 2
+    tokens, ext = synthetic.make_request(S, n_frames, seed=3, device="cpu")
+    tokens = tokens % cfgd["vocab"]
+    labels = torch.randint(0, cfgd["vocab"], (1, S), generator=gen)
+    loss_mask = torch.zeros(1, S)
+    loss_mask[0, S - 100:] = 1
+    images = ext["images"]
+
+    # ---- oracle: ViT frozen, projector + decoder differentiable ---------------------------------------------------------------------
+    with torch.no_grad():
+        x = ovit.vit_embed(images, vp, vcfg)
+        for lp in vp["layers"]:
+            x = ovit.vit_layer(x, lp, vcfg)
+    proj_keys = ("proj_ln_w", "proj_ln_b", "proj_fc1", "proj_fc2")
+    pall = dict(p)
+    for k in proj_keys:
+        pall[k] = vp[k]
+
+    def feature_fn(pp):
+        q = dict(vp)
+        for k in proj_keys:
+            q[k] = pp[k]
+        return ovit.vit_project(x, q, vcfg)
+    loss_ref, g_ref = otrain.loss_and_grads(tokens, labels, loss_mask, pall, ocfg, feature_fn=feature_fn, indices=ext["indices"])
+
+    # ---- the reference's composition over the registered classes ----------------------------------------------------------------------
+    mcfg = dm.TransformerConfig(num_layers=cfgd["num_layers"], hidden_size=cfgd["hidden"], num_attention_heads=cfgd["heads"],
+                                num_query_groups=cfgd["kv_groups"], kv_channels=cfgd["head_dim"], ffn_hidden_size=cfgd["ffn"])
+    efm, _, model = _vision_model(ovit, vcfg, vp, vit_grad=False, llm_cfg=mcfg, gpt_kwargs=dict(
+        transformer_layer_spec=megatron.get_gpt_layer_with_transformer_engine_spec(), vocab_size=cfgd["vocab"], max_sequence_length=S,
+        position_embedding_type="rope", rotary_base=ocfg.rope_theta))
+    model.embedding.load_state_dict({"word_embeddings.weight": p["embed"].to(DEV)})
+    for i, lp in enumerate(p["layers"]):
+        _load(model.decoder.layers[i], lp, True)
+    model.decoder.final_layernorm.load_state_dict({"weight": p["final_ln"].to(DEV)})
+    model.output_layer.load_state_dict({"weight": p["lm_head"].to(DEV)})
+    model.unused.data = model.unused.data.to(DEV).bfloat16()
+    model.train()
+    from long_vita_amd import layers
+    assert isinstance(model.decoder.final_layernorm, layers.RMSNorm) and isinstance(model.output_layer, layers.ColumnParallelLinear)
+    position_ids = torch.arange(S, dtype=torch.long).unsqueeze(0).to(DEV)
+    batch = (tokens.to(DEV), labels.to(DEV), loss_mask.to(DEV), None, position_ids,
+             {"images": images.to(DEV).bfloat16(), "indices": ext["indices"].to(DEV)})
+    output_tensor, lf = dm.forward_step(batch, model)
+    assert output_tensor.dtype == torch.float32 and tuple(output_tensor.shape) == (1, 99)      # 100 answer tokens, shifted by one
+    loss_sum, n_tok = lf(output_tensor)
+    loss = loss_sum / n_tok                            # schedules.forward_step: output_tensor / num_tokens
+    loss.backward()
+    assert int(n_tok) == 99
+    tol("loss vs oracle", abs(float(loss) - float(loss_ref)) / abs(float(loss_ref)), 2e-2)
+    names = {"qkv_w": "self_attention.linear_qkv.weight", "qkv_b": "self_attention.linear_qkv.bias",
+             "o_w": "self_attention.linear_proj.weight", "fc1_w": "mlp.linear_fc1.weight", "fc2_w": "mlp.linear_fc2.weight",
+             "ln1": "self_attention.linear_qkv.layer_norm_weight", "ln2": "mlp.linear_fc1.layer_norm_weight"}
+    got = {"embed": model.embedding.word_embeddings.weight.grad, "final_ln": model.decoder.final_layernorm.weight.grad,
+           "lm_head": model.output_layer.weight.grad,
+           "proj_ln_w": efm.pre_proj_layernorm.weight.grad, "proj_ln_b": efm.pre_proj_layernorm.bias.grad,
+           "proj_fc1": efm.vision_projection.encoder.linear_fc1.weight.grad, "proj_fc2": efm.vision_projection.encoder.linear_fc2.weight.grad}
+    errs = {k: rel_l2(v, g_ref[k]) for k, v in got.items()}
+    for i, rl in enumerate(g_ref["layers"]):
+        params = dict(model.decoder.layers[i].named_parameters())
+        for k, n in names.items():
+            assert params[n].grad is not None, (i, n)
+            errs[f"layers.{i}.{k}"] = rel_l2(params[n].grad, rl[k])
+    assert model.unused.grad is not None and float(model.unused.grad.abs().max()) == 0.0     # `hidden_states += 0.0 * self.unused`
+    assert all(q.grad is None for n_, q in efm.named_parameters() if n_.startswith("vit."))  # frozen (stage 3)
+    _record("whole_model_vs_oracle", errs)
+    worst = max(errs, key=errs.get)
+    tol(f"worst gradient vs oracle ({worst})", errs[worst], 1.8e-2)
+
+    # ---- and against the explicit sweep on the same weights -----------------------------------------------------------------------------
+    vis = V.MegatronVisionModel.from_oracle_layout(V.VisionConfig(num_layers=1, llm_hidden=cfgd["hidden"]), vp, DEV)
+    alone = G.GPTVLModel.from_oracle_layout(G.GPTConfig(**cfgd), p, vis, DEV)
+    loss2, g2 = training.TrainStep(alone).forward_backward(tokens.to(DEV), labels.to(DEV), loss_mask.to(DEV),
+                                                            {"images": images.to(DEV), "indices": ext["indices"].to(DEV)})
+    tol("loss vs TrainStep", abs(float(loss) - float(loss2)) / abs(float(loss2)), 5e-3)
+    errs2 = {k: rel_l2(got[k], g2[k]) for k in ("embed", "final_ln", "lm_head")}
+    errs2.update({k: rel_l2(got[k], g2["projector"][k]) for k in proj_keys})
+    for i, gl in enumerate(g2["layers"]):
+        params = dict(model.decoder.layers[i].named_parameters())
+        for k, n in names.items():
+            errs2[f"layers.{i}.{k}"] = rel_l2(params[n].grad, gl[k])
+    _record("whole_model_vs_trainstep", errs2)
+    worst = max(errs2, key=errs2.get)
+    tol(f"worst gradient vs TrainStep ({worst})", errs2[worst], 1.5e-2)
