@@ -371,12 +371,19 @@ class RotaryEmbedding(torch.nn.Module):
         self.inv_freq = 1.0 / (rotary_base ** (torch.arange(0, dim, 2, dtype=torch.float32) / dim))
 
     def forward(self, max_seq_len, offset=0):
+        from long_vita_amd import parallel_state as own          # (megatron.core.parallel_state in the original)
         seq = torch.arange(max_seq_len, dtype=torch.float32) + offset
         freqs = torch.outer(seq, self.inv_freq)
-        return torch.cat((freqs, freqs), dim=-1)[:, None, None, :]
+        emb = torch.cat((freqs, freqs), dim=-1)[:, None, None, :]
+        cp_size = own.get_context_parallel_world_size()
+        if cp_size > 1:                                           # get_pos_emb_on_this_cp_rank: the rank's two zig-zag chunks
+            cp_idx = torch.tensor([own.get_context_parallel_rank(), 2 * cp_size - own.get_context_parallel_rank() - 1])
+            emb = emb.view(2 * cp_size, -1, *emb.shape[1:]).index_select(0, cp_idx).view(-1, *emb.shape[1:])
+        return emb
 
     def get_rotary_seq_len(self, inference_params, transformer, transformer_input, transformer_config):
-        return transformer_input.size(0) if transformer_input is not None else transformer.input_tensor.size(0)
+        n = transformer_input.size(0) if transformer_input is not None else transformer.input_tensor.size(0)
+        return n * transformer_config.context_parallel_size
 
 
 ARGS = types.SimpleNamespace(output_multiplier_scale=None, output_logit_softcapping=None, is_instruction_dataset=True,
@@ -481,6 +488,10 @@ def loss_func(loss_mask, output_tensor):
     loss_mask = loss_mask[..., 1:].reshape(-1).float() if args.is_instruction_dataset else loss_mask.reshape(-1).float()
     total_tokens = loss_mask.sum()
     loss = torch.cat([torch.sum(losses.view(-1) * loss_mask).view(1), total_tokens.view(1)])
+    if args.context_parallel_size > 1:                                                    # :801-803
+        from long_vita_amd import parallel_state as own
+        # c10d reduces in place and autograd never sees it: the graph of loss[0] stays this rank's own terms
+        torch.distributed.all_reduce(loss.detach(), group=own.get_context_parallel_group())
     return loss[0] * args.context_parallel_size, loss[1].clone().detach().to(torch.int)
 
 

@@ -850,3 +850,108 @@ def test_whole_model_under_the_reference_forward_and_loss_func_trains_like_the_o
     _record("whole_model_vs_trainstep", errs2)
     worst = max(errs2, key=errs2.get)
     tol(f"worst gradient vs TrainStep ({worst})", errs2[worst], 1.5e-2)
+
+
+@pytest.mark.parametrize("answers", ["on_both_ranks", "on_rank_0_only"])
+def test_whole_model_under_context_parallelism_through_the_reference_composition(megatron, monkeypatch, answers):
+    """The same composition on two simulated CP ranks (threads; the collectives of test_train_gpu._run_grid): the reference's get_batch
+    (get_batch_on_this_cp_rank + the `external_` prefix stripped, pretrain_long_vita.py:671-696) -> forward_step -> GPTVLModel.forward:
+    each rank encodes the frames its chunks hold, scatters its columns (src / tgt indices), rotates with its slice of the angle table,
+    runs the decoder with K / V all-gathered (FlashAttnCPFn) and selects ITS answer rows; loss_func all-reduces (sum, tokens) over the CP
+    group and scales by CP; the gradients of the two ranks are averaged as Megatron's DDP does.  == the unsharded oracle with the
+    reference's per-rank instruction shift.  "on_rank_0_only" = config 5's situation: the answer sits at the end of the row, rank 1's
+    logit mask selects nothing — its head, CE and loss_func run on empty tensors and its backward still takes part in every collective."""
+    from oracle import train as otrain, vit as ovit
+    from long_vita_amd import parallel_state as mpu, synthetic, training_utils
+    from test_train_gpu import _run_grid
+    cp = 2
+    cfgd = dict(num_layers=2, hidden=1024, heads=8, kv_groups=2, head_dim=128, ffn=2816, vocab=1024)
+    ocfg = ollm.LLMConfig(**cfgd)
+    p = ollm.init_llm_params(ocfg, seed=18)
+    vcfg = ovit.ViTConfig(num_layers=1, llm_hidden=cfgd["hidden"])
+    vp = _randomised_vit_params(ovit, vcfg, seed=19)
+    S, n_frames = 1024, 2
+    tokens, ext = synthetic.make_request(S, n_frames, seed=5, device="cpu")
+    tokens = tokens % cfgd["vocab"]
+    gen = torch.Generator().manual_seed(6)
+    labels = torch.randint(0, cfgd["vocab"], (1, S), generator=gen)
+    loss_mask = torch.zeros(1, S)
+    loss_mask[0, S - 100:] = 1                                    # chunk 3: CP rank 0
+    if answers == "on_both_ranks":
+        loss_mask[0, 600:640] = 1                                 # chunk 2: CP rank 1
+    images = ext["images"]
+    with torch.no_grad():
+        x = ovit.vit_embed(images, vp, vcfg)
+        for lp in vp["layers"]:
+            x = ovit.vit_layer(x, lp, vcfg)
+    proj_keys = ("proj_ln_w", "proj_ln_b", "proj_fc1", "proj_fc2")
+    pall = dict(p)
+    for k in proj_keys:
+        pall[k] = vp[k]
+
+    def feature_fn(pp):
+        q = dict(vp)
+        for k in proj_keys:
+            q[k] = pp[k]
+        return ovit.vit_project(x, q, vcfg)
+    loss_ref, g_ref = otrain.loss_and_grads(tokens, labels, loss_mask, pall, ocfg, cp_size=cp, feature_fn=feature_fn, indices=ext["indices"])
+
+    names = {"qkv_w": "self_attention.linear_qkv.weight", "qkv_b": "self_attention.linear_qkv.bias",
+             "o_w": "self_attention.linear_proj.weight", "fc1_w": "mlp.linear_fc1.weight", "fc2_w": "mlp.linear_fc2.weight",
+             "ln1": "self_attention.linear_qkv.layer_norm_weight", "ln2": "mlp.linear_fc1.layer_norm_weight"}
+    monkeypatch.setattr(dm.ARGS, "context_parallel_size", cp)
+
+    def rank_fn(ci, ti):
+        with torch.autograd.set_multithreading_enabled(False):
+            return rank_body(ci)
+
+    def rank_body(ci):
+        mcfg = dm.TransformerConfig(num_layers=cfgd["num_layers"], hidden_size=cfgd["hidden"], num_attention_heads=cfgd["heads"],
+                                    num_query_groups=cfgd["kv_groups"], kv_channels=cfgd["head_dim"], ffn_hidden_size=cfgd["ffn"],
+                                    context_parallel_size=cp)
+        efm, _, model = _vision_model(ovit, vcfg, vp, vit_grad=False, llm_cfg=mcfg, gpt_kwargs=dict(
+            transformer_layer_spec=megatron.get_gpt_layer_with_transformer_engine_spec(), vocab_size=cfgd["vocab"], max_sequence_length=S,
+            position_embedding_type="rope", rotary_base=ocfg.rope_theta))
+        model.embedding.load_state_dict({"word_embeddings.weight": p["embed"].to(DEV)})
+        for i, lp in enumerate(p["layers"]):
+            _load(model.decoder.layers[i], lp, True)
+        model.decoder.final_layernorm.load_state_dict({"weight": p["final_ln"].to(DEV)})
+        model.output_layer.load_state_dict({"weight": p["lm_head"].to(DEV)})
+        model.unused.data = model.unused.data.to(DEV).bfloat16()
+        model.train()
+        batch = {"tokens": tokens.to(DEV), "labels": labels.to(DEV), "loss_mask": loss_mask.to(DEV),
+                 "position_ids": torch.arange(S, dtype=torch.long, device=DEV).unsqueeze(0),
+                 "external_images": images.to(DEV).bfloat16(), "external_indices": ext["indices"].to(DEV)}
+        batch = training_utils.get_batch_on_this_cp_rank(batch, seq_length=S)                   # get_batch (:683-692)
+        external_inputs = {k[len("external_"):]: batch.pop(k) for k in list(batch) if "external_" in k}
+        assert set(external_inputs) == {"images", "src_indices", "tgt_indices"}
+        out, lf = dm.forward_step((batch["tokens"], batch["labels"], batch["loss_mask"], None, batch["position_ids"], external_inputs), model)
+        loss_x_cp, n_tok = lf(out)
+        (loss_x_cp / n_tok).backward()                                                           # schedules.forward_step: / num_tokens
+        got = {"embed": model.embedding.word_embeddings.weight.grad, "final_ln": model.decoder.final_layernorm.weight.grad,
+               "lm_head": model.output_layer.weight.grad,
+               "proj_ln_w": efm.pre_proj_layernorm.weight.grad, "proj_ln_b": efm.pre_proj_layernorm.bias.grad,
+               "proj_fc1": efm.vision_projection.encoder.linear_fc1.weight.grad, "proj_fc2": efm.vision_projection.encoder.linear_fc2.weight.grad}
+        for i in range(cfgd["num_layers"]):
+            params = dict(model.decoder.layers[i].named_parameters())
+            for k, n in names.items():
+                got[f"layers.{i}.{k}"] = params[n].grad
+        assert all(v is not None for v in got.values()), [k for k, v in got.items() if v is None]
+        return float(loss_x_cp) / cp / int(n_tok), int(n_tok), int(out.shape[1]), {k: v.detach().float().clone() for k, v in got.items()}
+
+    outs = _run_grid(1, cp, rank_fn, {"mpu": mpu}, monkeypatch)
+    n_sel = [int(loss_mask[0, training_utils.zigzag_slice(torch.arange(S), cp, ci, seq_dim=0)].sum()) for ci in range(cp)]
+    assert [outs[(ci, 0)][2] for ci in range(cp)] == [max(n - 1, 0) for n in n_sel], (n_sel, [outs[(ci, 0)][2] for ci in range(cp)])
+    if answers == "on_rank_0_only":
+        assert n_sel[1] == 0
+    assert outs[(0, 0)][1] == outs[(1, 0)][1] == sum(max(n - 1, 0) for n in n_sel)              # the all-reduced token count
+    tol("loss vs oracle (cp = 2)", abs(outs[(0, 0)][0] - float(loss_ref)) / abs(float(loss_ref)), 2e-2)
+    assert outs[(0, 0)][0] == outs[(1, 0)][0]
+    errs = {}
+    for k in outs[(0, 0)][3]:
+        g = sum(outs[(ci, 0)][3][k] for ci in range(cp)) / cp                                    # DDP: the average over the DP x CP group
+        ref = g_ref["layers"][int(k.split(".")[1])][k.split(".")[2]] if k.startswith("layers.") else g_ref[k]
+        errs[k] = rel_l2(g, ref)
+    _record("whole_model_cp2_" + answers, errs)
+    worst = max(errs, key=errs.get)
+    tol(f"worst gradient vs oracle ({worst})", errs[worst], 2.0e-2)
