@@ -968,3 +968,81 @@ def test_whole_model_under_context_parallelism_through_the_reference_composition
     _record("whole_model_cp2_" + answers, errs)
     worst = max(errs, key=errs.get)
     tol(f"worst gradient vs oracle ({worst})", errs[worst], 2.0e-2)
+
+
+def test_vit_layer_under_tensor_parallelism_matches_the_unsharded_oracle(megatron, monkeypatch):
+    """BASELINE config 5 trains with TP = 2, and the vision tower is built from the same (tensor-parallel) Megatron modules as the decoder
+    (the vision args keep `tensor_model_parallel_size`, switch `sequence_parallel` off: M/pretrain_long_vita.py:67): the InternViT layer
+    from `get_vit_layer_local_spec_for_intern()` on two simulated TP ranks — qkv / fc1 column-parallel (8 of 16 heads, 2048 of 4096 FFN
+    rows per rank, input-gradient all-reduce), proj / fc2 row-parallel (output all-reduce, the bias added once after it) — output and input
+    gradient on every rank, sharded gradients reassembled, replicated ones (norms, LayerScale, row-parallel biases) equal on both ranks,
+    vs torch autograd over the unsharded oracle layer."""
+    from oracle import vit as ovit
+    from long_vita_amd import parallel_state as mpu
+    from test_train_gpu import _run_grid
+    tp = 2
+    vls = sys.modules["long_vita_megatron.core.models.vision.vit_layer_specs"]
+    vcfg = ovit.ViTConfig(num_layers=1, unfused_bias=True)
+    vp = ovit.init_vit_params(vcfg, seed=71)
+    gen = torch.Generator().manual_seed(72)
+    lp = {k: v.clone() for k, v in vp["layers"][0].items()}
+    for k in ("ln1_w", "ln2_w"):
+        lp[k] = (1 + 0.1 * torch.randn(lp[k].shape, generator=gen)).bfloat16()
+    for k in ("ln1_b", "ln2_b", "proj_b", "fc2_b"):
+        lp[k] = (0.1 * torch.randn(lp[k].shape, generator=gen)).bfloat16()
+    lp["ls1"] = (0.1 + 0.02 * torch.randn(lp["ls1"].shape, generator=gen)).bfloat16()
+    lp["ls2"] = (0.1 + 0.02 * torch.randn(lp["ls2"].shape, generator=gen)).bfloat16()
+    n, S, H = 2, vcfg.seq, vcfg.hidden
+    x = (torch.randn(n, S, H, generator=gen) * 0.5).bfloat16()
+    go = torch.randn(n, S, H, generator=gen).bfloat16()
+    xo = x.clone().requires_grad_(True)
+    lpo = {k: v.clone().requires_grad_(True) for k, v in lp.items()}
+    ref = ovit.vit_layer(xo, lpo, vcfg)
+    ref.backward(go)
+    names = {"ln1_w": "input_layernorm.weight", "ln1_b": "input_layernorm.bias", "qkv_w": "self_attention.linear_qkv.weight",
+             "qkv_b": "self_attention.linear_qkv.bias", "proj_w": "self_attention.linear_proj.weight",
+             "proj_b": "self_attention.linear_proj.bias", "ls1": "ls1", "ln2_w": "pre_mlp_layernorm.weight",
+             "ln2_b": "pre_mlp_layernorm.bias", "fc1_w": "mlp.linear_fc1.weight", "fc1_b": "mlp.linear_fc1.bias",
+             "fc2_w": "mlp.linear_fc2.weight", "fc2_b": "mlp.linear_fc2.bias", "ls2": "ls2"}
+    rows = ("qkv_w", "qkv_b", "fc1_w", "fc1_b")          # column-parallel: output features (rows of the weight) split; heads are contiguous
+    cols = ("proj_w", "fc2_w")                           # row-parallel: input features split
+
+    def shard(k, t, ti):
+        if k in rows:
+            return t.chunk(tp, 0)[ti]
+        if k in cols:
+            return t.chunk(tp, 1)[ti]
+        return t
+
+    def rank_fn(ci, ti):
+        with torch.autograd.set_multithreading_enabled(False):
+            mcfg = dm.TransformerConfig(hidden_size=H, num_attention_heads=vcfg.heads, num_query_groups=vcfg.heads, kv_channels=vcfg.head_dim,
+                                        ffn_hidden_size=vcfg.ffn, normalization="LayerNorm", layernorm_epsilon=vcfg.ln_eps,
+                                        add_bias_linear=True, add_qkv_bias=True, gated_linear_unit=False,
+                                        activation_func=torch.nn.functional.gelu, tensor_model_parallel_size=tp, sequence_parallel=False)
+            layer = dm.build_module(vls.get_vit_layer_local_spec_for_intern(), config=mcfg, layer_number=1)
+            assert tuple(layer.self_attention.linear_qkv.weight.shape) == (3 * H // tp, H)
+            assert tuple(layer.mlp.linear_fc2.weight.shape) == (H, vcfg.ffn // tp)
+            layer.load_state_dict({v: shard(k, lp[k], ti).contiguous().to(DEV) for k, v in names.items()})
+            xh = x.transpose(0, 1).contiguous().to(DEV).requires_grad_(True)
+            out, _ = layer(xh, attention_mask=None)
+            out.backward(go.transpose(0, 1).contiguous().to(DEV))
+            params = dict(layer.named_parameters())
+            return out.detach(), xh.grad.detach(), {k: params[v].grad.detach().clone() for k, v in names.items()}
+
+    outs = _run_grid(tp, 1, rank_fn, {"mpu": mpu}, monkeypatch)
+    (o0, dx0, g0), (o1, dx1, g1) = outs[(0, 0)], outs[(0, 1)]
+    assert torch.equal(o0, o1) and torch.equal(dx0, dx1)                             # all-reduced: the same on both ranks
+    errs = {"out": rel_l2(o0.transpose(0, 1), ref), "dx": rel_l2(dx0.transpose(0, 1), xo.grad)}
+    for k in names:
+        if k in rows:
+            g = torch.cat([g0[k], g1[k]], 0)
+        elif k in cols:
+            g = torch.cat([g0[k], g1[k]], 1)
+        else:
+            tol(f"replicated gradient {k}: rank 0 vs rank 1", rel_l2(g0[k], g1[k]), 1e-2)     # fp32 atomic sums: not bit-equal
+            g = g0[k]
+        errs[k] = rel_l2(g, lpo[k].grad)
+    _record("vit_layer_tp2", errs)
+    tol("forward", errs["out"], 2.0e-3)
+    tol("worst gradient", max(errs.values()), 9e-3)
