@@ -1105,3 +1105,24 @@ def test_tn_split_choice_never_leaves_an_empty_range_and_keeps_big_gradients_uns
     assert ops.tn_splits(13824, 5120, 16384) == 1
     assert ops.tn_splits(1024, 1024, 253 * 1025 // 64 * 64) > 1          # a ViT projection over 253 frames: 16 tiles
     assert ops.tn_splits(3584, 5120, 32768) > 1                # config 5: qkv at TP = 2
+
+
+def test_committed_pmc_json_follows_from_the_committed_raw_counter_passes(tmp_path):
+    """profiles/r04_attn128k_pmc.json (what bench.py's `roofline.traffic` reads) is tools/pmc_to_json.py applied to the committed raw
+    rocprofv3 --pmc summaries and the committed kernel-trace statistics: re-deriving it here gives the same bytes per launch, and the
+    corrected fetch figure is 2 x FETCH_SIZE KB (MI355X_MICROARCH.md's gfx950 correction) + WRITE_SIZE KB."""
+    import json
+    prof = os.path.join(ROOT, "profiles")
+    raw, stats, committed = (os.path.join(prof, f) for f in ("r04_attn128k_pmc_raw.txt", "r04_bench128k_kernel_stats.txt", "r04_attn128k_pmc.json"))
+    out = tmp_path / "pmc.json"
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "tools", "pmc_to_json.py"), raw, stats, str(out)], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-1000:]
+    a, b = json.load(open(out)), json.load(open(committed))
+    assert a["hbm_bytes_per_launch"] == b["hbm_bytes_per_launch"]
+    assert a["hbm_bytes_per_launch"] == a["FETCH_SIZE_KB"] * 1024 * 2 + a["WRITE_SIZE_KB"] * 1024
+    assert a["algorithmic_bytes_per_launch"] == (2 * 131072 * 40 * 128 + 2 * 131072 * 8 * 128) * 2       # Q, O; K, V: bf16
+    assert abs(a["sq_counters_S131072"]["ms_per_launch_rocprofv3_kernel_trace"] - 144.45) < 0.5
+    # the bench line of the round quotes the same launch shape within a few percent of the kernel-trace average
+    line = json.loads(open(os.path.join(prof, "r04_bench128k_n1.json")).read().strip().splitlines()[-1])
+    assert abs(line["roofline"]["ms_per_launch"] / a["sq_counters_S131072"]["ms_per_launch_rocprofv3_kernel_trace"] - 1) < 0.03
+    assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-9
