@@ -183,6 +183,13 @@ int vita_gemm_bf16_tn(const void* At, int64_t lda, const void* Wt, int64_t ldw, 
 /* Skinny-M GEMM for the logits-masked LM head (n_sel rows, M <= 16):
  *   logits[M, N] fp32-accumulated, stored bf16 (out_f32 == 0) or fp32 (out_f32 != 0).
  * Replaces torch.matmul on the masked rows, M/core/tensor_parallel/layers.py:402-409. */
+/* ABI 16: C[M, N] = A W with A [M, K] row-major and W [K, N] contraction-major — the input-gradient GEMM
+ * `grad_input = grad_output.matmul(weight)` (M/core/tensor_parallel/layers.py:444,453) with the weight [out, in] exactly as the forward holds
+ * it: no transposed copy.  M, N multiples of 256, K a multiple of 64, rows 16-byte aligned; other shapes: VITA_ERR_UNSUPPORTED (the caller
+ * transposes and uses vita_gemm_bf16). */
+int vita_gemm_bf16_nn(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N, int64_t K,
+                      void* stream);
+
 /* ABI 15: vita_gemm_bf16_tn with the contraction cut into `splits` ranges — for weight gradients whose output is only a few 256 x 256
  * tiles over a long token contraction (the ViT's linears; the decoder's narrow qkv / proj gradients).  Every (split, tile) workgroup
  * writes an fp32 partial to `workspace` ([splits][M][N] floats, vita_gemm_tn_splitk_workspace_bytes), a second kernel sums the splits and

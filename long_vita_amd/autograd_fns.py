@@ -33,7 +33,10 @@ def pad_rows(x: torch.Tensor, mult: int = 64) -> torch.Tensor:
 
 
 def dgrad(dy: torch.Tensor, w: torch.Tensor, out=None, epilogue=ops.EPI_NONE, residual=None) -> torch.Tensor:
-    """grad_input = grad_output.matmul(weight)  (layers.py:444):  dy [M, N], w [N, K] -> [M, K]."""
+    """grad_input = grad_output.matmul(weight)  (layers.py:444):  dy [M, N], w [N, K] -> [M, K].  Whole-tile shapes (every decoder
+    linear at its real sizes) take vita_gemm_bf16_nn: the weight is read contraction-major as it lies; others transpose it first."""
+    if epilogue == ops.EPI_NONE and residual is None and ops.gemm_nn_ok(dy, w) and (out is None or out.stride(1) == 1):
+        return ops.gemm_nn(dy, w, out=out)
     return ops.gemm(dy, transpose(w), epilogue, residual=residual, out=out)
 
 

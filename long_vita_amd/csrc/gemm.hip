@@ -570,10 +570,15 @@ constexpr int LINE = 1040, HALF = 16 * LINE, OPB = 2 * HALF, STAGE = 2 * OPB, LD
 // .. + 4..7; the hardware transposes 4 x 16 blocks inside 16-lane groups), and the eight rows a 32-lane half reads (r and r + 8,
 // r = 0..3) are spread over the 64 banks by XOR-ing the 32-byte chunk index with key(row) = (row & 3) | ((row >> 3) & 1) << 2 — on
 // the DMA's SOURCE address and on the read address.
-template <int EPI, bool INTERIOR, bool TN = false>
+//
+// OPM = 2 (r04, vita_gemm_bf16_nn): A as in the NT kernel ([M][K], row-major), W contraction-major ([K][N]) as in the TN kernel —
+// C = A W, which is what an input gradient is (dX [tokens, K_in] = dY [tokens, N] W [N, K_in] with the weight as the forward holds it),
+// so dgrad needs no vita_transpose_bf16 pass over the weight either.  A's half of a stage is the NT image, W's half the TN image.
+template <int EPI, bool INTERIOR, int OPM = 0>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   using namespace w4;
-  constexpr int STG = TN ? 65536 : STAGE, OPBS = TN ? 32768 : OPB;
+  constexpr bool TN = OPM == 1, TA = OPM == 1, TW = OPM != 0;          // TN: both operands contraction-major; TA / TW: per operand
+  constexpr int STG = TN ? 65536 : STAGE, OPBS = TA ? 32768 : OPB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -606,23 +611,29 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   // ---- DMA geometry: wave w fills lines (h = w >> 1, r16 = (w & 1) * 8 + i), i = 0..7, of both operands; per-lane byte offsets of
   // the eight pieces relative to the tile's first row (clamped rows for ragged edges; SwiGLU: 16-row blocks alternate gate / up) ------
   const int h = wave >> 1, r0 = (wave & 1) * 8;
-  const unsigned d_line0 = TN ? (unsigned)(wave * 8 * 1024) : (unsigned)(h * HALF + r0 * LINE);
-  constexpr int PIECE = TN ? 1024 : LINE;
+  const unsigned d_line0_a = TA ? (unsigned)(wave * 8 * 1024) : (unsigned)(h * HALF + r0 * LINE);
+  const unsigned d_line0_w = TW ? (unsigned)(wave * 8 * 1024) : (unsigned)(h * HALF + r0 * LINE);
+  constexpr int PIECE_A = TA ? 1024 : LINE, PIECE_W = TW ? 1024 : LINE;
   unsigned voff_a[8], voff_w[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
-    if (TN) {       // piece 8 wave + i = contraction rows 16 wave + 2 i + {0, 1}; lane -> (row lane / 32, 16-byte chunk lane % 32)
-      const int krow = 16 * wave + 2 * i + (lane >> 5), c16 = lane & 31;
-      const int key = (krow & 3) | (((krow >> 3) & 1) << 2);       // the 8 rows one 32-lane half reads (r, r + 8; r = 0..3 [+ 4]) get 8 keys
-      const int col = ((((c16 >> 1) ^ key) << 1) | (c16 & 1)) * 8;                          // source-side swizzle (32-byte chunks)
+    // contraction-major operand: piece 8 wave + i = contraction rows 16 wave + 2 i + {0, 1}; lane -> (row lane / 32, 16-byte chunk lane % 32)
+    const int krow = 16 * wave + 2 * i + (lane >> 5), c16 = lane & 31;
+    const int key = (krow & 3) | (((krow >> 3) & 1) << 2);         // the 8 rows one 32-lane half reads (r, r + 8; r = 0..3 [+ 4]) get 8 keys
+    const int col = ((((c16 >> 1) ^ key) << 1) | (c16 & 1)) * 8;                            // source-side swizzle (32-byte chunks)
+    const int lr = 128 * h + 16 * (lane >> 3) + r0 + i;
+    if (TA) {
       voff_a[i] = (unsigned)((krow * p.lda + col) * 2);
+    } else {
+      int64_t g = m0 + lr;
+      g = g < p.M ? g : p.M - 1;
+      voff_a[i] = (unsigned)((g - m0) * p.lda * 2 + (lane & 7) * 16);
+    }
+    if (TW) {
       voff_w[i] = (unsigned)((krow * p.ldw + col) * 2);
       continue;
     }
-    const int lr = 128 * h + 16 * (lane >> 3) + r0 + i;
-    int64_t g = m0 + lr;
-    g = g < p.M ? g : p.M - 1;
-    voff_a[i] = (unsigned)((g - m0) * p.lda * 2 + (lane & 7) * 16);
+    int64_t g;
     if (EPI == VITA_EPI_SWIGLU) {
       const int blk = lr >> 4;
       int64_t oc = n0 + (blk >> 1) * 16 + (lr & 15);
@@ -640,23 +651,23 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
     const unsigned lo = __builtin_amdgcn_readfirstlane((unsigned)v), hi = __builtin_amdgcn_readfirstlane((unsigned)(v >> 32));
     return (const char*)(uintptr_t)(((uint64_t)hi << 32) | lo);
   };
-  const char* const ap = uniform_ptr(TN ? p.A + m0 : p.A + m0 * p.lda);
-  const char* const wp = uniform_ptr(TN ? p.W + n0 : p.W + n0 * p.ldw);
-  const int64_t kstep_a = TN ? (int64_t)BK * p.lda * 2 : BK * 2, kstep_w = TN ? (int64_t)BK * p.ldw * 2 : BK * 2;
+  const char* const ap = uniform_ptr(TA ? p.A + m0 : p.A + m0 * p.lda);
+  const char* const wp = uniform_ptr(TW ? p.W + n0 : p.W + n0 * p.ldw);
+  const int64_t kstep_a = TA ? (int64_t)BK * p.lda * 2 : BK * 2, kstep_w = TW ? (int64_t)BK * p.ldw * 2 : BK * 2;
   // developer aid VITA_GEMM_STAGGER=1 (NT, no split): XCD x starts its K loop at tile x nk / 8 and wraps, so that the eight XCDs do not
   // pull the same K range of their panels through the fabric at the same time (the accumulation order of a tile then depends on its XCD)
-  int kt_fetch = (!TN && !SPLITK && p.stagger == 1) ? (int)(((int64_t)(blockIdx.x & 7) * nk) >> 3) : 0;
+  int kt_fetch = (OPM == 0 && !SPLITK && p.stagger == 1) ? (int)(((int64_t)(blockIdx.x & 7) * nk) >> 3) : 0;
   int64_t koff_a = SPLITK ? (int64_t)split * p.k_tiles_per_split * kstep_a : kt_fetch * kstep_a;     // byte offsets of the K tile fetched next
   int64_t koff_w = SPLITK ? (int64_t)split * p.k_tiles_per_split * kstep_w : kt_fetch * kstep_w;
   auto dma_piece = [&](unsigned stage, int j) __attribute__((always_inline)) {              // j = 0..7: A lines, 8..15: W lines
     const __amdgpu_buffer_rsrc_t r = __builtin_amdgcn_make_buffer_rsrc((void*)(j < 8 ? ap + koff_a : wp + koff_w), 0, 0x7fffffff, 0x00020000);
     const int i = j & 7;
-    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(uintptr_t)(stage + (j < 8 ? 0 : OPBS) + d_line0 + i * PIECE), 16,
+    __builtin_amdgcn_raw_ptr_buffer_load_lds(r, (lds_void*)(uintptr_t)(stage + (j < 8 ? d_line0_a + i * PIECE_A : OPBS + d_line0_w + i * PIECE_W)), 16,
                                              j < 8 ? voff_a[i] : voff_w[i], 0, 0, 0);
   };
   auto next_tile = [&]() __attribute__((always_inline)) {
     koff_a += kstep_a; koff_w += kstep_w;
-    if (!TN && !SPLITK && ++kt_fetch == nk) { kt_fetch = 0; koff_a = 0; koff_w = 0; }
+    if (OPM == 0 && !SPLITK && ++kt_fetch == nk) { kt_fetch = 0; koff_a = 0; koff_w = 0; }
   };
 
   // ---- fragment reads: lane -> (row lane % 16) * LINE + (k chunk lane / 16) * 16, + row block * 128 + k half * 64 ------------------
@@ -667,7 +678,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   // block x of an operand sits in 32-byte chunk (8 wm + x) ^ (row & 7) of each 512-byte row
   u32x2 tlo[16], thi[16];                                                  // the two halves of a fragment until its wait has passed
   unsigned toff_a[8], toff_w[8];
-  if (TN) {
+  if (TW) {
     const int i16 = lane & 15, sw = (i16 >> 2) | (((lane >> 4) & 1) << 2);          // = key(row) of both reads of this lane
     const unsigned lane_base = (unsigned)((lane >> 4) * 8 * 512 + (i16 >> 2) * 512 + (i16 & 3) * 8);
 #pragma unroll
@@ -678,8 +689,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   }
   // read q (0..15) of k half ks: W block 0 first, then the eight A blocks, then W blocks 1..7 (the order the MFMAs need them)
   auto frag_read = [&](unsigned stage, int ks, int q) __attribute__((always_inline)) {
-    if (TN) {
-      const bool is_w = q == 0 || q > 8;
+    const bool is_w = q == 0 || q > 8;
+    if (is_w ? TW : TA) {                                                  // this operand is contraction-major: transposed reads
       const int x = is_w ? (q == 0 ? 0 : q - 8) : q - 1;
       const unsigned a1 = stage + (is_w ? toff_w[x] : toff_a[x]);
       if (ks == 0) {                                                       // rows 32 ks + 8 g + {0..3}, then + {4..7} (same key)
@@ -704,9 +715,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   // TN: after the s_waitcnt that covers them, the 16 fragments of k half ks are assembled from their halves (the empty asm makes the
   // halves opaque HERE, so no compiler-placed copy of them can sit above the wait)
   auto frag_commit = [&](int ks) __attribute__((always_inline)) {
-    if (!TN) return;
+    if (!TW) return;
 #pragma unroll
     for (int q = 0; q < 16; ++q) {
+      if (!((q == 0 || q > 8) ? TW : TA)) continue;                        // (OPM = 2: only the W fragments come in halves)
       asm volatile("" : "+v"(tlo[q]), "+v"(thi[q]));
       const u32x4 f = {tlo[q][0], tlo[q][1], thi[q][0], thi[q][1]};
       if (q == 0 || q > 8) wf[ks][q == 0 ? 0 : q - 8] = __builtin_bit_cast(bf16x8, f);
@@ -1090,10 +1102,33 @@ extern "C" int vita_gemm_bf16_tn(const void* At, int64_t lda, const void* Wt, in
   a.tiles_m = (int)tm; a.tiles_n = (int)tn;
   static std::atomic<unsigned long long> attr_set{0};
   vita_device_once(attr_set, [&] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<VITA_EPI_NONE, true, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<VITA_EPI_NONE, true, 1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, w4::LDS_BYTES);
   });
-  hipLaunchKernelGGL((gemm_w4_kernel<VITA_EPI_NONE, true, true>), dim3((unsigned)(tm * tn)), dim3(256), w4::LDS_BYTES, (hipStream_t)stream, a);
+  hipLaunchKernelGGL((gemm_w4_kernel<VITA_EPI_NONE, true, 1>), dim3((unsigned)(tm * tn)), dim3(256), w4::LDS_BYTES, (hipStream_t)stream, a);
+  return vita_check_launch();
+}
+
+// C[M, N] = A W with A [M, K] row-major and W [K, N] contraction-major: the input-gradient GEMM (dX = dY W, the weight as the forward
+// holds it) without a transposed copy of the weight.  Whole tiles only; anything else returns VITA_ERR_UNSUPPORTED (callers transpose).
+extern "C" int vita_gemm_bf16_nn(const void* A, int64_t lda, const void* W, int64_t ldw, void* C, int64_t ldc, int64_t M, int64_t N,
+                                 int64_t K, void* stream) {
+  if (!A || !W || !C || M <= 0 || N <= 0 || K <= 0) return VITA_ERR_INVALID_ARG;
+  if ((M % 256) || (N % 256) || (K % BK) || (lda & 7) || (ldw & 7) || (ldc & 3)) return VITA_ERR_UNSUPPORTED;
+  if (BK * ldw * 2 + 512 >= 0x7fff0000LL || 256 * lda * 2 + 512 >= 0x7fff0000LL) return VITA_ERR_UNSUPPORTED;
+  GemmArgs a;
+  a.A = (const bf16_t*)A; a.lda = lda; a.W = (const bf16_t*)W; a.ldw = ldw;
+  a.C = (bf16_t*)C; a.ldc = ldc; a.M = M; a.N = N; a.K = K;
+  a.bias = nullptr; a.scale = nullptr; a.R = nullptr; a.ldr = 0; a.stagger = 0;
+  const int64_t tm = M / 256, tn = N / 256;
+  if (tm * tn > 0x7fffffff) return VITA_ERR_UNSUPPORTED;
+  a.tiles_m = (int)tm; a.tiles_n = (int)tn;
+  static std::atomic<unsigned long long> attr_set{0};
+  vita_device_once(attr_set, [&] {
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<VITA_EPI_NONE, true, 2>),
+                              hipFuncAttributeMaxDynamicSharedMemorySize, w4::LDS_BYTES);
+  });
+  hipLaunchKernelGGL((gemm_w4_kernel<VITA_EPI_NONE, true, 2>), dim3((unsigned)(tm * tn)), dim3(256), w4::LDS_BYTES, (hipStream_t)stream, a);
   return vita_check_launch();
 }
 
@@ -1155,11 +1190,11 @@ extern "C" int vita_gemm_bf16_tn_splitk(const void* At, int64_t lda, const void*
   a.tiles_m = (int)tm; a.tiles_n = (int)tn;
   static std::atomic<unsigned long long> attr_set{0};
   vita_device_once(attr_set, [&] {
-    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<VITA_EPI_F32_PARTIAL, true, true>),
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<VITA_EPI_F32_PARTIAL, true, 1>),
                               hipFuncAttributeMaxDynamicSharedMemorySize, w4::LDS_BYTES);
   });
   hipStream_t st = (hipStream_t)stream;
-  hipLaunchKernelGGL((gemm_w4_kernel<VITA_EPI_F32_PARTIAL, true, true>), dim3((unsigned)(tm * tn * splits)), dim3(256), w4::LDS_BYTES, st, a);
+  hipLaunchKernelGGL((gemm_w4_kernel<VITA_EPI_F32_PARTIAL, true, 1>), dim3((unsigned)(tm * tn * splits)), dim3(256), w4::LDS_BYTES, st, a);
   const int64_t quads = M * (N / 4);
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3((unsigned)((quads + 255) / 256 < 8192 ? (quads + 255) / 256 : 8192)), dim3(256), 0, st,
                      (const float*)workspace, (bf16_t*)C, ldc, M, N, splits);

@@ -23,7 +23,7 @@ if os.environ.get("VITA_HIP_LIB"):                    # developer A / B switch: 
     LIB_PATH = os.path.abspath(os.environ["VITA_HIP_LIB"])
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "vita_hip.h")
 
-ABI_VERSION = 15
+ABI_VERSION = 16
 VITA_OK = 0
 VITA_ERR_INVALID_ARG = -1
 VITA_ERR_UNSUPPORTED = -2
@@ -146,6 +146,7 @@ PROTOTYPES = {
     "vita_cp_src_tgt": (_i, [_p, _l, _i, _p, _p, _p, _p, _p, _p, _p, _p]),
     "vita_gemm_bf16": (_i, [_p, _l, _p, _l, _p, _l, _l, _l, _l, _i, _p, _p, _p, _l, _p]),
     "vita_gemm_bf16_tn": (_i, [_p, _l, _p, _l, _p, _l, _l, _l, _l, _p]),
+    "vita_gemm_bf16_nn": (_i, [_p, _l, _p, _l, _p, _l, _l, _l, _l, _p]),
     "vita_gemm_tn_splitk_workspace_bytes": (C.c_size_t, [_l, _l, _i]),
     "vita_gemm_bf16_tn_splitk": (_i, [_p, _l, _p, _l, _p, _l, _l, _l, _l, _i, _p, _p]),
     "vita_colsum_bf16": (_i, [_p, _l, _p, _l, _i, _p]),

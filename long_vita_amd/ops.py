@@ -325,6 +325,24 @@ def gemm_tn_ok(a_t: torch.Tensor, w_t: torch.Tensor) -> bool:
             and w_t.stride(0) % 8 == 0 and a_t.shape[0] > 0)
 
 
+def gemm_nn_ok(a: torch.Tensor, w: torch.Tensor) -> bool:
+    """Shapes vita_gemm_bf16_nn takes (a [M, K] row-major, w [K, N] contraction-major): whole 256 x 256 output tiles, K a multiple of 64."""
+    return (a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[0] and a.stride(1) == 1 and w.stride(1) == 1
+            and a.shape[0] % 256 == 0 and w.shape[1] % 256 == 0 and a.shape[1] % 64 == 0 and a.stride(0) % 8 == 0
+            and w.stride(0) % 8 == 0 and a.shape[0] > 0 and a.dtype == BF16 and w.dtype == BF16)
+
+
+def gemm_nn(a: torch.Tensor, w: torch.Tensor, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """out[M, N] = a[M, K] @ w[K, N] — the dgrad GEMM `grad_output.matmul(weight)` (M/core/tensor_parallel/layers.py:444,453) with the
+    weight [out_features, in_features] as the forward holds it: no vita_transpose_bf16 pass (r04)."""
+    M, K = a.shape
+    N = w.shape[1]
+    y = torch.empty((M, N), dtype=BF16, device=a.device) if out is None else out
+    _L.check(_L.load().vita_gemm_bf16_nn(_dev(a, "a", BF16), a.stride(0), _dev(w, "w", BF16), w.stride(0), _dev(y, "out", BF16), y.stride(0),
+                                         M, N, K, _stream()), "vita_gemm_bf16_nn")
+    return y
+
+
 def tn_splits(M: int, N: int, K: int) -> int:
     """How many ranges to cut the contraction of a TN (weight-gradient) GEMM into.  The kernel gives one 256 x 256 output tile to one
     workgroup; a gradient whose output is a few tiles (ViT linears: 16 - 64 tiles, the decoder's qkv / proj at config 5's TP-halved widths:

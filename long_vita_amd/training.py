@@ -39,7 +39,10 @@ def _t(x: torch.Tensor) -> torch.Tensor:
 
 
 def _dgrad(dy: torch.Tensor, w: torch.Tensor, out=None, epilogue=ops.EPI_NONE, residual=None) -> torch.Tensor:
-    """grad_input = grad_output.matmul(weight)  (layers.py:444):  dy [M, N], w [N, K] -> [M, K]."""
+    """grad_input = grad_output.matmul(weight)  (layers.py:444):  dy [M, N], w [N, K] -> [M, K]; whole-tile shapes read the weight
+    contraction-major as it lies (vita_gemm_bf16_nn, r04), others transpose it first."""
+    if epilogue == ops.EPI_NONE and residual is None and ops.gemm_nn_ok(dy, w) and (out is None or out.stride(1) == 1):
+        return ops.gemm_nn(dy, w, out=out)
     return ops.gemm(dy, _t(w), epilogue, residual=residual, out=out)
 
 

@@ -628,6 +628,38 @@ def test_gemm_tn_both_operands_contraction_major(ops, M, N, K):
     assert not ops.gemm_tn_ok(ad[:, :M - 8], wd) and not ops.gemm_tn_ok(ad[:K - 8], wd[:K - 8])
 
 
+@pytest.mark.parametrize("M,N,K", [(256, 256, 64), (256, 512, 128), (768, 256, 1024), (1024, 1536, 2112), (4096, 5120, 7168)])
+def test_gemm_nn_weight_read_contraction_major(ops, M, N, K):
+    """r04: vita_gemm_bf16_nn: C[M, N] = A[M, K] W[K, N] (the dgrad GEMM, grad_output.matmul(weight), M/core/tensor_parallel/layers.py:444,453,
+    with the weight [out, in] as the forward holds it) vs fp32 math, vs the NT kernel fed with a vita_transpose_bf16 copy of W (same MFMA
+    order along the contraction: bit-identical), strided operands, an identity case that catches swapped roles, and the dgrad helpers."""
+    from long_vita_amd import autograd_fns, training
+    a = (torch.randn(M, K, generator=g(400)) * 0.5).bfloat16()
+    w = (torch.randn(K, N, generator=g(401)) * (1.0 / math.sqrt(K))).bfloat16()
+    ref = (a.float() @ w.float()).bfloat16()
+    ad, wd = a.to(DEV), w.to(DEV)
+    assert ops.gemm_nn_ok(ad, wd)
+    out = ops.gemm_nn(ad, wd)
+    tol("vs fp32 math", rel_l2(out, ref), 2e-3)
+    nt = ops.gemm(ad, ops.transpose(wd))
+    assert torch.equal(out, nt)
+    big_a = torch.zeros(M, K + 64, dtype=torch.bfloat16, device=DEV)
+    big_a[:, 32:32 + K] = ad
+    big_w = torch.zeros(K, N + 512, dtype=torch.bfloat16, device=DEV)
+    big_w[:, 256:256 + N] = wd
+    assert torch.equal(ops.gemm_nn(big_a[:, 32:32 + K], big_w[:, 256:256 + N]), out)
+    if K >= M:
+        eye = torch.zeros(M, K, dtype=torch.bfloat16)
+        eye[:, :M] = torch.eye(M)                                      # A = [I | 0]: C = the first M rows of W
+        wa = (torch.arange(K * N).reshape(K, N) % 251 - 125).float().bfloat16()
+        assert torch.equal(ops.gemm_nn(eye.to(DEV), wa.to(DEV)).cpu(), wa[:M])
+    # the two dgrad helpers take this path for whole tiles and give what the transposing path gives
+    assert torch.equal(autograd_fns.dgrad(ad, wd), nt) and torch.equal(training._dgrad(ad, wd), nt)
+    assert not ops.gemm_nn_ok(ad[:M - 8], wd) and not ops.gemm_nn_ok(ad, wd[:, :N - 8])
+    ragged = autograd_fns.dgrad(ad[:M - 8].contiguous(), wd)           # rows not a multiple of 256: the transposing fallback
+    tol("ragged fallback", rel_l2(ragged, nt[:M - 8]), 2e-3)
+
+
 @pytest.mark.parametrize("M,N,K,S", [(256, 256, 4096, 4), (512, 256, 8320, 13), (1024, 1024, 66 * 64, 3), (256, 512, 130 * 64, 8)])
 def test_gemm_tn_split_k(ops, M, N, K, S):
     """r04: vita_gemm_bf16_tn_splitk — the contraction cut into S ranges (uneven when K / 64 is not a multiple of S), fp32 partials,
