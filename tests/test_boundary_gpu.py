@@ -729,11 +729,15 @@ def test_one_node_per_fused_module_is_bit_identical_and_keeps_less(megatron, mon
         layer = dm.build_module(builder(), config=mcfg, layer_number=1)
         _load(layer, lp, spec == "te")
         xh = x.clone().requires_grad_(True)
-        torch.cuda.synchronize()
-        base = torch.cuda.memory_allocated()
-        out, _ = layer(xh, attention_mask=None, rotary_pos_emb=freqs)
-        torch.cuda.synchronize()
-        kept = torch.cuda.memory_allocated() - base
+        held = {}                                  # storage -> bytes of everything autograd saves for the backward (views keep their storage)
+
+        def pack(t):
+            st = t.untyped_storage()
+            held[st.data_ptr()] = st.nbytes()
+            return t
+        with torch.autograd.graph.saved_tensors_hooks(pack, lambda t: t):
+            out, _ = layer(xh, attention_mask=None, rotary_pos_emb=freqs)
+        kept = sum(held.values())                  # (allocator deltas depend on when Python collects the previous layer: not used)
         out.backward(go)
         grads = {n: q.grad.clone() for n, q in layer.named_parameters()}
         res[fused] = (out.detach().clone(), xh.grad.clone(), grads, kept)
