@@ -327,6 +327,8 @@ def gemm_tn_ok(a_t: torch.Tensor, w_t: torch.Tensor) -> bool:
 
 def gemm_nn_ok(a: torch.Tensor, w: torch.Tensor) -> bool:
     """Shapes vita_gemm_bf16_nn takes (a [M, K] row-major, w [K, N] contraction-major): whole 256 x 256 output tiles, K a multiple of 64."""
+    if os.environ.get("VITA_DEBUG") and os.environ.get("VITA_DGRAD_NN") == "0":        # developer A / B switch: the transposing path
+        return False
     return (a.dim() == 2 and w.dim() == 2 and a.shape[1] == w.shape[0] and a.stride(1) == 1 and w.stride(1) == 1
             and a.shape[0] % 256 == 0 and w.shape[1] % 256 == 0 and a.shape[1] % 64 == 0 and a.stride(0) % 8 == 0
             and w.stride(0) % 8 == 0 and a.shape[0] > 0 and a.dtype == BF16 and w.dtype == BF16)
