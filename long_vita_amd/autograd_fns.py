@@ -7,8 +7,6 @@ Every forward and backward below is a library kernel — the same calls the expl
 """
 from __future__ import annotations
 
-from typing import Optional
-
 import torch
 import torch.distributed as dist
 

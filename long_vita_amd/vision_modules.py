@@ -36,7 +36,7 @@ import torch.distributed as dist
 from torch.nn import Parameter
 
 from . import autograd_fns as F_, ops, parallel_state as mpu
-from .layers import ColumnParallelLinear, LayerNorm, RowParallelLinear, ViTMLP
+from .layers import ColumnParallelLinear, RowParallelLinear, ViTMLP
 
 
 # ------------------------------------------------------------------------------------------------------------------------------
