@@ -63,6 +63,33 @@ def test_train_step_cp1_vs_autograd(amd, S, n_ans):
     _check_grads(g, g_ref, 1.8e-2)
 
 
+@pytest.mark.parametrize("n_rec", [None, 1])
+def test_train_step_keeping_the_attention_half_of_the_recompute_block_is_bit_identical(amd, n_rec):
+    """r04: TrainStep(keep_attention=True) — the layers of the recompute block keep rotated qkv / context / lse / the post-attention
+    residual stream and re-derive only norms + fc1 + SwiGLU in the backward: the same kernels on the same values, so the loss and EVERY
+    gradient equal the full-recompute step bit for bit (n_rec = None: every layer in the block; 1: one recomputed + one kept layer)."""
+    S = 1024
+    ocfg = ollm.LLMConfig(**SMALL)
+    p = ollm.init_llm_params(ocfg, seed=33)
+    tokens, labels, loss_mask = _data(S, SMALL["vocab"], 130, 34)
+    model = amd["gpt"].GPTVLModel.from_oracle_layout(amd["gpt"].GPTConfig(**SMALL), p, None, DEV)
+    args = (tokens.to(DEV), labels.to(DEV), loss_mask.to(DEV))
+    loss0, g0 = amd["train"].TrainStep(model, recompute_num_layers=n_rec).forward_backward(*args)
+    loss1, g1 = amd["train"].TrainStep(model, recompute_num_layers=n_rec, keep_attention=True).forward_backward(*args)
+    assert float(loss0) == float(loss1)
+    assert torch.equal(g0["lm_head"], g1["lm_head"])
+    tol("embed (fp32 atomic row sums)", rel_l2(g1["embed"], g0["embed"]), 1e-5)
+    for li, (a, b) in enumerate(zip(g0["layers"], g1["layers"])):
+        for k in a:
+            if k in ("ln1", "ln2", "qkv_b"):               # fp32 atomic sums: the order of the adds is not fixed
+                tol(f"layers.{li}.{k} (fp32 atomic sums)", rel_l2(b[k], a[k]), 1e-3)
+            else:
+                assert torch.equal(a[k], b[k]), (li, k)
+    loss_ref, g_ref = otrain.loss_and_grads(tokens, labels, loss_mask, p, ocfg)
+    assert abs(float(loss1) - float(loss_ref)) < 2e-2 * abs(float(loss_ref))
+    _check_grads(g1, g_ref, 1.8e-2)
+
+
 def test_train_step_with_logit_scale_and_softcap(amd):
     """output_multiplier_scale / output_logit_softcapping (gpt_vl_model.py:349-355) in the loss and its gradient."""
     S = 512

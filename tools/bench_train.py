@@ -14,6 +14,7 @@ ap.add_argument("--layers", type=int, default=48)
 ap.add_argument("--answer", type=int, default=512)
 ap.add_argument("--steps", type=int, default=2)
 ap.add_argument("--recompute-num-layers", type=int, default=-1, help="-1 = every layer (full recompute); stage 3 passes 20; 0 keeps all activations")
+ap.add_argument("--keep-attention", type=int, default=0, help="1: the recompute block keeps its attention half (TrainStep keep_attention)")
 args = ap.parse_args()
 lib.load(allow_build=False)
 dev = "cuda:0"
@@ -26,7 +27,7 @@ labels = torch.roll(tokens, -1, 1)
 loss_mask = torch.zeros(1, S, device=dev)
 loss_mask[0, S - args.answer:] = 1
 rec = None if args.recompute_num_layers < 0 else args.recompute_num_layers
-step = training.TrainStep(model, recompute_num_layers=rec)
+step = training.TrainStep(model, recompute_num_layers=rec, keep_attention=bool(args.keep_attention))
 loss, grads = step.forward_backward(tokens, labels, loss_mask)      # warm-up
 del grads
 torch.cuda.synchronize()
@@ -44,7 +45,7 @@ fwd = lin + attn
 n_rec = cfg.num_layers if rec is None else max(0, min(cfg.num_layers, rec))
 r = n_rec / cfg.num_layers
 alg = (3 + r) * lin + (3.5 + r) * attn
-print(json.dumps({"what": f"train step fwd+bwd, recompute block = {n_rec} of {cfg.num_layers} layers, TP=1 CP=1", "seq": S,
+print(json.dumps({"what": f"train step fwd+bwd, recompute block = {n_rec} of {cfg.num_layers} layers, TP=1 CP=1" + (", attention half kept (keep_attention)" if args.keep_attention else ""), "keep_attention": bool(args.keep_attention), "seq": S,
                   "layers": cfg.num_layers, "recompute_num_layers": n_rec,
                   "answer_tokens": args.answer, "s_per_step": dt, "loss": float(loss),
                   "algorithmic_tflop_per_step": alg / 1e12, "tflops": alg / dt / 1e12,
