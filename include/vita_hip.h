@@ -17,6 +17,7 @@
 #ifndef VITA_HIP_H
 #define VITA_HIP_H
 
+#include <stddef.h>
 #include <stdint.h>
 
 #ifdef __cplusplus
@@ -78,7 +79,8 @@ int vita_rope_cos_sin(const float* freqs, int64_t row_stride, void* cos_out, voi
 
 /* In-place RoPE on a strided [rows, heads, head_dim] bf16 view (non-interleaved halves):
  *   t = bf16(bf16(t*cos) + bf16(rotate_half(t)*sin))   — the rounding chain of :203.
- * row_stride / head_stride in elements.  sign = +1 forward, -1 backward (transpose rotation). */
+ * row_stride / head_stride in elements.  sign = +1 forward, -1 backward (transpose rotation).
+ * Replaces apply_rotary_pos_emb_bshd (M/core/models/common/embeddings/rotary_pos_embedding.py:181-204) on q / k views. */
 int vita_rope_apply(void* t, int64_t rows, int heads, int head_dim,
                     int64_t row_stride, int64_t head_stride,
                     const void* cos_tab, const void* sin_tab, int sign, void* stream);
@@ -93,7 +95,8 @@ int vita_rope_qkv_fwd(void* mixed_qkv, int64_t rows, int groups, int q_per_group
                       const void* cos_tab, const void* sin_tab, void* kv_out, int kv_split,
                       void* stream);
 /* Backward of the rotation on the gradient of the mixed QKV activation (in place): applies the
- * transpose rotation to the dQ and dK heads, leaves dV untouched. */
+ * transpose rotation to the dQ and dK heads, leaves dV untouched.
+ * The autograd of apply_rotary_pos_emb_bshd (rotary_pos_embedding.py:181-204) on the mixed QKV gradient. */
 int vita_rope_qkv_bwd(void* d_mixed_qkv, int64_t rows, int groups, int q_per_group, int head_dim,
                       const void* cos_tab, const void* sin_tab, void* stream);
 
@@ -362,12 +365,14 @@ int vita_transpose_bf16(const void* src, int64_t ld_src, void* dst, int64_t ld_d
 
 /* RMSNorm backward of vita_rmsnorm_fwd's expression: dx bf16 (+ `res` when not NULL: the gradient
  * arriving through the residual connection, dx = bf16(res + bf16(dx_norm))); dw_acc fp32 [cols] is
- * ACCUMULATED (caller zeroes it; may be NULL). */
+ * ACCUMULATED (caller zeroes it; may be NULL).
+ * The autograd of RMSNorm._norm / forward (M/core/transformer/custom_layers/transformer_engine.py:74-79). */
 int vita_rmsnorm_bwd(const void* dy, const void* x, const void* w, const void* res, void* dx,
                      float* dw_acc, int64_t rows, int cols, float eps, void* stream);
 
 /* SwiGLU on the unfused fc1 output y = [gate | up] ([rows, 2*ffn]):  a = bf16(bf16(silu(g)) * u);
- * backward writes dy = [dgate | dup]. */
+ * backward writes dy = [dgate | dup].
+ * Megatron MLP's `silu(gate) * up` under `--swiglu` (the MLP the spec of M/core/models/gpt/gpt_layer_specs.py:93-104 builds) and its autograd. */
 int vita_swiglu_fwd(const void* y, void* a, int64_t rows, int ffn, void* stream);
 int vita_swiglu_bwd(const void* y, const void* da, void* dy, int64_t rows, int ffn, void* stream);
 
@@ -418,7 +423,8 @@ int vita_ce_loss_f32(const float* logits, int64_t ld, const int64_t* labels, flo
 int vita_row_scatter_add_f32(const void* src, const int64_t* idx, float* dst, int64_t dst_rows,
                              int64_t n, int cols, int* err_flag, void* stream);
 
-/* delta[h, row] = sum_d float(dO[row,h,d]) * float(O[row,h,d])  (attention backward pre-pass). */
+/* delta[h, row] = sum_d float(dO[row,h,d]) * float(O[row,h,d])  (attention backward pre-pass).
+ * First kernel of the flash-attention backward that stands behind M/core/transformer/dot_product_attention.py:374-390. */
 int vita_attn_delta(const void* o, const void* d_o, float* delta, int64_t rows, int heads,
                     int head_dim, int64_t o_row_stride, int64_t o_head_stride, int64_t do_row_stride,
                     int64_t do_head_stride, void* stream);
@@ -501,7 +507,8 @@ int vita_decode_attn_merge(const void* part_m, const void* part_l, const void* p
 
 /* out[n] = bf16(a[n] + b[n]) (n % 8 == 0): the residual add that follows the tensor-parallel all-reduce of a
  * row-parallel linear's output (RowParallelLinear + bias_dropout_add, TP > 1 only; at TP = 1 the add is the GEMM's
- * RESIDUAL epilogue). */
+ * RESIDUAL epilogue).
+ * RowParallelLinear.forward + bias_dropout_add (M/core/tensor_parallel/layers.py:1059-1115). */
 int vita_add_bf16(const void* a, const void* b, void* out, int64_t n, void* stream);
 
 /* One decoder layer for one token, launched from C: vita_decode_layer_attn = RMSNorm (fused into the

@@ -1126,3 +1126,12 @@ def test_committed_pmc_json_follows_from_the_committed_raw_counter_passes(tmp_pa
     line = json.loads(open(os.path.join(prof, "r04_bench128k_n1.json")).read().strip().splitlines()[-1])
     assert abs(line["roofline"]["ms_per_launch"] / a["sq_counters_S131072"]["ms_per_launch_rocprofv3_kernel_trace"] - 1) < 0.03
     assert abs(line["roofline"]["frac"] - line["roofline"]["achieved"] / line["roofline"]["peak"]) < 1e-9
+
+
+def test_header_is_self_contained_c11(tmp_path):
+    """include/vita_hip.h compiles on its own as C11 (no prior #include in the translation unit) and as C++17."""
+    hdr = os.path.join(ROOT, "include", "vita_hip.h")
+    r = subprocess.run(["gcc", "-std=c11", "-Wall", "-Werror", "-fsyntax-only", "-x", "c", hdr], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
+    r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-x", "c++", hdr], capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr[-2000:]
