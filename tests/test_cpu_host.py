@@ -1135,3 +1135,72 @@ def test_header_is_self_contained_c11(tmp_path):
     assert r.returncode == 0, r.stderr[-2000:]
     r = subprocess.run(["g++", "-std=c++17", "-fsyntax-only", "-x", "c++", hdr], capture_output=True, text=True)
     assert r.returncode == 0, r.stderr[-2000:]
+
+
+# ---- bench.py launches its own ranks -----------------------------------------------------------------------
+def _bench_module():
+    import importlib
+    if ROOT not in sys.path:
+        sys.path.insert(0, ROOT)
+    return importlib.import_module("bench")
+
+
+def test_bench_self_launch_command_is_the_drivers_form():
+    """`python bench.py --gpus N` with no launcher re-runs itself as `python -m torch.distributed.run --nnodes=1 --nproc-per-node N
+    --master-addr 127.0.0.1 --master-port P bench.py --gpus N ...` (the task statement's command for N > 1; the reference's scripts
+    launch through torchrun themselves, R/scripts/megatron/qwen25/inference_qwen25_14b_intern_300m_server_cp.sh:96-181)."""
+    bench = _bench_module()
+    argv = ["--gpus", "8", "--steps", "20", "--warmup", "5"]
+    cmd = bench.launch_command(8, 29511, argv)
+    assert cmd[:3] == [sys.executable, "-m", "torch.distributed.run"]
+    assert cmd[3:10] == ["--nnodes=1", "--nproc-per-node", "8", "--master-addr", "127.0.0.1", "--master-port", "29511"]
+    assert os.path.samefile(cmd[10], os.path.join(ROOT, "bench.py")) and cmd[11:] == argv
+
+
+def test_bench_self_launch_relays_one_line_and_degrades_instead_of_dying(capsys):
+    """self_launch: a good first launch -> its line, rc 0, ONE launch; a launch that dies (or hangs past its limit) before a line ->
+    exactly one more launch on the plain exchange schedule with the reason handed down, and THAT line comes out with rc 0; two bad
+    launches -> non-zero.  The ranks never see VITA_BENCH_FORCE_SPAWN (they must not launch again) and always see dmabuf IPC."""
+    bench = _bench_module()
+    good = 'noise\n{"metric": "prefill tokens/sec/node (ViT+LLM) at seq=128K", "value": 1.0}\n'
+    calls = []
+
+    def runner(script):
+        def run(cmd, env, timeout):
+            calls.append((cmd, dict(env), timeout))
+            return script[len(calls) - 1]
+        return run
+
+    env0 = {"PATH": os.environ.get("PATH", ""), "VITA_BENCH_FORCE_SPAWN": "1"}
+    rc = bench.self_launch(2, ["--gpus", "2"], 2, 1, run=runner([(0, good)]), environ=env0)
+    out = capsys.readouterr().out.strip().splitlines()
+    assert rc == 0 and len(calls) == 1 and len(out) == 1 and out[0].startswith('{"metric"')
+    cmd, env, limit = calls[0]
+    assert "--nproc-per-node" in cmd and cmd[cmd.index("--nproc-per-node") + 1] == "2" and limit >= 900
+    assert env["HSA_ENABLE_IPC_MODE_LEGACY"] == "0" and "VITA_BENCH_FORCE_SPAWN" not in env and "VITA_BENCH_DEGRADED" not in env
+    assert env["VITA_BENCH_SELF_LAUNCHED"] == "1"
+
+    for first in ((1, "Traceback ...\n"), (None, "")):                         # died / killed on the time limit
+        calls.clear()
+        rc = bench.self_launch(4, ["--gpus", "4"], 2, 1, run=runner([first, (0, good)]), environ=env0)
+        out = capsys.readouterr().out.strip().splitlines()
+        assert rc == 0 and len(calls) == 2 and len(out) == 1
+        env2 = calls[1][1]
+        assert all(env2[k] == v for k, v in bench.DEGRADED_ENV.items()) and "plain exchange schedule" in env2["VITA_BENCH_DEGRADED"]
+        assert calls[0][0][calls[0][0].index("--master-port") + 1] != "" and "VITA_CP_STREAMS" not in calls[0][1]
+
+    calls.clear()
+    rc = bench.self_launch(2, ["--gpus", "2"], 2, 1, run=runner([(1, ""), (7, "")]), environ=env0)
+    assert rc == 7 and len(calls) == 2 and capsys.readouterr().out.strip() == ""
+
+
+def test_bench_run_ranks_ends_a_hung_launch_by_its_own_process_group():
+    """_run_ranks: stdout captured, the return code passed on; a launch that outlives its limit is killed as a process group (its own
+    session — nothing is matched by name) and reported as None."""
+    bench = _bench_module()
+    rc, out = bench._run_ranks([sys.executable, "-c", "print('{\"metric\": 1}')"], dict(os.environ), 60)
+    assert rc == 0 and out.strip() == '{"metric": 1}'
+    t0 = __import__("time").time()
+    rc, out = bench._run_ranks([sys.executable, "-c", "import time, subprocess, sys; print('started', flush=True); "
+                                "subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(600)']); time.sleep(600)"], dict(os.environ), 3)
+    assert rc is None and "started" in out and __import__("time").time() - t0 < 60

@@ -127,3 +127,40 @@ def test_bench_dry_run_goes_through_the_distributed_plumbing():
     comm = line["comm"]
     assert "error" not in comm, comm
     assert comm["ranks"] == 1 and comm["backend"] == "nccl" and comm["isolated_all_gather_ms"] > 0 and comm["kv_messages_per_layer"] >= 1
+
+
+def _bench_self_launched(extra_env):
+    """`python bench.py --gpus 1 --dry-run` with NO launcher around it and VITA_BENCH_FORCE_SPAWN=1: the file starts its own rank under
+    torch.distributed.run (what `--gpus N`, N > 1, does on a multi-GPU node) and relays the one line."""
+    import json
+    env = dict(os.environ, VITA_BENCH_FORCE_SPAWN="1", **extra_env)
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1", "--steps", "1", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout                                             # ONE line, rank 0's
+    return json.loads(lines[0]), r.stderr
+
+
+def test_bench_launches_its_own_ranks():
+    """the self-launch walked on one GPU — process group over RCCL, the gloo control group, the first-step
+    vote, the `comm` object — with no degradation reported."""
+    line, _ = _bench_self_launched({})
+    assert line["n_gpus"] == 1 and line["value"] > 0 and "degraded" not in line
+    assert line["comm"]["backend"] == "nccl" and line["comm"]["ranks"] == 1 and "error" not in line["comm"]
+
+
+def test_bench_first_step_failure_degrades_inside_the_ranks():
+    """A first step that raises on any rank: every rank drops to the plain exchange schedule together (the vote runs on gloo, not on the
+    communicator under test) and the line says so instead of the run ending with rc != 0."""
+    line, _ = _bench_self_launched({"VITA_BENCH_INJECT_FAILURE": "1"})
+    assert line["value"] > 0 and "injected first-step failure" in line["degraded"] and "rank 0" in line["degraded"]
+
+
+def test_bench_dead_ranks_get_one_plain_relaunch():
+    """Ranks that die before a line appears: the launcher starts them once more with DEGRADED_ENV and the reason in the line."""
+    line, err = _bench_self_launched({"VITA_BENCH_INJECT_FAILURE": "exit"})
+    assert line["value"] > 0 and "first launch of 1 ranks exited with code" in line["degraded"]
+    assert "re-run on the plain exchange schedule" in err
