@@ -408,7 +408,9 @@ int vita_bias_scale_res_bwd(const void* g, const void* x, const void* bias, cons
 /* Vocabulary cross-entropy of the selected rows (TP = 1 form of Megatron's vocab-parallel CE, called at
  * M/core/models/multimodal/gpt_vl_model.py:414):  loss[i] = logsumexp(float(logits[i])) - logits[i, label[i]];
  * when dlogits != NULL also dlogits[i] = bf16((softmax - onehot) * grad_scale[i]) (grad_scale NULL = 1).
- * Labels outside [0, vocab) set *err_flag. */
+ * A label outside [0, vocab) (the datasets pad with IGNORE_TOKEN_ID = -100, M/pretrain_long_vita.py:751) is treated as Megatron's
+ * vocab_parallel_cross_entropy treats it — masked target: loss[i] = log sum exp(logits[i] - max), no one-hot term in dlogits[i] — and
+ * additionally sets *err_flag when err_flag != NULL (ABI 17; before: the row was skipped). */
 int vita_ce_loss(const void* logits, int64_t ld, const int64_t* labels, float* loss, void* dlogits,
                  int64_t ld_d, const float* grad_scale, int64_t rows, int vocab, int* err_flag,
                  void* stream);
@@ -417,6 +419,20 @@ int vita_ce_loss(const void* logits, int64_t ld, const int64_t* labels, float* l
  * dlogits is wanted (the autograd backward re-runs the row pass with grad_scale = the incoming gradient). */
 int vita_ce_loss_f32(const float* logits, int64_t ld, const int64_t* labels, float* loss, float* dlogits,
                      int64_t ld_d, const float* grad_scale, int64_t rows, int vocab, int* err_flag, void* stream);
+
+/* ABI 17: the vocabulary-PARALLEL cross entropy (TP > 1) — megatron.core.tensor_parallel.cross_entropy.vocab_parallel_cross_entropy
+ * as LanguageModule.compute_language_model_loss calls it at M/core/models/multimodal/gpt_vl_model.py:414.  Each rank keeps its
+ * [rows, vocab_local] shard (logits bf16, or fp32 when is_f32) and its labels in GLOBAL vocabulary ids:
+ *   vita_ce_vp_stats   stats[row] = {max, sum exp(l - max), predicted raw logit or 0, 1 if vocab_start <= label < vocab_start + vocab_local};
+ *   (caller: all-gather the [rows, 4] fp32 records over the tensor-parallel group -> stats_all [tp, rows, 4], rank-major)
+ *   vita_ce_vp_finish  loss[row] = log(sum exp) - (predicted - max), or log(sum exp) when no shard holds the label (masked target);
+ *                      row_stat[row] = {global max, global sum exp} for the backward; loss may be NULL;
+ *   vita_ce_vp_grad    dlogits[row, v] = (exp(l - max) / sumexp - [v == label - vocab_start]) * grad_scale[row]  (NULL = 1), shard only. */
+int vita_ce_vp_stats(const void* logits, int is_f32, int64_t ld, const int64_t* labels, int64_t vocab_start, float* stats,
+                     int64_t rows, int vocab_local, void* stream);
+int vita_ce_vp_finish(const float* stats_all, int tp, int64_t rows, float* loss, float* row_stat, void* stream);
+int vita_ce_vp_grad(const void* logits, int is_f32, int64_t ld, const int64_t* labels, int64_t vocab_start, const float* row_stat,
+                    const float* grad_scale, void* dlogits, int64_t ld_d, int64_t rows, int vocab_local, void* stream);
 
 /* dst_f32[idx[i], :] += float(src_bf16[i, :]) — word-embedding weight gradient (the backward of
  * M/core/tensor_parallel/layers.py:216-232); idx[i] < 0 skips row i (visual-token positions). */

@@ -228,7 +228,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
 #pragma unroll
           for (int r = 0; r < 16; ++r) {
             const int key = kv_off + 32 * h + (r & 3) + 8 * (r >> 2) + 4 * hi;
-            s[r] = (key > lim_hi) | (key < lim_lo) ? 0.f : s[r];
+            s[r] = ((key > lim_hi) | (key < lim_lo)) ? 0.f : s[r];
           }
         }
 #pragma unroll
@@ -433,7 +433,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
 #pragma unroll
           for (int j = 0; j < 4; ++j) {
             const int qrow = need_mask ? q_off + 8 * rg + 4 * hi + j : 0x7fffffff;
-            pr[rg * 4 + j] = (my_key > qrow) | (my_key < st4[j]) ? 0.f : pr[rg * 4 + j];
+            pr[rg * 4 + j] = ((my_key > qrow) | (my_key < st4[j])) ? 0.f : pr[rg * 4 + j];
           }
         }
       }

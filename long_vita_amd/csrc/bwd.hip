@@ -657,12 +657,13 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const T* __restrict__ logi
   for (int v = threadIdx.x; v < V; v += blockDim.x) se += __expf(ce_ld(lr, v) - mx);
   se = block_reduce_sum(se, red);
   const int64_t lab = labels[row];
-  if (lab < 0 || lab >= V) {
-    if (threadIdx.x == 0 && err_flag) atomicExch(err_flag, 1);
-    return;
-  }
+  // A label outside [0, V) (the datasets pad with IGNORE_TOKEN_ID = -100, M/pretrain_long_vita.py:751): Megatron's
+  // vocab_parallel_cross_entropy masks the target — predicted logit 0 AFTER the max subtraction, no one-hot term in the gradient —
+  // and leaves the row to the caller's loss mask.  The same here; err_flag (when given) still reports that such a row was seen.
+  const bool in_range = lab >= 0 && lab < V;
+  if (!in_range && threadIdx.x == 0 && err_flag) atomicExch(err_flag, 1);
   const float lse = mx + __logf(se);
-  if (threadIdx.x == 0 && loss) loss[row] = lse - ce_ld(lr, lab);
+  if (threadIdx.x == 0 && loss) loss[row] = in_range ? lse - ce_ld(lr, lab) : __logf(se);
   if (dlogits) {
     const float gs = grad_scale ? grad_scale[row] : 1.0f;
     const float inv = 1.0f / se;
@@ -672,6 +673,79 @@ __global__ __launch_bounds__(256) void ce_loss_kernel(const T* __restrict__ logi
       if (v == lab) pr -= 1.0f;
       ce_st(dr, v, pr * gs);
     }
+  }
+}
+
+// ---------------------------------------------------------------------------------------------
+// The vocabulary-PARALLEL form (TP > 1; megatron/core/tensor_parallel/cross_entropy.py): every rank holds [rows, V / TP] and never
+// sees the other shards.  Three row passes, ONE collective between the first two:
+//   stats   per row of the local shard: {max, sum exp(l - max), predicted raw logit (0 if the label is not in this shard), in-shard 0/1}
+//           -> the caller all-gathers the [rows, 4] records of the TP group
+//   finish  per row: global max, global sum-exp (each shard's sum rescaled), loss = log(sumexp) - (predicted - max) — or log(sumexp)
+//           when no shard holds the label (Megatron's masked target) — and {max, sumexp} kept for the backward
+//   grad    per row of the local shard: dlogits = (exp(l - max) / sumexp - [v == label - vocab_start]) * grad_scale
+// ---------------------------------------------------------------------------------------------
+template <typename T>
+__global__ __launch_bounds__(256) void ce_vp_stats_kernel(const T* __restrict__ logits, int64_t ld, const int64_t* __restrict__ labels,
+                                                          int64_t vocab_start, float* __restrict__ stats, int V) {
+  __shared__ float red[16];
+  const int64_t row = blockIdx.x;
+  const T* lr = logits + row * ld;
+  float mx = -INFINITY;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) mx = fmaxf(mx, ce_ld(lr, v));
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) mx = fmaxf(mx, __shfl_xor(mx, off, 64));
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = mx;
+  __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
+  float se = 0.f;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) se += __expf(ce_ld(lr, v) - mx);
+  se = block_reduce_sum(se, red);
+  if (threadIdx.x == 0) {
+    const int64_t lab = labels[row] - vocab_start;
+    const bool mine = lab >= 0 && lab < V;
+    float* st = stats + row * 4;
+    st[0] = mx;
+    st[1] = se;
+    st[2] = mine ? ce_ld(lr, lab) : 0.f;
+    st[3] = mine ? 1.f : 0.f;
+  }
+}
+
+// stats_all [tp, rows, 4] (rank-major, as all_gather_into_tensor leaves it) -> loss [rows], row_stat [rows, 2] = {max, sumexp}
+__global__ __launch_bounds__(256) void ce_vp_finish_kernel(const float* __restrict__ stats_all, int tp, int64_t rows,
+                                                           float* __restrict__ loss, float* __restrict__ row_stat) {
+  const int64_t row = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (row >= rows) return;
+  float mx = -INFINITY;
+  for (int r = 0; r < tp; ++r) mx = fmaxf(mx, stats_all[((int64_t)r * rows + row) * 4]);
+  float se = 0.f, pred = 0.f, held = 0.f;
+  for (int r = 0; r < tp; ++r) {
+    const float* st = stats_all + ((int64_t)r * rows + row) * 4;
+    se += st[1] * __expf(st[0] - mx);
+    pred += st[2];
+    held += st[3];
+  }
+  if (loss) loss[row] = __logf(se) - (held > 0.f ? pred - mx : 0.f);
+  row_stat[row * 2] = mx;
+  row_stat[row * 2 + 1] = se;
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void ce_vp_grad_kernel(const T* __restrict__ logits, int64_t ld, const int64_t* __restrict__ labels,
+                                                         int64_t vocab_start, const float* __restrict__ row_stat,
+                                                         const float* __restrict__ grad_scale, T* __restrict__ dlogits, int64_t ldd, int V) {
+  const int64_t row = blockIdx.x;
+  const T* lr = logits + row * ld;
+  T* dr = dlogits + row * ldd;
+  const float mx = row_stat[row * 2], inv = 1.0f / row_stat[row * 2 + 1];
+  const float gs = grad_scale ? grad_scale[row] : 1.0f;
+  const int64_t lab = labels[row] - vocab_start;
+  for (int v = threadIdx.x; v < V; v += blockDim.x) {
+    float pr = __expf(ce_ld(lr, v) - mx) * inv;
+    if (v == lab) pr -= 1.0f;
+    ce_st(dr, v, pr * gs);
   }
 }
 
@@ -933,6 +1007,42 @@ extern "C" int vita_ce_loss_f32(const float* logits, int64_t ld, const int64_t* 
   if (rows > 0x7fffffff) return VITA_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(ce_loss_kernel<float>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream,
                      logits, ld, labels, loss, dlogits, ld_d, grad_scale, vocab, err_flag);
+  return vita_check_launch();
+}
+
+// ---- vocabulary-parallel cross entropy (ABI 17) ----
+extern "C" int vita_ce_vp_stats(const void* logits, int is_f32, int64_t ld, const int64_t* labels, int64_t vocab_start, float* stats,
+                                int64_t rows, int vocab_local, void* stream) {
+  if (!logits || !labels || !stats || rows < 0 || vocab_local <= 0) return VITA_ERR_INVALID_ARG;
+  if (rows == 0) return VITA_OK;
+  if (rows > 0x7fffffff) return VITA_ERR_UNSUPPORTED;
+  if (is_f32)
+    hipLaunchKernelGGL(ce_vp_stats_kernel<float>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const float*)logits, ld, labels,
+                       vocab_start, stats, vocab_local);
+  else
+    hipLaunchKernelGGL(ce_vp_stats_kernel<bf16_t>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, ld,
+                       labels, vocab_start, stats, vocab_local);
+  return vita_check_launch();
+}
+
+extern "C" int vita_ce_vp_finish(const float* stats_all, int tp, int64_t rows, float* loss, float* row_stat, void* stream) {
+  if (!stats_all || !row_stat || tp <= 0 || rows < 0) return VITA_ERR_INVALID_ARG;
+  if (rows == 0) return VITA_OK;
+  hipLaunchKernelGGL(ce_vp_finish_kernel, dim3(grid_for(rows, 256)), dim3(256), 0, (hipStream_t)stream, stats_all, tp, rows, loss, row_stat);
+  return vita_check_launch();
+}
+
+extern "C" int vita_ce_vp_grad(const void* logits, int is_f32, int64_t ld, const int64_t* labels, int64_t vocab_start, const float* row_stat,
+                               const float* grad_scale, void* dlogits, int64_t ld_d, int64_t rows, int vocab_local, void* stream) {
+  if (!logits || !labels || !row_stat || !dlogits || rows < 0 || vocab_local <= 0) return VITA_ERR_INVALID_ARG;
+  if (rows == 0) return VITA_OK;
+  if (rows > 0x7fffffff) return VITA_ERR_UNSUPPORTED;
+  if (is_f32)
+    hipLaunchKernelGGL(ce_vp_grad_kernel<float>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const float*)logits, ld, labels,
+                       vocab_start, row_stat, grad_scale, (float*)dlogits, ld_d, vocab_local);
+  else
+    hipLaunchKernelGGL(ce_vp_grad_kernel<bf16_t>, dim3((unsigned)rows), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)logits, ld, labels,
+                       vocab_start, row_stat, grad_scale, (bf16_t*)dlogits, ld_d, vocab_local);
   return vita_check_launch();
 }
 

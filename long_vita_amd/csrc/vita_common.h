@@ -129,12 +129,14 @@ __device__ __forceinline__ vita_rsrc_t vita_make_rsrc_uniform(const void* base) 
   r[0] = (unsigned)v; r[1] = (unsigned)(v >> 32) & 0xffffu; r[2] = 0x7fffffffu; r[3] = 0x00020000u;
   return r;
 }
+// m0 is handed to the asm as an INPUT operand ("{m0}"): the compiler writes it (and knows it did — no reserved-register clobber, so no
+// "may not be preserved" warning and no reliance on m0 being dead across the statement); the `s_nop 0` is the wait state the hardware
+// wants between an SALU write of m0 and an LDS-DMA that reads it, which the hazard recognizer cannot see inside an asm string.
 __device__ __forceinline__ void vita_lds_dma16(vita_rsrc_t rsrc, unsigned voff_bytes, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
-               :: "s"(lds_addr), "v"(voff_bytes), "s"(rsrc) : "memory", "m0");
+  asm volatile("s_nop 0\n\tbuffer_load_dwordx4 %1, %2, 0 offen lds"
+               :: "{m0}"(lds_addr), "v"(voff_bytes), "s"(rsrc) : "memory");
 }
 __device__ __forceinline__ void vita_lds_dma4(vita_rsrc_t rsrc, unsigned voff_bytes, unsigned lds_addr) {
-  asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
-               :: "s"(lds_addr), "v"(voff_bytes), "s"(rsrc) : "memory", "m0");
+  asm volatile("s_nop 0\n\tbuffer_load_dword %1, %2, 0 offen lds"
+               :: "{m0}"(lds_addr), "v"(voff_bytes), "s"(rsrc) : "memory");
 }
-

@@ -23,7 +23,7 @@ if os.environ.get("VITA_HIP_LIB"):                    # developer A / B switch: 
     LIB_PATH = os.path.abspath(os.environ["VITA_HIP_LIB"])
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "vita_hip.h")
 
-ABI_VERSION = 16
+ABI_VERSION = 17
 VITA_OK = 0
 VITA_ERR_INVALID_ARG = -1
 VITA_ERR_UNSUPPORTED = -2
@@ -175,6 +175,9 @@ PROTOTYPES = {
     "vita_bias_scale_res_bwd": (_i, [_p, _p, _p, _p, _p, _p, _p, _l, _i, _p]),
     "vita_ce_loss": (_i, [_p, _l, _p, _p, _p, _l, _p, _l, _i, _p, _p]),
     "vita_ce_loss_f32": (_i, [_p, _l, _p, _p, _p, _l, _p, _l, _i, _p, _p]),
+    "vita_ce_vp_stats": (_i, [_p, _i, _l, _p, _l, _p, _l, _i, _p]),
+    "vita_ce_vp_finish": (_i, [_p, _i, _l, _p, _p, _p]),
+    "vita_ce_vp_grad": (_i, [_p, _i, _l, _p, _l, _p, _p, _p, _l, _l, _i, _p]),
     "vita_row_scatter_add_f32": (_i, [_p, _p, _p, _l, _l, _i, _p, _p]),
     "vita_attn_delta": (_i, [_p, _p, _p, _l, _i, _i, _l, _l, _l, _l, _p]),
     "vita_flash_attn_bwd": (_i, [C.POINTER(AttnBwdParams), _p]),

@@ -301,12 +301,15 @@ _PAD_CACHE: dict = {}
 
 
 def _padded_weight(w: torch.Tensor, kp: int) -> torch.Tensor:
-    """The zero-padded copy of a weight whose contraction length is not a multiple of 64 (SigLIP's fc2: K = 4304), made once per
-    weight VERSION: only `torch.nn.Parameter`s are cached — keyed by identity of the storage and shape, validated by torch's in-place
-    version counter, so an optimizer step or a checkpoint load invalidates the copy.  Anything else (activations, the transposed weight
-    of a dgrad: fresh tensors whose address the allocator reuses) is padded per call.  The cache drops its oldest entry beyond 128."""
-    if not isinstance(w, torch.nn.Parameter):
-        return torch.nn.functional.pad(w, (0, kp - w.shape[1]))
+    """The zero-padded copy of a weight whose contraction length is not a multiple of 64 (SigLIP's fc2: K = 4304).  Cached ONLY for
+    FROZEN `torch.nn.Parameter`s (requires_grad False: inference, `--vision-model-freeze`) — keyed by storage identity and shape and
+    validated by torch's in-place version counter, which `load_state_dict` / `copy_` bump.  A trainable weight is padded on every call:
+    optimizers write through `param.data` (Megatron's Float16Optimizer._copy_main_params_to_model_params, the distributed optimizer's
+    param-buffer all-gather, apex multi-tensor kernels) and `.data` writes do NOT move the version counter, so a cached copy would go
+    stale after the first step.  Code that rewrites a frozen weight through `.data` calls `invalidate_padded_weights()`.
+    Anything else (activations, the transposed weight of a dgrad) is padded per call.  The cache drops its oldest entry beyond 128."""
+    if not isinstance(w, torch.nn.Parameter) or w.requires_grad:
+        return torch.nn.functional.pad(w.detach(), (0, kp - w.shape[1]))
     key = (w.data_ptr(), tuple(w.shape), w.stride(0), w.device.index)
     hit = _PAD_CACHE.get(key)
     if hit is not None and hit[0] == w._version:
@@ -316,6 +319,11 @@ def _padded_weight(w: torch.Tensor, kp: int) -> torch.Tensor:
         _PAD_CACHE.pop(next(iter(_PAD_CACHE)))
     _PAD_CACHE[key] = (w._version, padded)
     return padded
+
+
+def invalidate_padded_weights() -> None:
+    """Drop every cached padded weight (after frozen weights were rewritten through `.data`, which torch's version counter cannot see)."""
+    _PAD_CACHE.clear()
 
 
 def gemm_tn_ok(a_t: torch.Tensor, w_t: torch.Tensor) -> bool:
@@ -709,8 +717,11 @@ def layernorm_param_grad(dy, x, dgamma: torch.Tensor, dbeta: torch.Tensor, eps: 
 
 
 def ce_loss(logits: torch.Tensor, labels: torch.Tensor, grad_scale: Optional[torch.Tensor] = None,
-            want_grad: bool = False, want_loss: bool = True):
-    """logits [n, V] bf16 (or fp32: dlogits fp32 too), labels [n] int64 -> loss [n] fp32 (, dlogits [n, V]); grad_scale fp32 [n]."""
+            want_grad: bool = False, want_loss: bool = True, strict: bool = True):
+    """logits [n, V] bf16 (or fp32: dlogits fp32 too), labels [n] int64 -> loss [n] fp32 (, dlogits [n, V]); grad_scale fp32 [n].
+    A label outside [0, V): the kernel follows Megatron's masked-target rule (loss = log sum exp(l - max), no one-hot term in the
+    gradient; the datasets pad with -100 and the loss mask removes those rows).  strict=True (the stand-alone step, whose labels are
+    always real tokens) additionally raises IndexError for such a label; strict=False neither checks nor synchronises."""
     n, V = logits.shape
     f32 = logits.dtype == torch.float32
     if not f32 and logits.dtype != BF16:
@@ -721,14 +732,62 @@ def ce_loss(logits: torch.Tensor, labels: torch.Tensor, grad_scale: Optional[tor
     dl = torch.empty_like(logits, memory_format=torch.contiguous_format) if want_grad else None
     if n == 0:
         return (loss, dl) if want_grad else loss
-    flag = _err_flag(logits.device)
+    flag = _err_flag(logits.device) if strict else None
     fn = _L.load().vita_ce_loss_f32 if f32 else _L.load().vita_ce_loss
     _L.check(fn(_dev(logits, "logits"), logits.stride(0), _dev(labels.contiguous(), "labels", torch.int64), _opt(loss, "loss"),
                 _opt(dl, "dlogits"), dl.stride(0) if want_grad else 0, _opt(grad_scale, "grad_scale", torch.float32), n, V,
-                _dev(flag, "flag"), _stream()), "vita_ce_loss")
-    if int(flag.item()):
+                _opt(flag, "flag"), _stream()), "vita_ce_loss")
+    if strict and int(flag.item()):
         raise IndexError("vita_ce_loss: label out of range")
     return (loss, dl) if want_grad else loss
+
+
+def _ce_vp_logits(logits: torch.Tensor):
+    if logits.dtype not in (torch.float32, BF16):
+        raise ValueError("logits must be bf16 or fp32")
+    if logits.dim() != 2:
+        raise ValueError("logits must be [rows, vocab_local]")
+    return logits if logits.stride(1) == 1 else logits.contiguous()
+
+
+def ce_vp_stats(logits: torch.Tensor, labels: torch.Tensor, vocab_start: int) -> torch.Tensor:
+    """Vocabulary-parallel cross entropy, pass 1 on this rank's shard [n, V / TP] (labels in global ids): fp32 [n, 4] =
+    {max, sum exp(l - max), predicted raw logit or 0, label-in-shard 0 / 1} — the record the tensor-parallel group all-gathers."""
+    logits = _ce_vp_logits(logits)
+    n, v_l = logits.shape
+    stats = torch.empty((n, 4), dtype=torch.float32, device=logits.device)
+    _L.check(_L.load().vita_ce_vp_stats(_dev(logits, "logits"), int(logits.dtype == torch.float32), logits.stride(0),
+                                        _dev(labels.contiguous(), "labels", torch.int64), int(vocab_start), _dev(stats, "stats"), n, v_l,
+                                        _stream()), "vita_ce_vp_stats")
+    return stats
+
+
+def ce_vp_finish(stats_all: torch.Tensor, want_loss: bool = True):
+    """stats_all fp32 [tp, n, 4] (rank-major) -> (loss [n] fp32 or None, row_stat [n, 2] = {global max, global sum exp})."""
+    tp, n, four = stats_all.shape
+    if four != 4 or not stats_all.is_contiguous():
+        raise ValueError("stats_all must be contiguous [tp, rows, 4]")
+    loss = torch.empty(n, dtype=torch.float32, device=stats_all.device) if want_loss else None
+    row_stat = torch.empty((n, 2), dtype=torch.float32, device=stats_all.device)
+    _L.check(_L.load().vita_ce_vp_finish(_dev(stats_all, "stats_all", torch.float32), tp, n, _opt(loss, "loss"), _dev(row_stat, "row_stat"),
+                                         _stream()), "vita_ce_vp_finish")
+    return loss, row_stat
+
+
+def ce_vp_grad(logits: torch.Tensor, labels: torch.Tensor, vocab_start: int, row_stat: torch.Tensor,
+               grad_scale: Optional[torch.Tensor] = None, out: Optional[torch.Tensor] = None) -> torch.Tensor:
+    """dlogits of this rank's shard only: (exp(l - max) / sumexp - onehot(label - vocab_start)) * grad_scale.  `out` may be the
+    logits tensor itself (element-wise, in place — Megatron reuses the buffer the same way)."""
+    logits = _ce_vp_logits(logits)
+    n, v_l = logits.shape
+    dl = torch.empty_like(logits) if out is None else out
+    if dl.shape != logits.shape or dl.dtype != logits.dtype or dl.stride(1) != 1:
+        raise ValueError("out must match the logits' shape / dtype with unit column stride")
+    _L.check(_L.load().vita_ce_vp_grad(_dev(logits, "logits"), int(logits.dtype == torch.float32), logits.stride(0),
+                                       _dev(labels.contiguous(), "labels", torch.int64), int(vocab_start),
+                                       _dev(row_stat, "row_stat", torch.float32), _opt(grad_scale, "grad_scale", torch.float32),
+                                       _dev(dl, "dlogits"), dl.stride(0), n, v_l, _stream()), "vita_ce_vp_grad")
+    return dl
 
 
 def row_scatter_add_f32_(dst: torch.Tensor, idx: torch.Tensor, src: torch.Tensor) -> torch.Tensor:

@@ -18,8 +18,10 @@
         `gpt_vl_model_init_wrapper` (registered on GPTVLModel.__init__) calls this on `self.external_feature_model`.
         `pre_proj_layernorm` stays the torch.nn.LayerNorm the reference constructs — as a parameter container only.
   vocab_parallel_cross_entropy      megatron.core.tensor_parallel.cross_entropy (called through
-        LanguageModule.compute_language_model_loss at gpt_vl_model.py:414): vita_ce_loss(_f32) forward, the same row pass with
-        grad_scale = incoming gradient backward; vocabulary shards are gathered over the tensor-parallel group first.
+        LanguageModule.compute_language_model_loss at gpt_vl_model.py:414): TP = 1 vita_ce_loss(_f32) forward, the same row pass with
+        grad_scale = incoming gradient backward; TP > 1 the vocabulary-parallel form on the local shard (vita_ce_vp_stats -> one
+        all-gather of 16-byte row records -> vita_ce_vp_finish; vita_ce_vp_grad).  Targets outside the vocabulary (the -100 padding)
+        are masked as Megatron masks them.
 
 `final_layernorm` needs no class of its own: megatron_adaptor registers layers.Norm on
 `megatron.core.transformer.custom_layers.transformer_engine.TENorm`, the name TransformerBlock builds it from
@@ -250,7 +252,9 @@ def _fusable(model) -> bool:
 def hip_forward_downsample(self, vit_output):
     """forward_downsample (M/pretrain_long_vita.py:452-470): drop the class token + pixel_shuffle(0.5) as one permutation kernel."""
     if not _fusable(self) or vit_output.shape[2] * 4 > 4096:
-        return self._vita_ref_forward_downsample(vit_output)
+        # the reference's pixel_shuffle `view`s its input (M/pretrain_long_vita.py:452-470): the encoder's strided [b, s, h] view of
+        # [s, b, h] memory (vita_keep_sbh) has to be made contiguous first (ADVICE r4: hidden * 4 > 4096, e.g. InternViT-6B)
+        return self._vita_ref_forward_downsample(vit_output.contiguous())
     if torch.is_grad_enabled() and vit_output.requires_grad:
         return PixelShuffleLNFn.apply(vit_output, None, None, _grid_of(self, vit_output), bool(self.add_class_token), 0.0)
     return ops.pixel_shuffle_ln(vit_output, None, None, _grid_of(self, vit_output), bool(self.add_class_token), 0.0, norm=False)
@@ -336,10 +340,12 @@ def gpt_vl_model_init_wrapper(fn):
 # vocabulary-parallel cross entropy
 # ------------------------------------------------------------------------------------------------------------------------------
 class VocabParallelCrossEntropyFn(torch.autograd.Function):
-    """logits [s, b, V / TP] (fp32 as Megatron passes them, or bf16), target [s, b] int64 -> loss [s, b] fp32
-    (megatron/core/tensor_parallel/cross_entropy.py: max / predicted logit / sum-exp all-reduced over the TP group; here the
-    vocabulary shards are gathered and every rank runs the row pass over the whole vocabulary — with the logit mask the rows are the
-    few hundred answer tokens — keeping its own slice of the gradient)."""
+    """logits [s, b, V / TP] (fp32 as Megatron passes them, or bf16), target [s, b] int64 in global vocabulary ids -> loss [s, b] fp32.
+    megatron/core/tensor_parallel/cross_entropy.py in its vocabulary-parallel form: every rank keeps only its [rows, V / TP] shard;
+    one row pass produces {max, sum-exp, predicted logit, holds-the-label} per row, the TP group all-gathers those 16-byte records (ONE
+    small collective where Megatron runs three all-reduces), and the backward writes the local slice of the gradient only.  Targets
+    outside the vocabulary (IGNORE_TOKEN_ID = -100 padding, M/pretrain_long_vita.py:751) are masked as Megatron masks them —
+    predicted logit 0, no one-hot term — and left to the caller's loss mask; nothing raises and nothing synchronises."""
 
     @staticmethod
     def forward(ctx, vocab_parallel_logits, target, label_smoothing=0.0):
@@ -349,26 +355,31 @@ class VocabParallelCrossEntropyFn(torch.autograd.Function):
         shape = target.shape
         v_l = vocab_parallel_logits.shape[-1]
         local = vocab_parallel_logits.reshape(-1, v_l)
-        if tp > 1:
-            parts = torch.empty((tp,) + tuple(local.shape), dtype=local.dtype, device=local.device)
-            dist.all_gather_into_tensor(parts.view(-1), local.contiguous().view(-1), group=group)
-            full = parts.permute(1, 0, 2).reshape(local.shape[0], tp * v_l)
-        else:
-            full = local
-        full = full.contiguous()
         labels = target.reshape(-1).contiguous()
-        loss = ops.ce_loss(full, labels)
-        ctx.save_for_backward(full, labels)
-        ctx.meta = (tp, mpu.get_tensor_model_parallel_rank(), v_l, tuple(vocab_parallel_logits.shape))
+        if tp == 1:
+            loss = ops.ce_loss(local, labels, strict=False)
+            ctx.save_for_backward(local, labels)
+            ctx.meta = (1, 0, tuple(vocab_parallel_logits.shape))
+            return loss.view(shape)
+        start = mpu.get_tensor_model_parallel_rank() * v_l
+        stats = ops.ce_vp_stats(local, labels, start)
+        stats_all = torch.empty((tp,) + tuple(stats.shape), dtype=stats.dtype, device=stats.device)
+        dist.all_gather_into_tensor(stats_all.view(-1), stats.view(-1), group=group)
+        loss, row_stat = ops.ce_vp_finish(stats_all)
+        ctx.save_for_backward(local, labels, row_stat)
+        ctx.meta = (tp, start, tuple(vocab_parallel_logits.shape))
         return loss.view(shape)
 
     @staticmethod
     def backward(ctx, g):
-        full, labels = ctx.saved_tensors
-        tp, rank, v_l, shape = ctx.meta
-        _, dl = ops.ce_loss(full, labels, g.reshape(-1).float().contiguous(), want_grad=True, want_loss=False)
-        if tp > 1:
-            dl = dl[:, rank * v_l:(rank + 1) * v_l]
+        tp, start, shape = ctx.meta
+        gs = g.reshape(-1).float().contiguous()
+        if tp == 1:
+            local, labels = ctx.saved_tensors
+            _, dl = ops.ce_loss(local, labels, gs, want_grad=True, want_loss=False, strict=False)
+        else:
+            local, labels, row_stat = ctx.saved_tensors
+            dl = ops.ce_vp_grad(local, labels, start, row_stat, gs)
         return dl.reshape(shape), None, None
 
 

@@ -93,8 +93,18 @@ def test_ce_loss_and_grad(ops):
     loss, dl = ops.ce_loss(logits.to(DEV), labels.to(DEV), scale.to(DEV), want_grad=True)
     torch.testing.assert_close(loss.cpu(), ref.detach(), rtol=1e-5, atol=1e-5)
     tol("dl, lf.grad", rel_l2(dl, lf.grad), 1.9e-03)
-    with pytest.raises(IndexError):
+    with pytest.raises(IndexError):                               # strict (the stand-alone step: labels are always real tokens)
         ops.ce_loss(logits.to(DEV), torch.full((n,), V, dtype=torch.int64, device=DEV))
+    # strict=False: Megatron's masked target for the -100 padding — loss = log sum exp(l - max), gradient = softmax * scale, no raise
+    lab2 = labels.clone()
+    lab2[[1, 5]] = -100
+    loss2, dl2 = ops.ce_loss(logits.to(DEV), lab2.to(DEV), scale.to(DEV), want_grad=True, strict=False)
+    lf2 = logits.float()
+    want = (lf2 - lf2.max(-1, keepdim=True)[0]).exp().sum(-1).log()
+    torch.testing.assert_close(loss2.cpu()[[1, 5]], want[[1, 5]], rtol=1e-5, atol=1e-5)
+    torch.testing.assert_close(loss2.cpu()[[0, 2, 3, 4, 6, 7, 8]], ref.detach()[[0, 2, 3, 4, 6, 7, 8]], rtol=1e-5, atol=1e-5)
+    sm = torch.softmax(lf2[[1, 5]], -1) * scale[[1, 5], None]
+    tol("masked rows: softmax * scale", rel_l2(dl2[[1, 5]], sm), 1.9e-03)
 
 
 def test_row_scatter_add(ops):

@@ -1204,3 +1204,25 @@ def test_bench_run_ranks_ends_a_hung_launch_by_its_own_process_group():
     rc, out = bench._run_ranks([sys.executable, "-c", "import time, subprocess, sys; print('started', flush=True); "
                                 "subprocess.Popen([sys.executable, '-c', 'import time; time.sleep(600)']); time.sleep(600)"], dict(os.environ), 3)
     assert rc is None and "started" in out and __import__("time").time() - t0 < 60
+
+
+def test_padded_weight_is_never_stale_for_a_trainable_parameter():
+    """optimizers write through `param.data`, which torch's version counter does not see — a trainable weight is padded
+    per call (SigLIP's fc2, K = 4304), a frozen one is cached and follows `copy_` / `load_state_dict`; `invalidate_padded_weights`
+    covers `.data` writes to frozen weights."""
+    import torch
+    from long_vita_amd import ops
+    w = torch.nn.Parameter(torch.ones(4, 70))
+    a = ops._padded_weight(w, 128)
+    assert a.shape == (4, 128) and float(a[:, :70].min()) == 1.0 and float(a[:, 70:].abs().max()) == 0.0
+    w.data.mul_(3.0)                                              # what Float16Optimizer._copy_main_params_to_model_params does
+    assert float(ops._padded_weight(w, 128)[0, 0]) == 3.0
+    f = torch.nn.Parameter(torch.ones(4, 70), requires_grad=False)
+    b = ops._padded_weight(f, 128)
+    assert ops._padded_weight(f, 128) is b                       # frozen: one copy
+    with torch.no_grad():
+        f.copy_(torch.full((4, 70), 2.0))                         # load_state_dict's write: bumps the version
+    assert float(ops._padded_weight(f, 128)[0, 0]) == 2.0
+    f.data.fill_(5.0)
+    ops.invalidate_padded_weights()
+    assert float(ops._padded_weight(f, 128)[0, 0]) == 5.0
