@@ -1216,6 +1216,18 @@ def main():
             continue
         fn()
         print(name, "ok")
+    # r05: the reference's composite classes over plain-torch leaves (oracle/make_golden_composites.py).  Last: they re-bind names on
+    # the stub modules and re-import reference modules.
+    from . import make_golden_composites as comp
+    for name, fn in [("gptvl_forward", lambda: comp.golden_gptvl_forward(OUT, STATE)),
+                     ("transformer_block", lambda: comp.golden_transformer_block(OUT, STATE)),
+                     ("intern_vit_forward", lambda: comp.golden_intern_vit_forward(OUT, STATE, cpu_as_cuda)),
+                     ("vision_model", lambda: comp.golden_vision_model(OUT, STATE)),
+                     ("forward_step", lambda: comp.golden_forward_step(OUT, STATE))]:
+        if only and name not in only:
+            continue
+        fn()
+        print(name, "ok")
 
 
 if __name__ == "__main__":

@@ -393,7 +393,9 @@ ARGS = types.SimpleNamespace(output_multiplier_scale=None, output_logit_softcapp
 class GPTVLModel(torch.nn.Module):
     """long_vita_megatron.core.models.multimodal.gpt_vl_model.GPTVLModel restated: `__init__` (:73-180 — external_feature_model from
     its provider (:110-113), LanguageModelEmbedding, RotaryEmbedding, TransformerBlock, the ColumnParallelLinear output layer, `unused`)
-    and the training branch of `forward` (:233-416).  Every class it instantiates is looked up under the dotted name the reference
+    and `forward` (:233-416: training and inference branches, incl. the `inference_params` overrides :258-262, :278-283), the three
+    freeze methods (:182-216).  Pinned bit for bit on the reference's own class over plain-torch leaves (tests/golden/gptvl_forward.pt,
+    tests/test_oracle_golden.py).  Every class it instantiates is looked up under the dotted name the reference
     imports it from, i.e. it is whatever the adaptors left there.  transformer_layer_spec = None keeps the r04 shell (vision tests):
     only the external feature model is built."""
 
@@ -428,6 +430,25 @@ class GPTVLModel(torch.nn.Module):
                                     embedding_activation_buffer=None, grad_output_buffer=None)
         self.unused = torch.nn.Parameter(0.01 * torch.ones(config.hidden_size))                                         # :180
 
+    def vision_projector_freeze(self):                                                    # :182-191
+        for name, param in self.named_parameters():
+            if "external_feature_model." in name and ".vit." not in name:
+                param.requires_grad = False
+        return self
+
+    def vision_model_freeze(self):                                                        # :193-202
+        for name, param in self.named_parameters():
+            if "external_feature_model.vit." in name:
+                param.requires_grad = False
+        return self
+
+    def language_model_freeze(self):                                                      # :204-216
+        for name, param in self.named_parameters():
+            if "external_feature_model." in name or name == "unused":
+                continue
+            param.requires_grad = False
+        return self
+
     def compute_language_model_loss(self, labels, logits):
         """megatron.core.models.common.language_module.LanguageModule.compute_language_model_loss."""
         labels = labels.transpose(0, 1).contiguous()                                     # [b s] => [s b]
@@ -440,6 +461,9 @@ class GPTVLModel(torch.nn.Module):
         if decoder_input is not None:
             pass
         elif self.pre_process:
+            if hasattr(inference_params, "external_inputs") and inference_params.external_inputs is not None \
+                    and not inference_params.key_value_memory_dict:                      # :258-262 (first decode step only)
+                external_inputs = inference_params.external_inputs
             if external_inputs:                                                           # :264-272
                 external_feature = self.external_feature_model(**external_inputs)
                 external_feature_dict = {"features": external_feature}
@@ -449,6 +473,10 @@ class GPTVLModel(torch.nn.Module):
                 decoder_input = self.embedding(input_ids=input_ids, position_ids=position_ids, external_feature_dict=external_feature_dict)
             else:
                 decoder_input = self.embedding(input_ids=input_ids, position_ids=position_ids)
+        if hasattr(inference_params, "logit_mask") and inference_params.logit_mask is not None:    # :278-280
+            logit_mask = inference_params.logit_mask
+        if hasattr(inference_params, "use_kv_cache") and not inference_params.use_kv_cache:        # :282-283
+            inference_params = None
         rotary_pos_emb = None
         if self.position_embedding_type == "rope":                                        # :287-295
             rotary_seq_len = self.rotary_pos_emb.get_rotary_seq_len(inference_params, self.decoder, decoder_input, self.config)

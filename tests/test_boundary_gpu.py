@@ -591,6 +591,45 @@ def test_vision_tower_under_the_reference_entry_classes_forward_and_every_gradie
     tol("no-grad path vs autograd path", rel_l2(out2, out), 1e-5)                      # measured 0: the same rounding chain
 
 
+def test_registered_intern_vit_front_end_against_the_references_own_forward(megatron, monkeypatch):
+    """`InternViTModel.forward` of the reference (M/core/models/vision/intern_vit_model.py:190-261, imported and run
+    on CPU in fp32 over a plain-torch block, oracle/make_golden_composites.py -> intern_vit_forward.pt) against the class this package
+    registers on the same dotted name, built with the reference's constructor call and loaded with the same state dict: the input the
+    block receives (conv1 as patchify + GEMM, class token, position rows, [s, b, h]), the output after the same plain-torch block, and
+    the gradients of conv1 / class token / position table.  With and without the class token (position ids 1.. of a table one row longer,
+    class_token kept but frozen)."""
+    from conftest import load_golden
+    from oracle import leaves, make_golden_composites as comp
+    g = load_golden("intern_vit_forward.pt")
+    monkeypatch.setattr(sys.modules["megatron.core.transformer.transformer_block"], "TransformerBlock", leaves.Block)
+    cls = sys.modules["long_vita_megatron.core.models.vision.intern_vit_model"].InternViTModel
+    for c in g["cases"]:
+        cfg = dm.TransformerConfig(hidden_size=c["hidden"], params_dtype=torch.bfloat16)
+        vit = cls(cfg, "spec", add_class_token=c["add_class_token"], patch_dim=c["patch"], img_h=c["img"], img_w=c["img"])
+        assert sorted(vit.state_dict()) == c["state_keys"] and [n for n, _ in vit.named_parameters()] == c["param_names"]
+        assert vit.seq_length == c["seq_length"] and torch.equal(vit.position_ids.cpu(), c["position_ids"])
+        assert bool(vit.class_token.requires_grad) == c["class_token_requires_grad"]
+        vit.decoder = vit.decoder.to(DEV)
+        leaves.init_by_name(vit, seed=11)                                              # the fixture's weights, by parameter name
+        vit = vit.to(torch.bfloat16)
+        seen = {}
+        h = vit.decoder.register_forward_hook(lambda m, a, o: seen.setdefault("x", a[0].detach().clone()))
+        x = comp.vit_case_inputs(c).bfloat16().to(DEV)
+        out = vit(x)
+        h.remove()
+        assert out.shape == c["out"].shape and seen["x"].shape == c["block_input"].shape
+        tol(f"block input ({c['name']})", rel_l2(seen["x"], c["block_input"]), 6e-3)      # bf16 weights / images / output vs fp32
+        tol(f"output ({c['name']})", rel_l2(out, c["out"]), 8e-3)
+        w = torch.linspace(-1, 1, out.numel()).view_as(out).to(DEV)
+        (out.float() * w).sum().backward()
+        for n, p in vit.named_parameters():
+            want = c["grads"][n]
+            if want is None:
+                assert p.grad is None, n
+            elif not n.startswith("decoder."):
+                tol(f"d {n} ({c['name']})", rel_l2(p.grad, want), 2.5e-2)
+
+
 def test_transformer_block_final_norm_recompute_and_loss_run_on_the_library(megatron):
     """(1) `TransformerBlock(config, spec, post_process=True)` builds `final_layernorm` from the module-level name TENorm
     (M/core/transformer/transformer_block.py:201): after the adaptor that name is layers.Norm -> RMSNorm with library forward / backward.
