@@ -12,7 +12,7 @@
 // P reaches dS rounded to bf16 — as in the reference's own chain (scale_mask_softmax hands bf16 probabilities to the backward,
 // M/core/transformer/dot_product_attention.py:186-289); kv64 used the unrounded value there.
 // LDS images: ONE dual-use image per Q tile and per dO tile (slot XOR swz(row), attn_bwd_kv64.hip's header): A reads Q as fragments
-// and dO transposed, B reads dO as fragments and Q transposed — 32 KB of LDS-DMA per 64-row query tile, rings of three.
+// and dO transposed, B reads dO as fragments and Q transposed — 32 KB of LDS-DMA per 64-row query tile, rings of four (r05; three in r04).
 // Pipeline per half u (32 query rows), 16-MFMA groups, one MFMA + its share of the arithmetic per slot:
 //     B: [16 dP MFMAs of half u + 1 || dS(u), k-step 0 (8 pairs, every other slot)]  [16 dK MFMAs of half u || dS(u), k-step 1 under the first 8]
 //     A: [16 dV MFMAs of half u || exp2 of elements 0 .. 15 of S(u + 1)]  [16 S MFMAs of half u + 2 || elements 16 .. 31]  hand-over of P(u + 1)
@@ -23,17 +23,36 @@
 // Timing-only ablations (KVP_ABL, same box, whole backward 8.84 ms): no barriers 8.90, no exp2 8.38, no softmax / dS arithmetic at all 7.9 —
 // the barriers are free, and what the arithmetic costs it costs in power, not in issue slots: 1.25 PFLOP/s executed without it is the
 // chip's ceiling for an LDS-fed MFMA stream on random data (MI355X_MICROARCH.md, DVFS; the forward runs 1.20-1.24).
+//
+// r05 — the schedule across workgroups (what the XCD's L2 sees).  Every workgroup streams the Q / dO tiles its keys are visible to; in r04
+// each of the 32 workgroups resident on an XCD walked its own (head, tile) sequence from its own first tile, the sequences drifted apart by
+// two tiles per workgroup and per head, and the XCD's 4 MB L2 served half of the 21 GB of tile reads (10.2 GB fetched per 16K launch against
+// 0.4 GB of distinct data: rocprofv3 FETCH_SIZE, profiles/r04_attn_bwd16k_pmc.txt).  Now:
+//   * block b = one kv head (b % n_kv_heads: with 8 kv heads one head per XCD) and one PAIR of 128-key blocks of it, (w, NB - 1 - w) in
+//     global key order: under the causal mask the pair sees NB + 1 tile columns whatever w is, so all workgroups are equally long
+//     (16K: 512 workgroups = exactly two rounds of 256 CUs, no triangular tail);
+//   * inside a block the tiles go tile-major with the group's query heads innermost, block w from the LAST query tile DOWN to its
+//     diagonal, block NB - 1 - w from its diagonal UP to the last tile: at global step s every first-phase workgroup of the XCD reads
+//     tile (last - s / G, head s % G) and every second-phase workgroup tile (s / G - 1, head s % G) — two streams per XCD instead of 32.
+// Measured (16K, same box, dK + dV pass alone, best / median of 5): r04 5.20 / 5.45 ms -> 5.13 / 5.29 ms with 0.89 GB fetched per launch
+// (11 x less); the ceiling of ANY locality scheme — timing ablation KVP_ABL = 8, every tile index taken mod 64 so that all reads hit the
+// L2 — is 5.00 / 5.10 ms.  The 25 x re-reads of r04 cost 5 % of the pass, not more: the pass is bound by issue and power
+// (MI355X_MICROARCH.md, DVFS: the fifth back-to-back launch of the same kernel runs 11 % slower than the first), as r04 concluded.
 #include "attn_bwd_args.h"
 #include <stdlib.h>
 
 namespace {
 
 constexpr int D = 128, QT = 64, KWG = 128, ROWB = D * 2, TILEB = QT * ROWB;             // 16 KiB per image of a 64-row query tile
-constexpr int LDS_Q = 0, LDS_DO = 3 * TILEB, LDS_ST = 6 * TILEB, LDS_X = LDS_ST + 3 * 512, LDS_TOTAL = LDS_X + 2 * 2 * 4096;
+constexpr int NRING = 4;                                // Q / dO tile images in LDS: tiles t, t + 1 (read), t + 2 (landed or landing), t + 3 (just issued)
+constexpr int LDS_Q = 0, LDS_DO = NRING * TILEB, LDS_ST = 2 * NRING * TILEB, LDS_X = LDS_ST + NRING * 512, LDS_TOTAL = LDS_X + 2 * 2 * 4096;
 constexpr float LOG2E = 1.44269504088896340736f;
 constexpr int PF_NONE = 0, PF_FRAG = 1, PF_TR = 2;
 // timing-only ablations (WRONG results; never in libvita_hip.so): -DKVP_ABL=1 no barrier between the two trips of a tile, 2 no exp2,
-// 3 no barrier at all, 5 no softmax / dS arithmetic at all (MFMAs + LDS traffic only), 6 = 5 + 3
+// 3 no barrier at all, 5 no softmax / dS arithmetic at all (MFMAs + LDS traffic only), 6 = 5 + 3, 7 every tile read from the SAME
+// addresses (tile 0 of head 0: every LDS-DMA after the first hits the XCD's L2 — the upper bound of what any re-ordering of the
+// workgroups for L2 locality could give — but also the same operand bits in every MFMA: less switching power, higher clock), 8 every tile
+// read from a 64-tile window of head 0 (tile index mod 64: 2 MB of DISTINCT random data that stays in the XCD's 4 MB L2)
 #ifndef KVP_ABL
 #define KVP_ABL 0
 #endif
@@ -46,12 +65,11 @@ typedef __attribute__((address_space(3))) u32x4 lds_u32x4;
 typedef __attribute__((address_space(3))) char lds_char;
 
 struct QTileIt {
-  int hq, c, j, jend;   // query head of the group, query chunk, tile inside the chunk, one past the last tile; hq == G: end
+  int hq, c, j, jlo;    // query head of the group, query chunk, tile inside the chunk, first tile of the chunk the key block reaches
   int diag;             // chunk c is the key block's own chunk
-  const char* qp;       // first Q / dO row of the tile, lse / delta of its first row
+  int stat;             // index of the tile's first row in lse / delta: head * n_q_rows + row
+  const char* qp;       // first Q / dO row of the tile
   const char* dop;
-  const char* lp;
-  const char* dlp;
 };
 
 template <bool ROLE_B>
@@ -61,18 +79,16 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
   const int G = p.n_q_heads / p.n_kv_heads;
   const int kt_per_chunk = p.chunk_len / KWG;
   int bid = blockIdx.x;
-  const int kvh = bid % p.n_kv_heads; bid /= p.n_kv_heads;
-  const int kc = bid / kt_per_chunk;                    // kv chunk (buffer order)
-  const int kti = bid % kt_per_chunk;
-  const int gk = p.kv_gid[kc];
-  const int k_off_wg = kti * KWG;                       // first key of the workgroup inside its chunk
-  const int k_off = k_off_wg + pair * 64;               // this PAIR's first key inside the chunk
-  const int64_t k_row0 = p.kv_row[kc] + k_off;          // its row in the K / V buffers
+  const int kvh = bid % p.n_kv_heads; bid /= p.n_kv_heads;   // bid: the pair (bid, NB - 1 - bid) of key blocks in global key order
+  const int NB = p.n_kv_chunks * kt_per_chunk;
   const float scale_log2e = p.scale_log2e, scale = p.scale;
 
-  // ---- the pair's own keys: A keeps K, B keeps V, as MFMA B operands (key k_off + 32 kb + l31, d = 16 ds + 8 hi .. + 7) ------------------
-  bf16x8 wf[2][8];
-  {
+  // ---- per key block (set by the phase loop below) ---------------------------------------------------------------------------------------
+  int gk = 0, k_off_wg = 0, k_off = 0, j0 = 0, dir = 1;  // gid of the block's chunk, first key of the block / of this PAIR inside the chunk,
+  int64_t k_row0 = 0;                                    // first own-chunk tile that reaches the block, walking direction; row in K / V
+  bf16x8 wf[2][8];                                       // the pair's own keys: A keeps K, B keeps V, as MFMA B operands (key k_off + 32 kb + l31,
+                                                         // d = 16 ds + 8 hi .. + 7), pinned in AGPRs
+  auto load_own_keys = [&]() __attribute__((always_inline)) {
     const bf16_t* wp = ROLE_B ? p.v + (int64_t)kvh * p.v_hs + (k_row0 + l31) * p.v_rs + hi * 8
                               : p.k + (int64_t)kvh * p.k_hs + (k_row0 + l31) * p.k_rs + hi * 8;
     const int64_t rs = ROLE_B ? p.v_rs : p.k_rs;
@@ -80,11 +96,11 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
     for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
       for (int ds = 0; ds < 8; ++ds) wf[kb][ds] = *reinterpret_cast<const bf16x8*>(wp + (int64_t)32 * kb * rs + ds * 16);
-  }
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
+    for (int kb = 0; kb < 2; ++kb)
 #pragma unroll
-    for (int ds = 0; ds < 8; ++ds) asm volatile("" : "+a"(wf[kb][ds]));        // consumed (loads waited for) and pinned in AGPRs here
+      for (int ds = 0; ds < 8; ++ds) asm volatile("" : "+a"(wf[kb][ds]));      // consumed (loads waited for) and pinned in AGPRs here
+  };
 
   // ---- LDS offsets of the dual-use images ----------------------------------------------------------------------------------------------
   auto swz = [](int row) { return ((row & 3) << 2) | ((row >> 2) & 3); };
@@ -110,6 +126,7 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
     off_do[q] = (unsigned)((row * p.do_rs + fs * 8) * 2);
   }
   const unsigned lds_w = lds0 + wave * 4096;
+  const char* qbase = (const char*)(p.q + (int64_t)kvh * p.q_gs);
   auto dma_tile = [&](const QTileIt& t, int slot3) __attribute__((always_inline)) {
     const vita_rsrc_t rq = vita_make_rsrc_uniform(t.qp), rd = vita_make_rsrc_uniform(t.dop);
     unsigned base = lds_w + slot3 * TILEB;
@@ -120,70 +137,59 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
       vita_lds_dma16(rd, off_do[q], base + LDS_DO + q * 1024);
     }
     // 64 lse (wave 0) / 64 delta (wave 1) of the tile's rows: lane -> row
-    if (wave == 0) vita_lds_dma4(vita_make_rsrc_uniform(t.lp), (unsigned)(lane * 4), lds0 + LDS_ST + slot3 * 512);
-    if (wave == 1) vita_lds_dma4(vita_make_rsrc_uniform(t.dlp), (unsigned)(lane * 4), lds0 + LDS_ST + slot3 * 512 + 256);
+    if (wave == 0) vita_lds_dma4(vita_make_rsrc_uniform(p.lse + t.stat), (unsigned)(lane * 4), lds0 + LDS_ST + slot3 * 512);
+    if (wave == 1) vita_lds_dma4(vita_make_rsrc_uniform(p.delta + t.stat), (unsigned)(lane * 4), lds0 + LDS_ST + slot3 * 512 + 256);
   };
 
-  // ---- iteration space: (query head of the group) x (query chunks that see this key block) x (64-row tiles) ---------------------------
+  // ---- iteration space: (query chunks that see the key block) x (64-row tiles) x (query heads of the group, innermost) ------------------
+  // walked upwards (dir = 1: from the block's diagonal to the last tile) or downwards (dir = -1: the reverse sequence)
   const int q_tiles_per_chunk = p.chunk_len / QT;
-  const int j0 = k_off_wg / QT;                          // first tile of the own chunk whose rows reach the workgroup's keys
-  const char* qbase = (const char*)(p.q + (int64_t)kvh * p.q_gs);
-  const char* dobase = (const char*)p.d_o;
-  auto enter = [&](QTileIt& t) __attribute__((always_inline)) {     // position on the first tile of (hq, c ..), or hq == G
-    while (t.hq < G) {
-      while (t.c < p.n_q_chunks) {
-        const int gq = p.q_gid[t.c];
-        if (gq >= gk) {
-          t.diag = gq == gk;
-          t.j = t.diag ? j0 : 0;
-          t.jend = q_tiles_per_chunk;
-          const int64_t row = (int64_t)t.c * p.chunk_len + (int64_t)t.j * QT;
-          const int head = kvh * G + t.hq;
-          t.qp = qbase + ((int64_t)t.hq * p.q_hs + row * p.q_rs) * 2;
-          t.dop = dobase + ((int64_t)head * p.do_hs + row * p.do_rs) * 2;
-          t.lp = (const char*)(p.lse + (int64_t)head * p.n_q_rows + row);
-          t.dlp = (const char*)(p.delta + (int64_t)head * p.n_q_rows + row);
-          return;
-        }
-        ++t.c;
+  // steps of the walk, signed by its direction (set per key block): one query head on, and one tile on while the head wraps around
+  int64_t q_hstep = 0, do_hstep = 0, q_tstep = 0, do_tstep = 0;
+  int st_hstep = 0, st_tstep = 0;
+  auto setptr = [&](QTileIt& t) __attribute__((always_inline)) {    // chunk entry only: everything else is increments
+    const int64_t row = ABL == 7 ? 0 : (ABL == 8 ? (int64_t)(t.j & 63) * QT : (int64_t)t.c * p.chunk_len + (int64_t)t.j * QT);
+    const int hq = ABL == 7 || ABL == 8 ? 0 : t.hq;
+    const int head = kvh * G + hq;
+    t.qp = qbase + ((int64_t)hq * p.q_hs + row * p.q_rs) * 2;
+    t.dop = (const char*)p.d_o + ((int64_t)head * p.do_hs + row * p.do_rs) * 2;
+    t.stat = head * p.n_q_rows + (int)row;
+  };
+  auto enter = [&](QTileIt& t) __attribute__((always_inline)) {     // from chunk t.c on (in direction dir): the first tile of the next visible chunk
+    while (t.c >= 0 && t.c < p.n_q_chunks) {
+      const int gq = p.q_gid[t.c];
+      if (gq >= gk) {
+        t.diag = gq == gk;
+        t.jlo = t.diag ? j0 : 0;
+        t.j = dir > 0 ? t.jlo : q_tiles_per_chunk - 1;
+        t.hq = dir > 0 ? 0 : G - 1;
+        setptr(t);
+        return;
       }
-      ++t.hq; t.c = 0;
+      t.c += dir;
     }
   };
-  const int q_tile_bytes = (int)(p.q_rs * 2 * QT), do_tile_bytes = (int)(p.do_rs * 2 * QT);
   auto advance = [&](QTileIt& t) __attribute__((always_inline)) {
-    t.qp += q_tile_bytes; t.dop += do_tile_bytes; t.lp += QT * 4; t.dlp += QT * 4;
-    if (++t.j == t.jend) { ++t.c; enter(t); }
-  };
-  int n_tiles = 0;                                       // 0, or >= 2 G: the own chunk contributes at least two tiles
-  for (int c = 0; c < p.n_q_chunks; ++c) {
-    const int gq = p.q_gid[c];
-    n_tiles += gq > gk ? q_tiles_per_chunk : (gq == gk ? q_tiles_per_chunk - j0 : 0);
-  }
-  n_tiles *= G;
-  bf16_t* const out = ROLE_B ? p.dk + (int64_t)kvh * p.dk_hs : p.dv + (int64_t)kvh * p.dv_hs;
-  const int64_t out_rs = ROLE_B ? p.dk_rs : p.dv_rs;
-  if (n_tiles == 0) {                                    // context parallelism: a key chunk none of the local queries can see
-    const u32x2 z = {0u, 0u};
-#pragma unroll
-    for (int kb = 0; kb < 2; ++kb) {
-      bf16_t* op = out + (k_row0 + 32 * kb + l31) * out_rs;
-#pragma unroll
-      for (int i = 0; i < 16; ++i) *reinterpret_cast<u32x2*>(op + 8 * i + 4 * hi) = z;
+    t.hq += dir;
+    if (t.hq >= 0 && t.hq < G) {                          // the next head of the same tile (G - 1 times out of G)
+      if (ABL != 7 && ABL != 8) { t.qp += q_hstep; t.dop += do_hstep; t.stat += st_hstep; }
+      return;
     }
-    return;
-  }
+    t.hq = dir > 0 ? 0 : G - 1;
+    t.j += dir;
+    if (t.j >= t.jlo && t.j < q_tiles_per_chunk) {
+      if (ABL == 8) setptr(t);
+      else if (ABL != 7) { t.qp += q_tstep; t.dop += do_tstep; t.stat += st_tstep; }
+      return;
+    }
+    t.c += dir;
+    enter(t);
+  };
+  // the causal mask of a tile: its first row inside the chunk when rows of the tile precede keys of the workgroup, else -1
+  auto mask_row = [&](const QTileIt& t) __attribute__((always_inline)) { return t.diag && t.j * QT < k_off_wg + KWG ? t.j * QT : -1; };
 
   // ---- state -------------------------------------------------------------------------------------------------------------------------
-  f32x16 o[2][4];                                        // A: dV^T, B: dK^T  [kb][db] (AGPRs)
-#pragma unroll
-  for (int kb = 0; kb < 2; ++kb)
-#pragma unroll
-    for (int db = 0; db < 4; ++db) {
-#pragma unroll
-      for (int r = 0; r < 16; ++r) o[kb][db][r] = 0.f;
-      asm volatile("" : "+a"(o[kb][db]));
-    }
+  f32x16 o[2][4];                                        // A: dV^T, B: dK^T  [kb][db] (AGPRs); zeroed per key block
   f32x16 xb[2][2];                                       // A: S, B: dP of a half [parity][kb]: row 32 qh + (r & 3) + 8 (r >> 2) + 4 hi
   unsigned pk[2][2][2][4];                               // A: packed P, B: packed dS  [parity][kb][k-step t'][4 dwords]
   u32x4 pin[2][2];                                       // B: the pair's packed P of the current half, as A wrote it  [kb][t']
@@ -205,7 +211,7 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
   auto load_stat = [&](unsigned st, int qh) __attribute__((always_inline)) { stat_fetch(st, qh); stat_finish(); };
   // A: P of pair e (kb = e >> 3, registers 2 (e & 7), +1) of buffer `par`, in place
   auto exp_pair = [&](int par, int e) __attribute__((always_inline)) {
-    if (ABL == 2 || ABL >= 5) return;
+    if (ABL == 2 || ABL == 5 || ABL == 6) return;
     const int kb = e >> 3, r = 2 * (e & 7);
     xb[par][kb][r] = __builtin_amdgcn_exp2f(fmaf(xb[par][kb][r], scale_log2e, -rstat[r]));
     xb[par][kb][r + 1] = __builtin_amdgcn_exp2f(fmaf(xb[par][kb][r + 1], scale_log2e, -rstat[r + 1]));
@@ -213,19 +219,19 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
   // A: P of ONE element (el = 16 kb + r) — one transcendental per MFMA slot: two in one slot (r04 first form) took 40 cycles of issue
   // against the MFMA's 32 and left the next slot half empty (timing ablations: the softmax arithmetic cost 17 % of the kernel)
   auto exp_one = [&](int par, int el) __attribute__((always_inline)) {
-    if (ABL == 2 || ABL >= 5) return;
+    if (ABL == 2 || ABL == 5 || ABL == 6) return;
     const int kb = el >> 4, r = el & 15;
     xb[par][kb][r] = __builtin_amdgcn_exp2f(fmaf(xb[par][kb][r], scale_log2e, -rstat[r]));
   };
   auto pack_pair = [&](int par, int e) __attribute__((always_inline)) {          // A: bf16 pair of P
     const int kb = e >> 3, pr = e & 7, r = 2 * pr;
-    if (ABL >= 5) { pk[par][kb][pr >> 2][pr & 3] = __builtin_bit_cast(unsigned, xb[par][kb][r]); return; }
+    if (ABL == 5 || ABL == 6) { pk[par][kb][pr >> 2][pr & 3] = __builtin_bit_cast(unsigned, xb[par][kb][r]); return; }
     pk[par][kb][pr >> 2][pr & 3] = pack_bf16x2(xb[par][kb][r], xb[par][kb][r + 1]);
     asm volatile("" :: "v"(pk[par][kb][pr >> 2][pr & 3]));                       // computed HERE (no sinking past the phase)
   };
   auto ds_pair = [&](int par, int e) __attribute__((always_inline)) {            // B: dS = P o (dP scale - delta scale), packed
     const int kb = e >> 3, pr = e & 7, r = 2 * pr;
-    if (ABL >= 5) { pk[par][kb][pr >> 2][pr & 3] = pin[kb][pr >> 2][pr & 3] ^ __builtin_bit_cast(unsigned, xb[par][kb][r]); return; }
+    if (ABL == 5 || ABL == 6) { pk[par][kb][pr >> 2][pr & 3] = pin[kb][pr >> 2][pr & 3] ^ __builtin_bit_cast(unsigned, xb[par][kb][r]); return; }
     const unsigned w = pin[kb][pr >> 2][pr & 3];
     const float a = bf16lo_to_f32(w) * fmaf(xb[par][kb][r], scale, -rstat[r]);
     const float b = bf16hi_to_f32(w) * fmaf(xb[par][kb][r + 1], scale, -rstat[r + 1]);
@@ -337,7 +343,6 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
     }
     if (!ROLE_B && fill) pack_pair(par ^ 1, 7);
   };
-  auto needs_mask = [&](const QTileIt& t) __attribute__((always_inline)) { return t.diag && t.j * QT < k_off_wg + KWG; };
   // VALU result -> inline-asm MFMA operand: wait states the compiler does not know are needed, tied to the operands
   auto settle = [&](int par) __attribute__((always_inline)) {
     asm volatile("s_nop 4" : "+v"(pk[par][0][0][0]), "+v"(pk[par][0][0][1]), "+v"(pk[par][0][0][2]), "+v"(pk[par][0][0][3]),
@@ -349,45 +354,30 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
     __builtin_amdgcn_s_barrier();
   };
 
-  // ---- prologue: tiles 0 and 1 -> LDS; X of half 0; A: P(0) packed and handed over ---------------------------------------------------
-  QTileIt cur;
-  cur.hq = 0; cur.c = 0; cur.j = 0; cur.jend = 0; cur.diag = 0; cur.qp = qbase; cur.dop = dobase; cur.lp = (const char*)p.lse;
-  cur.dlp = (const char*)p.delta;
-  enter(cur);
-  QTileIt nx1 = cur;
-  advance(nx1);                                          // n_tiles >= 2
-  QTileIt nx2 = nx1;
-  if (n_tiles > 2) advance(nx2);
-  dma_tile(cur, 0); dma_tile(nx1, 1);
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  __syncthreads();
+  // ---- the tile pipeline's cursor: ONE full iterator (two tiles ahead of the arithmetic: it feeds the LDS-DMA) + the mask rows of the
+  // tiles in flight ------------------------------------------------------------------------------------------------------------------------
+  QTileIt it;
+  int m_cur = -1, m_nx1 = -1, m_nx2 = -1;                // mask_row of tile t / t + 1 / t + 2
+  int s3 = 0, s3n = 1, s3nn = 2, s3n3 = 3;               // ring slots of tiles t, t+1, t+2, t+3
   const unsigned IMG_X = ROLE_B ? LDS_DO : LDS_Q;        // the image this role reads as fragments (dO for dP, Q for S)
   const unsigned IMG_G = ROLE_B ? LDS_Q : LDS_DO;        // ... and transposed (Q^T for dK, dO^T for dV)
-  // B: dP(0) -> buffers 0, and under it the first fragments of trip 0's x_group (dO rows 32 ..) + delta of half 0
-  x_group(1, lds0 + IMG_X, 0, false, false, ROLE_B ? PF_FRAG : PF_NONE, lds0 + IMG_X, 1, ROLE_B, lds0 + LDS_ST, 0);
-  if (!ROLE_B) {
-    if (needs_mask(cur)) mask_half(0, cur.j * QT);
-    load_stat(lds0 + LDS_ST, 0);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) exp_pair(0, e);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) pack_pair(0, e);
-    hand_over(0);
-    settle(0);
-    // A runs two halves ahead: S(1) -> buffers 1 (tile 0 always has both halves); under it the first dO^T fragments of trip 0's g_group
-    // and the lse of half 1
-    x_group(0, lds0 + IMG_X, 1, false, false, PF_TR, lds0 + IMG_G, 0, true, lds0 + LDS_ST, 1);
-    if (needs_mask(cur)) mask_half(1, cur.j * QT + 32);
-  }
-  pair_barrier();
-
-  // ---- main loop: one tile = two trips (half qh = buffer parity qh) ------------------------------------------------------------------------
+  // ---- one tile = two trips (half qh = buffer parity qh) ------------------------------------------------------------------------
   // Every 16-MFMA group starts from fragments its predecessor read at slot 12 (fr_pre) and the statistics of a half are fetched a trip
   // ahead (stat_raw), so that neither the group after a barrier nor the second group of a trip waits for an LDS round trip before its
   // first MFMA (r04 first form: 11 ds_reads and an s_waitcnt between s_barrier and the first MFMA of every trip).
-  int s3 = 0, s3n = 1, s3nn = 2;                         // ring slots of tiles t, t+1, t+2
-  auto iteration = [&](const bool has1, const bool has2) __attribute__((always_inline)) {
-    if (has2) dma_tile(nx2, s3nn);                       // that slot held tile t-1 (last read before the previous tile barrier)
+  // The LDS-DMA of tile t + 3 is issued at the top of tile t and has to have LANDED at the end of tile t + 1 (tile t + 2 is read from the
+  // start of tile t + 1 on: A runs two halves ahead): two tile times, ~4 us.  r04 kept a ring of three and waited `vmcnt(0)` at the end
+  // of the tile that issued the DMA — one tile time, ~2 us.  Same-box A / B of the two rings: equal within the noise (5.09 vs 5.12 ms);
+  // the longer ring is kept for the context-parallel case, where a tile of a remote chunk may come from further away.
+  auto iteration = [&](const bool has1, const bool has3) __attribute__((always_inline)) {
+    int m_nx3 = -1;
+    if (has3) dma_tile(it, s3n3);                        // tile t + 3 -> the slot that held tile t - 1 (last read before the previous tile barrier)
+    // the cursor's own step (compares, 64-bit adds, two branches: ~15 scalar instructions, more at a chunk boundary) goes BEHIND the first
+    // 16-MFMA group of the trip, where the matrix pipe is still draining: at the top of the trip — straight after the barrier, in all four
+    // waves at once — it sat on the critical path of every tile (r05 first form: + 5 % SQ_WAVE_CYCLES)
+    auto step_cursor = [&]() __attribute__((always_inline)) {
+      if (has3) { m_nx3 = mask_row(it); advance(it); }
+    };
     const unsigned x_cur = lds0 + IMG_X + s3 * TILEB, x_nxt = lds0 + IMG_X + s3n * TILEB;
     const unsigned g_cur = lds0 + IMG_G + s3 * TILEB, g_nxt = lds0 + IMG_G + s3n * TILEB;
     const unsigned st_cur = lds0 + LDS_ST + s3 * 512, st_nxt = lds0 + LDS_ST + s3n * 512;
@@ -396,12 +386,14 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
       take_over(0);                                      // P(u), written by A before the last barrier
       stat_finish();                                     // delta of half u (fetched under the previous trip's dK group)
       x_group(0, x_cur, 1, true, true, PF_TR, g_cur, 0, false, 0, 0);                              // dP(u + 1)  ||  dS(u)
+      step_cursor();
       settle(0);
       g_group(0, g_cur, 0, true, true, has1 ? PF_FRAG : PF_TR, has1 ? x_nxt : g_cur, has1 ? 0 : 1, true, st_cur, 1);   // dK^T += Q^T dS(u)  ||  dS(u), k-step 1
     } else {
       // A holds P(u) packed in pk[0] and the raw (masked) S(u + 1) in buffers 1
       stat_finish();                                     // lse of half u + 1
       g_group(0, g_cur, 0, true, true, has1 ? PF_FRAG : PF_TR, has1 ? x_nxt : g_cur, has1 ? 0 : 1, false, 0, 0);   // dV^T += dO^T P(u) || exp2 0 .. 7 of S(u + 1)
+      step_cursor();
       if (has1) {
         x_group(1, x_nxt, 0, true, true, PF_TR, g_cur, 1, true, st_nxt, 0);                      // S(u + 2) -> buffers 0  ||  pairs 8 .. 15 of S(u + 1)
       } else {
@@ -411,7 +403,7 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
         for (int e = 8; e < 16; ++e) pack_pair(1, e);
       }
       hand_over(1);                                      // P(u + 1) -> the partner, before the barrier that ends this trip
-      if (has1 && needs_mask(nx1)) mask_half(0, nx1.j * QT);                                       // wave-uniform, diagonal tiles only
+      if (has1 && m_nx1 >= 0) mask_half(0, m_nx1);                                       // wave-uniform, diagonal tiles only
     }
     if (ABL != 1) pair_barrier();
     // ---- trip 1: half u = (tile t, rows 32 ..) in buffers 1; u + 1, u + 2 = the two halves of tile t + 1 if has1 ---------------------------
@@ -432,34 +424,131 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
       if (has1) {
         x_group(0, x_nxt, 1, true, true, PF_TR, g_nxt, 0, true, st_nxt, 1);                      // S(u + 2) -> buffers 1; next: trip 0 of tile t + 1
         hand_over(0);
-        if (needs_mask(nx1)) mask_half(1, nx1.j * QT + 32);
+        if (m_nx1 >= 0) mask_half(1, m_nx1 + 32);
       }
     }
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    // tile t + 2 has landed (every wave waits for ITS pieces, then the barrier): all but the pieces issued at the top of this tile —
+    // 8 per wave, + 1 (lse / delta) in waves 0 and 1
+    if (has3) {
+      if (wave < 2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
     if (ABL != 3 && ABL != 6) __syncthreads();
-    cur = nx1; nx1 = nx2;
-    if (has2) advance(nx2);
-    const int tmp = s3; s3 = s3n; s3n = s3nn; s3nn = tmp;
+    m_cur = m_nx1; m_nx1 = m_nx2; m_nx2 = m_nx3;
+    const int tmp = s3; s3 = s3n; s3n = s3nn; s3nn = s3n3; s3n3 = tmp;
   };
-  for (int t = 0; t + 2 < n_tiles; ++t) iteration(true, true);
-  iteration(true, false);
-  iteration(false, false);
 
-  // ---- epilogue: dK / dV [key][d] -----------------------------------------------------------------------------------------------------------
-  asm volatile("s_nop 15\n\ts_nop 15" : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[0][2]), "+a"(o[0][3]), "+a"(o[1][0]), "+a"(o[1][1]),
-               "+a"(o[1][2]), "+a"(o[1][3]));
+  // ---- the two key blocks of the pair: global block `bid` walked DOWN from the last query tile, block NB - 1 - bid walked UP to it ----------
+  // (Measured null, same box: starting the 32 workgroups of an XCD 300 .. 4200 cycles apart, so that one of them misses and the others hit
+  // instead of 32 hits-under-miss on the same lines, changes nothing: 5.13 - 5.25 ms at every spacing.)
+#pragma nounroll
+  for (int phase = 0; phase < 2; ++phase) {
+    const int gb = phase == 0 ? bid : NB - 1 - bid;      // block index in global key order
+    if (phase == 1 && gb <= bid) break;                  // NB odd: the middle block has no partner
+    dir = phase == 0 ? -1 : 1;
+    q_hstep = dir * p.q_hs * 2; do_hstep = dir * p.do_hs * 2; st_hstep = dir * p.n_q_rows;
+    q_tstep = dir * ((int64_t)QT * p.q_rs - (G - 1) * p.q_hs) * 2;
+    do_tstep = dir * ((int64_t)QT * p.do_rs - (G - 1) * p.do_hs) * 2;
+    st_tstep = dir * (QT - (G - 1) * p.n_q_rows);
+    int kc = 0;                                          // the chunk (buffer order) whose gid has rank gb / kt_per_chunk
+    for (int c = 0; c < p.n_kv_chunks; ++c) {
+      int rank = 0;
+      for (int e = 0; e < p.n_kv_chunks; ++e) rank += p.kv_gid[e] < p.kv_gid[c];
+      if (rank == gb / kt_per_chunk) kc = c;
+    }
+    gk = p.kv_gid[kc];
+    k_off_wg = (gb % kt_per_chunk) * KWG;                // first key of the block inside its chunk
+    k_off = k_off_wg + pair * 64;                        // this PAIR's first key inside the chunk
+    k_row0 = p.kv_row[kc] + k_off;                       // its row in the K / V buffers
+    j0 = k_off_wg / QT;                                  // first tile of the own chunk whose rows reach the block's keys
+    int n_tiles = 0;                                     // 0, or >= 2 G: the own chunk contributes at least two tiles
+    for (int c = 0; c < p.n_q_chunks; ++c) {
+      const int gq = p.q_gid[c];
+      n_tiles += gq > gk ? q_tiles_per_chunk : (gq == gk ? q_tiles_per_chunk - j0 : 0);
+    }
+    n_tiles *= G;
+    bf16_t* const out = ROLE_B ? p.dk + (int64_t)kvh * p.dk_hs : p.dv + (int64_t)kvh * p.dv_hs;
+    const int64_t out_rs = ROLE_B ? p.dk_rs : p.dv_rs;
+    if (n_tiles == 0) {                                  // context parallelism: a key chunk none of the local queries can see
+      const u32x2 z = {0u, 0u};
 #pragma unroll
-  for (int kb = 0; kb < 2; ++kb) {
-    bf16_t* op = out + (k_row0 + 32 * kb + l31) * out_rs;
+      for (int kb = 0; kb < 2; ++kb) {
+        bf16_t* op = out + (k_row0 + 32 * kb + l31) * out_rs;
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int d = 32 * db + 8 * rg + 4 * hi;
-        const u32x2 w = {pack_bf16x2(o[kb][db][rg * 4 + 0], o[kb][db][rg * 4 + 1]),
-                         pack_bf16x2(o[kb][db][rg * 4 + 2], o[kb][db][rg * 4 + 3])};
-        *reinterpret_cast<u32x2*>(op + d) = w;
+        for (int i = 0; i < 16; ++i) *reinterpret_cast<u32x2*>(op + 8 * i + 4 * hi) = z;
       }
+      continue;
+    }
+    load_own_keys();
+#pragma unroll
+    for (int kb = 0; kb < 2; ++kb)
+#pragma unroll
+      for (int db = 0; db < 4; ++db) {
+#pragma unroll
+        for (int r = 0; r < 16; ++r) o[kb][db][r] = 0.f;
+        asm volatile("" : "+a"(o[kb][db]));
+      }
+
+    // ---- prologue: tiles 0 and 1 -> LDS; X of half 0; A: P(0) packed and handed over -------------------------------------------------
+    it.hq = 0; it.c = dir > 0 ? 0 : p.n_q_chunks - 1; it.j = 0; it.jlo = 0; it.diag = 0; it.stat = 0; it.qp = qbase; it.dop = qbase;
+    enter(it);
+    s3 = 0; s3n = 1; s3nn = 2; s3n3 = 3;
+    m_cur = mask_row(it); dma_tile(it, 0); advance(it);
+    m_nx1 = mask_row(it); dma_tile(it, 1); advance(it);  // n_tiles >= 2
+    m_nx2 = -1;
+    if (n_tiles > 2) {                                   // tile 2 stays in flight under the prologue; `it` then stands on tile 3 (or past the end)
+      m_nx2 = mask_row(it); dma_tile(it, 2); advance(it);
+      if (wave < 2) asm volatile("s_waitcnt vmcnt(9)" ::: "memory");
+      else asm volatile("s_waitcnt vmcnt(8)" ::: "memory");
+    } else {
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    }
+    __syncthreads();
+    // B: dP(0) -> buffers 0, and under it the first fragments of trip 0's x_group (dO rows 32 ..) + delta of half 0
+    x_group(1, lds0 + IMG_X, 0, false, false, ROLE_B ? PF_FRAG : PF_NONE, lds0 + IMG_X, 1, ROLE_B, lds0 + LDS_ST, 0);
+    if (!ROLE_B) {
+      if (m_cur >= 0) mask_half(0, m_cur);
+      load_stat(lds0 + LDS_ST, 0);
+  #pragma unroll
+      for (int e = 0; e < 16; ++e) exp_pair(0, e);
+  #pragma unroll
+      for (int e = 0; e < 16; ++e) pack_pair(0, e);
+      hand_over(0);
+      settle(0);
+      // A runs two halves ahead: S(1) -> buffers 1 (tile 0 always has both halves); under it the first dO^T fragments of trip 0's g_group
+      // and the lse of half 1
+      x_group(0, lds0 + IMG_X, 1, false, false, PF_TR, lds0 + IMG_G, 0, true, lds0 + LDS_ST, 1);
+      if (m_cur >= 0) mask_half(1, m_cur + 32);
+    }
+    pair_barrier();
+
+
+    int t = 0;
+    for (; t + 3 < n_tiles; ++t) iteration(true, true);
+    for (; t + 1 < n_tiles; ++t) iteration(true, false);   // the last one or two tiles that still have a successor
+    iteration(false, false);
+
+    // ---- epilogue: dK / dV [key][d] -----------------------------------------------------------------------------------------------------------
+    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(o[0][0]), "+a"(o[0][1]), "+a"(o[0][2]), "+a"(o[0][3]), "+a"(o[1][0]), "+a"(o[1][1]),
+                 "+a"(o[1][2]), "+a"(o[1][3]));
+  #pragma unroll
+    for (int kb = 0; kb < 2; ++kb) {
+      bf16_t* op = out + (k_row0 + 32 * kb + l31) * out_rs;
+  #pragma unroll
+      for (int db = 0; db < 4; ++db)
+  #pragma unroll
+        for (int rg = 0; rg < 4; ++rg) {
+          const int d = 32 * db + 8 * rg + 4 * hi;
+          const u32x2 w = {pack_bf16x2(o[kb][db][rg * 4 + 0], o[kb][db][rg * 4 + 1]),
+                           pack_bf16x2(o[kb][db][rg * 4 + 2], o[kb][db][rg * 4 + 3])};
+          *reinterpret_cast<u32x2*>(op + d) = w;
+        }
+    }
+    // the counted `vmcnt` waits of the next key block assume that nothing but its own LDS-DMA is in flight: drain the stores above
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                                     // the LDS images and the hand-over buffers are free for the next key block
   }
 }
 
@@ -489,7 +578,8 @@ int vita_attn_bwd_kvp_launch(const BwdArgs& a, hipStream_t st) {
   vita_device_once(attr_set, [&] {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_kvp_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS_TOTAL);
   });
-  const int64_t n = (int64_t)a.n_kv_heads * a.n_kv_chunks * (a.chunk_len / KWG);
+  const int64_t nb = (int64_t)a.n_kv_chunks * (a.chunk_len / KWG);         // 128-key blocks per kv head; one workgroup per PAIR of them
+  const int64_t n = (int64_t)a.n_kv_heads * ((nb + 1) / 2);
   if (n > 0x7fffffff) return VITA_ERR_UNSUPPORTED;
   hipLaunchKernelGGL(attn_bwd_kvp_kernel, dim3((unsigned)n), dim3(256), LDS_TOTAL, st, a);
   return vita_check_launch();

@@ -8,6 +8,12 @@ S, Hq, Hkv, D = 16384, 40, 8, 128
 q = torch.randn(1, S, Hq, D, device="cuda").bfloat16(); k = torch.randn(1, S, Hkv, D, device="cuda").bfloat16(); v = torch.randn(1, S, Hkv, D, device="cuda").bfloat16()
 o, lse = ops.flash_attn(q, k, v, causal=True, return_lse=True)
 d_o = torch.randn_like(o); dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+if os.environ.get("ABL_PERIODIC") == "1":        # the DATA of the KVP_ABL = 8 ablation at the real addresses: every head = head 0, rows repeat with period 4096
+    q = q[:, :4096, :1].repeat(1, S // 4096, Hq, 1).contiguous(); d_o = d_o[:, :4096, :1].repeat(1, S // 4096, Hq, 1).contiguous()
+    lse = lse[:, :1, :4096].repeat(1, Hq, S // 4096).contiguous()
+if os.environ.get("ABL_HEADMAJOR") == "1":       # the same values, Q and dO stored head-major ([heads, rows, d]: a tile = 16 KB contiguous) behind strided views
+    q = q.transpose(1, 2).contiguous().transpose(1, 2); d_o = d_o.transpose(1, 2).contiguous().transpose(1, 2)
+    dq = torch.empty_like(q)
 os.environ["VITA_ATTN_BWD_ONLY"] = "dkv"
 f = lambda: ops.flash_attn_bwd(q, k, v, o, d_o, lse, dq5=dq, dk=dk, dv=dv)
 f(); torch.cuda.synchronize()
