@@ -13,7 +13,7 @@
             `--recompute-granularity full --recompute-method block --recompute-num-layers N`), wall-clock.
 
     python tools/bench_config5.py rank [step [N]]
-Writes JSON lines to gpurun_out/r04_config5.jsonl."""
+Writes JSON lines to gpurun_out/r05_config5.jsonl."""
 import json
 import os
 import sys
@@ -28,7 +28,7 @@ from long_vita_amd import gpt_vl_model, lib, ops, training  # noqa: E402
 DEV = "cuda:0"
 OUT = os.path.join(ROOT, "gpurun_out")
 os.makedirs(OUT, exist_ok=True)
-LOG = open(os.path.join(OUT, "r04_config5.jsonl"), "a")
+LOG = open(os.path.join(OUT, "r05_config5.jsonl"), "a")
 lib.load(allow_build=False)
 
 
