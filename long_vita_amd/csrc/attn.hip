@@ -590,6 +590,8 @@ extern "C" int vita_flash_attn_fwd(const vita_attn_params* p, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   // d = 128 causal with whole 256-row / 64-key tiles: the 4 x 64-row in-wave-pipelined kernel (attn64.hip)
   if (vita_attn64_eligible(a, p->head_dim, p->causal != 0)) return vita_attn64_launch(a, nblocks, st);
+  // d = 64 non-causal (the vision towers): the same structure at head size 64, ragged rows / keys (attn64v.hip)
+  if (vita_attn64v_eligible(a, p->head_dim, p->causal != 0)) return vita_attn64v_launch(a, st);
   if (p->head_dim == 128) return p->causal ? launch_attn<128, true>(a, nblocks, st) : launch_attn<128, false>(a, nblocks, st);
   return p->causal ? launch_attn<64, true>(a, nblocks, st) : launch_attn<64, false>(a, nblocks, st);
 }

@@ -27,3 +27,6 @@ struct AttnArgs {
 // attn64.hip: true when the geometry qualifies (head_dim 128, causal, no packed segments, chunk_len % 256 == 0, whole chunks)
 bool vita_attn64_eligible(const AttnArgs& a, int head_dim, bool causal);
 int vita_attn64_launch(const AttnArgs& a, int64_t nblocks, hipStream_t st);
+// attn64v.hip (r05): head_dim 64, non-causal, one chunk, ragged rows / keys, any batch — the vision towers' attention
+bool vita_attn64v_eligible(const AttnArgs& a, int head_dim, bool causal);
+int vita_attn64v_launch(const AttnArgs& a, hipStream_t st);

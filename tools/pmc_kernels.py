@@ -7,6 +7,15 @@ import torch
 from long_vita_amd import ops
 DEV = "cuda"
 S = int(os.environ.get("PMC_S", "32768"))
+if os.environ.get("PMC_VIT", "0") != "0":            # the ViT's attention: 253 frames x 1025 tokens, 16 heads x 64, non-causal
+    B = int(os.environ.get("PMC_VIT_FRAMES", "253"))
+    q, k, v = (torch.randn(B, 1025, 16, 64, device=DEV).bfloat16() for _ in range(3))
+    o = torch.empty_like(q)
+    for _ in range(3):
+        ops.flash_attn(q, k, v, causal=False, out=o)
+    torch.cuda.synchronize()
+    print("done")
+    sys.exit(0)
 q = torch.randn(1, S, 40, 128, device=DEV).bfloat16(); k = torch.randn(1, S, 8, 128, device=DEV).bfloat16()
 v = torch.randn(1, S, 8, 128, device=DEV).bfloat16(); o = torch.empty_like(q)
 do_gemm = os.environ.get("PMC_GEMM", "1") != "0"

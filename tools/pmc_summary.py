@@ -9,6 +9,7 @@ def main(root):
             elif "attn_bwd_dq64" in k: k = "attn_bwd_dq64 (dQ)"
             elif "attn_delta" in k: k = "attn_delta (pre-pass)"
             elif "attn_bwd" in k: k = k.split("::")[-1].split("(")[0][:60]
+            elif "flash_fwd64v" in k: k = "flash_fwd64v (d = 64, non-causal)"
             elif "flash_fwd64" in k: k = "flash_fwd64"
             elif "flash_fwd" in k: k = "flash_fwd<" + ("128" if "128" in k else "64") + ">"
             elif "gemm_bf16" in k: k = "gemm_bf16<" + k.split("<")[1].split(">")[0] + ">"
