@@ -12,7 +12,13 @@
   step      one whole 128K training step on one GPU (TP = CP = 1, 48 layers, 512 answer tokens, logits-masked head,
             `--recompute-granularity full --recompute-method block --recompute-num-layers N`), wall-clock.
 
-    python tools/bench_config5.py rank [step [N]]
+  rankstep  (r05) the WHOLE training step of ONE emulated rank (tp 0 of 2, cp 1 of 4): embedding, 48 TP-halved layers at S_l = 32768 with the
+            CP = 4 chunk tables against 131072 gathered keys, `--recompute-num-layers N`, final norm, vocab-parallel head, loss — every
+            kernel the real rank would run, with LOCAL stand-ins for the collectives (all-gather = this rank's message copied into every
+            slot, reduce-scatter = this rank's slice, all-reduce = identity: the bytes move inside the GPU, nothing waits for a peer), so
+            the figure is the rank's compute time with zero exposed communication — to be put beside the modelled one.
+
+    python tools/bench_config5.py rank [step [N]] [rankstep [N]]
 Writes JSON lines to gpurun_out/r05_config5.jsonl."""
 import json
 import os
@@ -163,8 +169,69 @@ def bench_step(n_rec):
          peak_mem_gb=torch.cuda.max_memory_allocated() / 2 ** 30)
 
 
+def bench_rankstep(n_rec, tp=2, cp=4, tp_rank=0, cp_rank=1):
+    import types
+    import torch.distributed as dist
+    from long_vita_amd import parallel_state as mpu, tensor_parallel as tpar
+
+    class Work:
+        def wait(self):
+            return True
+
+    def group(n, r):
+        return types.SimpleNamespace(size=n, rank=r)
+
+    def all_gather_into_tensor(out, inp, group=None, async_op=False):
+        flat = out.view(group.size, -1)
+        for q in range(group.size):
+            flat[q].copy_(inp.reshape(-1))
+        return Work() if async_op else None
+
+    def reduce_scatter_tensor(out, inp, group=None, async_op=False, op=None):
+        out.view(-1).copy_(inp.view(group.size, -1)[group.rank])
+        return Work() if async_op else None
+
+    def all_reduce(t, group=None, op=None, async_op=False):
+        return Work() if async_op else None
+
+    dist.all_gather_into_tensor, dist.reduce_scatter_tensor, dist.all_reduce = all_gather_into_tensor, reduce_scatter_tensor, all_reduce
+    full_cfg = gpt_vl_model.GPTConfig()
+    full = gpt_vl_model.GPTVLModel.random_init(full_cfg, seed=1, device=DEV)
+    shard, cfg_l = tpar.shard_llm_params(full.p, full_cfg, tp, tp_rank)
+    del full
+    torch.cuda.empty_cache()
+    model = gpt_vl_model.GPTVLModel(cfg_l, shard)
+    mpu.set_context_parallel_state(cp, cp_rank, group(cp, cp_rank))
+    mpu.set_tensor_parallel_state(tp, tp_rank, group(tp, tp_rank))
+    g = torch.Generator(device=DEV).manual_seed(2)
+    S, ans = 131072, 512
+    tokens = torch.randint(0, 151643, (1, S), generator=g, device=DEV)
+    labels = torch.roll(tokens, -1, 1)
+    loss_mask = torch.zeros(1, S, device=DEV)
+    loss_mask[0, S - ans:] = 1
+    step = training.TrainStep(model, recompute_num_layers=n_rec)
+    times = []
+    for i in range(3):
+        torch.cuda.synchronize()
+        if i == 1:
+            torch.cuda.reset_peak_memory_stats()
+        t0 = time.perf_counter()
+        loss, grads = step.forward_backward(tokens, labels, loss_mask)
+        torch.cuda.synchronize()
+        times.append(time.perf_counter() - t0)
+        del grads
+    emit(kind="cfg5_rank_step", what=f"the whole training step of one emulated rank (tp {tp_rank} of {tp}, cp {cp_rank} of {cp}): 48 layers, S = {S} "
+         f"(S_l = {S // cp}), recompute block = {n_rec} layers, collectives replaced by local copies (no peer, nothing exposed)",
+         recompute_num_layers=n_rec, s_per_step=min(times[1:]), s_per_step_all=times, loss=float(loss),
+         tokens_per_s_node_at_zero_exposed_comm=S / min(times[1:]), peak_mem_gb=torch.cuda.max_memory_allocated() / 2 ** 30)
+    mpu.destroy_model_parallel()
+
+
 if __name__ == "__main__":
     which = sys.argv[1:] or ["rank"]
+    if "rankstep" in which:
+        i = which.index("rankstep")
+        bench_rankstep(int(which[i + 1]) if len(which) > i + 1 and which[i + 1].isdigit() else 20)
     if "rank" in which:
         bench_rank()
     if "step" in which:
