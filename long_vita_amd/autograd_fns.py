@@ -462,10 +462,14 @@ class FlashAttnFn(torch.autograd.Function):
     (position ids with resets; _flash_attention_forward(position_ids=...), M/core/transformer/dot_product_attention.py:374-390)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, softmax_scale, causal=True, seg_start=None, seg_end=None):
+    def forward(ctx, q, k, v, softmax_scale, causal=True, seg_start=None, seg_end=None, kept=None):
+        """kept = (o, lse) of an earlier run on the same inputs (recompute_cache: the replay of a checkpointed layer): no kernel launch."""
         if not causal:
             raise ValueError("non-causal attention goes through FlashAttnNonCausalFn")
-        o, lse = ops.flash_attn(q, k, v, causal=True, softmax_scale=softmax_scale, return_lse=True, seg_start=seg_start)
+        if kept is not None:
+            o, lse = kept
+        else:
+            o, lse = ops.flash_attn(q, k, v, causal=True, softmax_scale=softmax_scale, return_lse=True, seg_start=seg_start)
         ctx.save_for_backward(q, k, v, o, lse, seg_start, seg_end)
         ctx.softmax_scale = softmax_scale
         return o
@@ -475,7 +479,7 @@ class FlashAttnFn(torch.autograd.Function):
         q, k, v, o, lse, seg_start, seg_end = ctx.saved_tensors
         dq, dk, dv = ops.flash_attn_bwd(q, k, v, o, d_o.contiguous(), lse, softmax_scale=ctx.softmax_scale,
                                         seg_start=seg_start, seg_end=seg_end)
-        return dq, dk, dv, None, None, None, None
+        return dq, dk, dv, None, None, None, None, None
 
 
 class FlashAttnNonCausalFn(torch.autograd.Function):
@@ -544,8 +548,9 @@ class FlashAttnCPFn(torch.autograd.Function):
     training.TrainStep issues, instead of TE's CP - 1 P2P ring steps in each direction."""
 
     @staticmethod
-    def forward(ctx, q, k, v, impl):
-        cp, r, group = mpu.get_context_parallel_world_size(), mpu.get_context_parallel_rank(), mpu.get_context_parallel_group()
+    def run_forward(q, k, v, impl):
+        """The forward proper -> (o [1, S_l, Hq, D], lse [1, Hq, S_l]); also what a checkpointed layer's first (no-grad) run calls when
+        its result is kept for the replay (recompute_cache)."""
         _, s_l, hq, d = q.shape
         hkv = k.shape[2]
         if s_l % 2:
@@ -558,6 +563,13 @@ class FlashAttnCPFn(torch.autograd.Function):
         lse = torch.empty(1, hq, s_l, dtype=torch.float32, device=q.device)
         o = torch.empty(1, s_l, hq, d, dtype=q.dtype, device=q.device)
         impl.forward_cp(q.reshape(1, s_l, hkv, hq // hkv, d), kv_local, out=o, lse=lse)
+        return o, lse
+
+    @staticmethod
+    def forward(ctx, q, k, v, impl, kept=None):
+        """kept = (o, lse) of an earlier run on the same inputs: neither the K / V all-gather nor the kernels run again."""
+        cp, r, group = mpu.get_context_parallel_world_size(), mpu.get_context_parallel_rank(), mpu.get_context_parallel_group()
+        o, lse = kept if kept is not None else FlashAttnCPFn.run_forward(q, k, v, impl)
         ctx.save_for_backward(q, k, v, o, lse)
         ctx.cp, ctx.rank, ctx.group, ctx.softmax_scale = cp, r, group, impl.softmax_scale   # the backward runs on autograd's thread
         return o
@@ -605,7 +617,7 @@ class FlashAttnCPFn(torch.autograd.Function):
         dkv = dkv.view(n_split, 2, s_l, hg, d)
         dk = dkv[:, 0].permute(1, 0, 2, 3).reshape(1, s_l, hkv, d)
         dv = dkv[:, 1].permute(1, 0, 2, 3).reshape(1, s_l, hkv, d)
-        return dq, dk, dv, None
+        return dq, dk, dv, None, None
 
 
 # ------------------------------------------------------------------------------------------------

@@ -16,7 +16,7 @@ from typing import Optional
 import torch
 import torch.distributed as dist
 
-from . import ops, parallel_state as mpu, training_utils
+from . import ops, parallel_state as mpu, recompute_cache, training_utils
 
 
 class HipDotProductAttention(torch.nn.Module):
@@ -43,7 +43,10 @@ class HipDotProductAttention(torch.nn.Module):
 
     def forward(self, query, key, value, attention_mask=None, attn_mask_type=None, packed_seq_params=None):
         needs_grad = torch.is_grad_enabled() and (query.requires_grad or key.requires_grad or value.requires_grad)
+        region, phase = recompute_cache.current()
         if not needs_grad:
+            if region is not None and phase == "store" and self._impl.causal and query.shape[1] == 1 and packed_seq_params is None:
+                return self._forward_and_keep(query, key, value)
             return self._impl.forward(query, key, value, attention_mask, attn_mask_type, packed_seq_params)
         assert packed_seq_params is None, (
             "Packed sequence is not supported by DotProductAttention."
@@ -65,12 +68,29 @@ class HipDotProductAttention(torch.nn.Module):
             # dK / dV reduce-scatter backward
             if training_utils.get_packed_segments() is not None:
                 raise NotImplementedError("packed samples under context parallelism are not built (reference stage 2 is CP = 1)")
-            out = FlashAttnCPFn.apply(q, k, v, self._impl)
+            out = FlashAttnCPFn.apply(q, k, v, self._impl, recompute_cache.take())
         else:
             seg = training_utils.get_packed_segments() if self._impl.causal else None
             out = FlashAttnFn.apply(q, k, v, self._impl.softmax_scale, self._impl.causal,
-                                    None if seg is None else seg[0], None if seg is None else seg[1])
+                                    None if seg is None else seg[0], None if seg is None else seg[1], recompute_cache.take())
         return out.transpose(0, 1).reshape(sq, b, np_ * hn)
+
+    def _forward_and_keep(self, query, key, value):
+        """The first (no-grad) run of a checkpointed layer under VITA_KEEP_ATTENTION=1: the same kernels as the plain call, with the
+        log-sum-exp written out, and (context, lse) left with recompute_cache for the replay in the backward."""
+        from .autograd_fns import FlashAttnCPFn
+        sq, b, np_, hn = query.shape
+        q, k, v = query.transpose(0, 1), key.transpose(0, 1), value.transpose(0, 1)
+        if mpu.get_context_parallel_world_size() > 1:
+            if training_utils.get_packed_segments() is not None:
+                raise NotImplementedError("packed samples under context parallelism are not built (reference stage 2 is CP = 1)")
+            o, lse = FlashAttnCPFn.run_forward(q, k, v, self._impl)
+        else:
+            seg = training_utils.get_packed_segments()
+            o, lse = ops.flash_attn(q, k, v, causal=True, softmax_scale=self._impl.softmax_scale, return_lse=True,
+                                    seg_start=None if seg is None else seg[0])
+        recompute_cache.store((o, lse))
+        return o.transpose(0, 1).reshape(sq, b, np_ * hn)
 
 
 def _pad_head_dim(t: torch.Tensor) -> torch.Tensor:

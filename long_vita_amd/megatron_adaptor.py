@@ -113,7 +113,7 @@ def _targets():
     from .layers import ColumnParallelLinear
     from .layers import Norm
     from .rotary_pos_embedding import apply_rotary_pos_emb
-    from . import vision_modules as vm
+    from . import recompute_cache, vision_modules as vm
     return [
         ("megatron.core.transformer.dot_product_attention.DotProductAttention.forward",
          dot_product_attention_forward_wrapper),
@@ -139,6 +139,8 @@ def _targets():
         ("long_vita_megatron.core.models.multimodal.gpt_vl_model.GPTVLModel.__init__", vm.gpt_vl_model_init_wrapper),
         ("megatron.core.transformer.custom_layers.transformer_engine.TENorm", Norm),
         ("megatron.core.tensor_parallel.cross_entropy.vocab_parallel_cross_entropy", vm.vocab_parallel_cross_entropy),
+        # r05: activation recompute that keeps the attention's result (VITA_KEEP_ATTENTION=1; a pass-through otherwise)
+        ("megatron.core.tensor_parallel.random.checkpoint", recompute_cache.checkpoint_wrapper),
     ]
 
 
@@ -156,7 +158,8 @@ EXTRA_TARGETS = ("megatron.core.models.common.embeddings.rotary_pos_embedding.ap
                  VISION + "multimodal_projector.MultimodalProjector",
                  "long_vita_megatron.core.models.multimodal.gpt_vl_model.GPTVLModel.__init__",
                  "megatron.core.transformer.custom_layers.transformer_engine.TENorm",
-                 "megatron.core.tensor_parallel.cross_entropy.vocab_parallel_cross_entropy")
+                 "megatron.core.tensor_parallel.cross_entropy.vocab_parallel_cross_entropy",
+                 "megatron.core.tensor_parallel.random.checkpoint")
 
 PATCHES = [name for name, _ in _targets()]
 

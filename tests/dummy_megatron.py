@@ -609,6 +609,7 @@ _STUBS = {
     "megatron.core.transformer.custom_layers.transformer_engine": dict(TENorm=_TENormPlaceholder),
     "megatron.core.transformer.transformer_block": dict(TransformerBlock=TransformerBlock, TENorm=_TENormPlaceholder),
     "megatron.core.tensor_parallel": dict(checkpoint=checkpoint, vocab_parallel_cross_entropy=_vocab_parallel_cross_entropy_placeholder),
+    "megatron.core.tensor_parallel.random": dict(checkpoint=checkpoint),      # defined there, re-exported by the package (as in Megatron)
     "megatron.core.tensor_parallel.cross_entropy": dict(vocab_parallel_cross_entropy=_vocab_parallel_cross_entropy_placeholder),
     "long_vita_megatron.core.models.multimodal.gpt_vl_model": dict(GPTVLModel=GPTVLModel),
     "megatron.core.transformer.spec_utils": dict(ModuleSpec=ModuleSpec, build_module=build_module),

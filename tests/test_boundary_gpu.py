@@ -778,6 +778,47 @@ def test_vocab_parallel_cross_entropy_masks_ignored_targets_and_stays_sharded(me
         tol("d logits, bf16 logits", rel_l2(lb.grad.view(n, V), wg[0] * gl), 4e-3)
 
 
+def test_recompute_keeping_the_attention_result_is_bit_identical_and_skips_the_second_forward(megatron, monkeypatch):
+    """`--recompute-granularity full --recompute-method block` through the (patched) tensor_parallel.checkpoint with
+    VITA_KEEP_ATTENTION=1 — the checkpointed layers' first run leaves (context, lse) with recompute_cache, the replay in the backward hands
+    them to FlashAttnFn instead of launching the forward kernel again.  Output, input gradient and every parameter gradient are BIT
+    identical to the same block without the switch, and the attention forward runs once per layer instead of twice."""
+    from long_vita_amd import ops as ops_mod
+    tb_mod = sys.modules["megatron.core.transformer.transformer_block"]
+    S = 512
+    mcfg = dm.TransformerConfig(num_layers=2, hidden_size=CFG["hidden"], num_attention_heads=CFG["heads"], num_query_groups=CFG["kv_groups"],
+                                kv_channels=CFG["head_dim"], ffn_hidden_size=CFG["ffn"], recompute_granularity="full",
+                                recompute_method="block", recompute_num_layers=2)
+    torch.manual_seed(11)
+    blk = tb_mod.TransformerBlock(mcfg, megatron.get_gpt_layer_with_transformer_engine_spec(), post_process=True)
+    blk.train()
+    g = torch.Generator().manual_seed(92)
+    x = (torch.randn(S, 1, CFG["hidden"], generator=g) * 0.5).bfloat16().to(DEV)
+    go = torch.randn(S, 1, CFG["hidden"], generator=g).bfloat16().to(DEV)
+    freqs = glue.rope_emb(S, glue.rope_inv_freq(CFG["head_dim"], 1e6)).to(DEV)
+    calls = {"n": 0}
+    real = ops_mod.flash_attn
+
+    def counting(*a, **k):
+        calls["n"] += 1
+        return real(*a, **k)
+
+    monkeypatch.setattr(ops_mod, "flash_attn", counting)
+    outs = []
+    for keep in ("0", "1"):
+        monkeypatch.setenv("VITA_KEEP_ATTENTION", keep)
+        calls["n"] = 0
+        blk.zero_grad(set_to_none=True)
+        xi = x.clone().requires_grad_(True)
+        o = blk(xi, attention_mask=None, rotary_pos_emb=freqs)
+        o.backward(go)
+        outs.append((o.detach().clone(), xi.grad.clone(), {k: v.grad.clone() for k, v in blk.named_parameters()}, calls["n"]))
+    assert outs[0][3] == 4 and outs[1][3] == 2, (outs[0][3], outs[1][3])            # 2 layers: forward + recompute vs forward only
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    for k in outs[0][2]:
+        assert torch.equal(outs[0][2][k], outs[1][2][k]), k
+
+
 def test_output_layer_with_a_logit_mask_that_selects_nothing(megatron):
     """under CP the answer tokens of a 128K row all sit on CP rank 0 — every other rank's `logit_mask` is all
     False.  ColumnParallelLinear(output_layer).forward must return an empty [0, b, V] tensor (the reference's masked_select does), and

@@ -1226,3 +1226,52 @@ def test_padded_weight_is_never_stale_for_a_trainable_parameter():
     f.data.fill_(5.0)
     ops.invalidate_padded_weights()
     assert float(ops._padded_weight(f, 128)[0, 0]) == 5.0
+
+
+def test_recompute_cache_marks_store_and_replay_runs_of_a_checkpointed_function(monkeypatch):
+    """recompute_cache.checkpoint_wrapper around Megatron's tensor_parallel.checkpoint (restated in tests/dummy_megatron.py): the first run
+    of the function is the "store" run, the run inside the backward the "replay" run; what the store run left comes back in call order,
+    exactly once; outside a region, or with VITA_KEEP_ATTENTION unset, nothing is kept and the wrapper is a pass-through."""
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dummy_megatron as dm
+    from long_vita_amd import recompute_cache as rc
+    log = []
+
+    def layer(x):
+        region, phase = rc.current()
+        log.append(phase)
+        if phase == "store":
+            rc.store(("a", 1)); rc.store(("b", 2))
+        kept = [rc.take(), rc.take(), rc.take()] if phase == "replay" else None
+        log.append(kept)
+        return x * 2.0
+
+    wrapped = rc.checkpoint_wrapper(dm.checkpoint)
+    x = torch.ones(3, requires_grad=True)
+    monkeypatch.delenv("VITA_KEEP_ATTENTION", raising=False)
+    wrapped(layer, False, x).sum().backward()
+    assert log == [None, None, None, None] and rc.current() == (None, None)            # pass-through: no region in either run
+    log.clear()
+    monkeypatch.setenv("VITA_KEEP_ATTENTION", "1")
+    x.grad = None
+    y = wrapped(layer, False, x)
+    assert log == ["store", None] and rc.current() == (None, None)
+    y.sum().backward()
+    assert log[2] == "replay" and log[3] == [("a", 1), ("b", 2), None] and float(x.grad[0]) == 2.0
+    assert rc.take() is None                                                            # outside any region
+    # two regions alive at once (two checkpointed layers): each replay sees its own slots
+    log.clear()
+    x.grad = None
+    def layer_n(tag):
+        def f(t):
+            _, phase = rc.current()
+            if phase == "store":
+                rc.store(tag)
+            else:
+                log.append((tag, rc.take()))
+            return t + 1.0
+        return f
+    z = wrapped(layer_n("L1"), False, wrapped(layer_n("L0"), False, x))
+    z.sum().backward()
+    assert sorted(log) == [("L0", "L0"), ("L1", "L1")]

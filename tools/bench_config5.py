@@ -231,7 +231,9 @@ if __name__ == "__main__":
     which = sys.argv[1:] or ["rank"]
     if "rankstep" in which:
         i = which.index("rankstep")
-        bench_rankstep(int(which[i + 1]) if len(which) > i + 1 and which[i + 1].isdigit() else 20)
+        n = int(which[i + 1]) if len(which) > i + 1 and which[i + 1].isdigit() else 20
+        r = int(which[i + 2]) if len(which) > i + 2 and which[i + 2].isdigit() else 1     # cp rank: 0 holds the answer tokens (the last chunk)
+        bench_rankstep(n, cp_rank=r)
     if "rank" in which:
         bench_rank()
     if "step" in which:
