@@ -2,10 +2,10 @@
 with labels + logit mask -> loss_func -> loss.backward() through autograd over the registered modules (48 full-width decoder layers,
 vocabulary 152064, 16384 tokens, 512 answer tokens, text only) — `tests/dummy_megatron.py` restates GPTVLModel / TransformerBlock /
 tensor_parallel.checkpoint / forward_step / loss_func (Megatron-LM is not installable here) — next to training.TrainStep's explicit
-sweep on the same sizes (tools/bench_train.py: profiles/r04_train_step_16k_n1.jsonl).
+sweep on the same sizes (tools/bench_train.py: profiles/r05_train_step_16k_n1.jsonl).
 
     python tools/bench_dropin_model.py [recompute_num_layers ...]      (0 = every activation kept, 20 = stage 3's flag, 48 = all)
-Appends JSON lines to gpurun_out/r04_dropin_model.jsonl."""
+Appends JSON lines to gpurun_out/r05_dropin_model.jsonl."""
 import json
 import os
 import sys
@@ -28,7 +28,7 @@ specs = sys.modules["megatron.core.models.gpt.gpt_layer_specs"]
 gpt_cls = sys.modules["long_vita_megatron.core.models.multimodal.gpt_vl_model"].GPTVLModel
 DEV = "cuda"
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-LOG = open(os.path.join(ROOT, "gpurun_out", "r04_dropin_model.jsonl"), "a")
+LOG = open(os.path.join(ROOT, "gpurun_out", "r05_dropin_model.jsonl"), "a")
 S, V, L, ANSWER = 16384, 152064, 48, 512
 
 
@@ -80,7 +80,7 @@ def run(n_rec):
         torch.cuda.synchronize(); ts.append(time.perf_counter() - t0)
     rec = dict(kind="dropin_model_step", what="forward_step -> GPTVLModel.forward -> loss_func -> backward through autograd over the registered "
                "modules (tests/dummy_megatron.py stands in for Megatron-LM)", seq=S, layers=L, vocab=V, answer_tokens=ANSWER, parameters=n_params,
-               recompute_num_layers=n_rec, s_per_step=min(ts), s_per_step_all=ts, loss=float(loss),
+               recompute_num_layers=n_rec, VITA_KEEP_ATTENTION=os.environ.get("VITA_KEEP_ATTENTION", "0"), s_per_step=min(ts), s_per_step_all=ts, loss=float(loss),
                activations_kept_after_forward_gb=kept / 1e9, peak_allocated_gb=peak / 1e9, weights_gb=base / 1e9)
     s = json.dumps(rec)
     print(s, flush=True)
