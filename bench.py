@@ -469,7 +469,7 @@ def main():
     # HBM traffic of that kernel: PMC counters cannot be read from inside this process; when a
     # rocprofv3 --pmc measurement of the same launch shape is committed under profiles/, report it
     traffic, traffic_src = None, None
-    for tag in ("r04", "r03"):                      # the newest committed measurement of this launch shape
+    for tag in ("r05", "r04", "r03"):                      # the newest committed measurement of this launch shape
         try:
             pmc = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_attn128k_pmc.json")))
             if pmc["seq"] == seq and pmc["n_gpus"] == world:

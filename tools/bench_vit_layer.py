@@ -1,7 +1,7 @@
 """ViT layer forward + backward through the Megatron-built module (VERDICT r3 "next round" 6): the InternViT layer of
 `get_vit_layer_local_spec_for_intern()` (tests/dummy_megatron.py stands in for Megatron-LM) at 253 / 64 frames x 1025 tokens, autograd on,
 with the attention backward at the native head size 64 (r04: attn_bwd.hip templated on d) against the r03 path that zero-padded q / k / v / o /
-dO to d = 128 (VITA_VIT_BWD_PAD128=1).  Appends JSON lines to gpurun_out/r04_vit_layer.jsonl."""
+dO to d = 128 (VITA_VIT_BWD_PAD128=1).  Appends JSON lines to gpurun_out/r05_vit_layer.jsonl."""
 import json, os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, ROOT); sys.path.insert(0, os.path.join(ROOT, "tests"))
@@ -16,7 +16,7 @@ aspm.patches_info = {}
 assert ad.exe_adaptation(create_dummy=True)
 vls = sys.modules["long_vita_megatron.core.models.vision.vit_layer_specs"]
 DEV = "cuda"
-LOG = open(os.path.join(ROOT, "gpurun_out", "r04_vit_layer.jsonl"), "a")
+LOG = open(os.path.join(ROOT, "gpurun_out", "r05_vit_layer.jsonl"), "a")
 mcfg = dm.TransformerConfig(hidden_size=1024, num_attention_heads=16, num_query_groups=16, kv_channels=64, ffn_hidden_size=4096,
                             normalization="LayerNorm", layernorm_epsilon=1e-6, add_bias_linear=True, add_qkv_bias=True, gated_linear_unit=False,
                             activation_func=torch.nn.functional.gelu)

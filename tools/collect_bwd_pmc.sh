@@ -2,7 +2,7 @@
 # PMC passes of the attention backward kernels at S = 16384 (40 : 8 heads, d = 128): separate rocprofv3 --pmc runs (never combined with tracing),
 # summarised per kernel by tools/pmc_summary.py.   usage: tools/collect_bwd_pmc.sh <tag>  -> gpurun_out/<tag>_attn_bwd16k_pmc_raw.txt
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=$PWD/gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp

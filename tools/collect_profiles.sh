@@ -4,7 +4,7 @@
 # attention / GEMM microbenchmarks of the round, the 16K line, and a roctx-marked dry run.
 # usage: tools/collect_profiles.sh <tag>    -> gpurun_out/<tag>_*
 set -u
-TAG=${1:-r04}
+TAG=${1:-r05}
 OUT=gpurun_out
 mkdir -p $OUT
 export TMPDIR=/tmp
