@@ -357,12 +357,25 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world != args.gpus:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}: the launcher's --nproc-per-node and --gpus must agree")
+    # VITA_BENCH_BACKEND=gloo-staged (diagnostic, --dry-run only): N processes on whatever devices exist, device tensors exchanged through
+    # host memory by gloo (tools/gloo_staging.py) — walks the N > 1 code on a one-GPU box, where RCCL refuses two ranks on one device
+    staged = os.environ.get("VITA_BENCH_BACKEND", "nccl") == "gloo-staged"
+    if staged and not args.dry_run:
+        raise SystemExit("VITA_BENCH_BACKEND=gloo-staged is a plumbing check: it is accepted together with --dry-run only")
+    if staged:
+        local_rank %= max(torch.cuda.device_count(), 1)
     torch.cuda.set_device(local_rank)
     dev = f"cuda:{local_rank}"
     selftest = "MASTER_ADDR" in os.environ and (args.dry_run or os.environ.get("VITA_BENCH_SELF_LAUNCHED") == "1")
     ctl = None
     if world > 1 or selftest:
-        dist.init_process_group("nccl", device_id=torch.device(dev))
+        if staged:
+            dist.init_process_group("gloo")
+            sys.path.insert(0, os.path.join(ROOT, "tools"))
+            import gloo_staging
+            gloo_staging.install()
+        else:
+            dist.init_process_group("nccl", device_id=torch.device(dev))
         # a control plane that does not ride on the thing being tested: the "did every rank get through the first step" vote
         ctl = dist.new_group(backend="gloo")
 
@@ -504,6 +517,8 @@ def main():
     }
     if degraded:
         line["degraded"] = degraded
+    if staged:
+        line["transport"] = "gloo-staged (diagnostic: device tensors through host memory; not a measurement)"
     if parity is not None:
         line["parity_check"] = parity
     line["comm"] = comm

@@ -164,3 +164,31 @@ def test_bench_dead_ranks_get_one_plain_relaunch():
     line, err = _bench_self_launched({"VITA_BENCH_INJECT_FAILURE": "exit"})
     assert line["value"] > 0 and "first launch of 1 ranks exited with code" in line["degraded"]
     assert "re-run on the plain exchange schedule" in err
+
+
+def test_bench_two_processes_on_one_gpu_over_staged_gloo():
+    """The N = 2 path of bench.py executed by TWO real processes on this one GPU (RCCL refuses two ranks on one device —
+    profiles/r05_rccl_same_device.txt — so the transport is the diagnostic one of tools/gloo_staging.py: device tensors exchanged between
+    the processes through host memory by gloo).  Everything else is the product's code in multi-process form for the first time: the
+    self-launch of two ranks, process-group and control-group set-up, the zig-zag split of the request, a K / V all-gather per layer,
+    the logits gather, the first-step vote, `comm`, and `cross_rank_check` — CP = 2 logits against rank 0 alone at CP = 1."""
+    import json
+    env = dict(os.environ, VITA_BENCH_BACKEND="gloo-staged")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=900, env=env)
+    assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
+    lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, r.stdout
+    line = json.loads(lines[0])
+    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "cp2" and "degraded" not in line and "gloo-staged" in line["transport"]
+    comm = line["comm"]
+    assert "error" not in comm and comm["ranks"] == 2 and comm["backend"] == "gloo" and comm["kv_bytes_sent_per_layer_per_rank"] > 0
+    cross = line["cross_rank_check"]
+    assert "error" not in cross, cross
+    assert cross["rows"] == 4 and cross["argmax_equal"] == 4 and cross["rel_l2"] < 1.4e-2, cross     # two bf16 evaluations of the same prefill
+    # without --dry-run the switch is refused: it can never produce a number that looks like a measurement
+    r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], capture_output=True, text=True, timeout=300,
+                        env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
+    assert r2.returncode != 0 and "--dry-run only" in (r2.stderr + r2.stdout)
