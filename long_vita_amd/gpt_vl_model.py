@@ -275,10 +275,12 @@ class GPTVLModel:
 
     def _decode_workspace(self, device):
         ws = self._ws.get("decode")
+        cp = mpu.get_context_parallel_world_size()
+        if ws is not None and ws["gmsg"].shape[0] != cp:          # the model object outlived a change of the context-parallel size
+            ws = None                                             # (r05: found by the first two-PROCESS run of the decode loop)
         if ws is None:
             c = self.cfg
             e = lambda *shape, dt=torch.bfloat16: torch.empty(*shape, dtype=dt, device=device)  # noqa: E731
-            cp = mpu.get_context_parallel_world_size()
             msg = c.heads * c.head_dim + 2 * c.heads
             ws = {"x": e(1, c.hidden), "qkv": e(1, c.qkv_out), "ctx": e(c.heads, c.head_dim), "act": e(c.ffn),
                   "h": e(1, c.hidden), "msg": e(msg, dt=torch.float32), "gmsg": e(cp, msg, dt=torch.float32)}

@@ -20,9 +20,17 @@ _WORKER = r"""
 import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["VITA_ROOT"])
 rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
-torch.cuda.set_device(rank)
-dev = f"cuda:{rank}"
-dist.init_process_group("nccl", device_id=torch.device(dev))
+staged = os.environ.get("VITA_WORKER_BACKEND") == "gloo-staged"      # two PROCESSES on one GPU: tools/gloo_staging.py (RCCL refuses that)
+dev_index = rank % torch.cuda.device_count() if staged else rank
+torch.cuda.set_device(dev_index)
+dev = f"cuda:{dev_index}"
+if staged:
+    dist.init_process_group("gloo")
+    sys.path.insert(0, os.path.join(os.environ["VITA_ROOT"], "tools"))
+    import gloo_staging
+    gloo_staging.install()
+else:
+    dist.init_process_group("nccl", device_id=torch.device(dev))
 from long_vita_amd import generation, gpt_vl_model, lib, parallel_state as mpu, training
 lib.load(allow_build=False)
 cfgd = dict(num_layers=2, hidden=1024, heads=8, kv_groups=4, head_dim=128, ffn=2816, vocab=1024)
@@ -73,7 +81,7 @@ if rank == 0:
     try:
         os.makedirs(os.path.dirname(path), exist_ok=True)
         data = json.load(open(path)) if os.path.exists(path) else {}
-        data[f"test_multigpu_gpu.py::real_rccl_world{world}"] = MEASURED
+        data[f"test_multigpu_gpu.py::{'two_processes_staged_gloo' if staged else 'real_rccl'}_world{world}"] = MEASURED
         json.dump(data, open(path, "w"), indent=1, sort_keys=True)
     except (OSError, ValueError):
         pass
@@ -102,6 +110,15 @@ def _launch(tmp_path, world, extra_env=None):
 @pytest.mark.skipif(torch.cuda.device_count() < 2, reason="needs two GPUs (real RCCL ranks)")
 def test_two_real_rccl_ranks_match_cp1(tmp_path):
     _launch(tmp_path, 2)
+
+
+def test_the_same_worker_as_two_processes_on_one_gpu_over_staged_gloo(tmp_path):
+    """The worker above — CP = 2 prefill, the training step with its K / V all-gather, dK / dV reduce-scatter and loss all-reduce, cached
+    decode over the sequence-sharded KV cache, each against CP = 1 — run by TWO real processes that share this box's one GPU, with the
+    diagnostic transport of tools/gloo_staging.py (device tensors exchanged between the processes through host memory by gloo; RCCL
+    refuses two ranks on one device).  Process groups, rank-dependent indexing, asynchronous handles and the order of the collectives
+    are the product's own; only the wire is not RCCL."""
+    _launch(tmp_path, 2, {"VITA_WORKER_BACKEND": "gloo-staged"})
 
 
 def test_the_same_worker_on_one_real_rccl_rank(tmp_path):
