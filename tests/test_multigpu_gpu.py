@@ -183,8 +183,9 @@ def test_bench_dead_ranks_get_one_plain_relaunch():
     assert "re-run on the plain exchange schedule" in err
 
 
-def test_bench_two_processes_on_one_gpu_over_staged_gloo():
-    """The N = 2 path of bench.py executed by TWO real processes on this one GPU (RCCL refuses two ranks on one device —
+@pytest.mark.parametrize("n", [2, 8])
+def test_bench_n_processes_on_one_gpu_over_staged_gloo(n):
+    """The N = 2 and the N = 8 path of bench.py (the driver's `python bench.py --gpus 8`) executed by N real processes on this one GPU (RCCL refuses two ranks on one device —
     profiles/r05_rccl_same_device.txt — so the transport is the diagnostic one of tools/gloo_staging.py: device tensors exchanged between
     the processes through host memory by gloo).  Everything else is the product's code in multi-process form for the first time: the
     self-launch of two ranks, process-group and control-group set-up, the zig-zag split of the request, a K / V all-gather per layer,
@@ -193,18 +194,21 @@ def test_bench_two_processes_on_one_gpu_over_staged_gloo():
     env = dict(os.environ, VITA_BENCH_BACKEND="gloo-staged")
     for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT"):
         env.pop(k, None)
-    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "1", "--dry-run"],
-                       capture_output=True, text=True, timeout=900, env=env)
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", str(n), "--steps", "1", "--warmup", "1", "--dry-run"],
+                       capture_output=True, text=True, timeout=1500, env=env)
     assert r.returncode == 0, r.stdout[-2000:] + r.stderr[-4000:]
     lines = [ln for ln in r.stdout.splitlines() if ln.startswith("{")]
     assert len(lines) == 1, r.stdout
     line = json.loads(lines[0])
-    assert line["n_gpus"] == 2 and line["config"]["parallelism"] == "cp2" and "degraded" not in line and "gloo-staged" in line["transport"]
+    assert line["n_gpus"] == n and line["config"]["parallelism"] == f"cp{n}" and "degraded" not in line and "gloo-staged" in line["transport"]
     comm = line["comm"]
-    assert "error" not in comm and comm["ranks"] == 2 and comm["backend"] == "gloo" and comm["kv_bytes_sent_per_layer_per_rank"] > 0
+    assert "error" not in comm and comm["ranks"] == n and comm["backend"] == "gloo" and comm["kv_bytes_sent_per_layer_per_rank"] > 0
     cross = line["cross_rank_check"]
     assert "error" not in cross, cross
-    assert cross["rows"] == 4 and cross["argmax_equal"] == 4 and cross["rel_l2"] < 1.4e-2, cross     # two bf16 evaluations of the same prefill
+    # two bf16 evaluations of the same prefill (random weights: at 16 positions one near-tie may tip — measured 15 of 16 at N = 8, rel-L2 8.8e-3)
+    assert cross["rows"] == 2 * n and cross["argmax_equal"] >= 2 * n - (0 if n == 2 else 1) and cross["rel_l2"] < 1.4e-2, cross
+    if n != 2:
+        return
     # without --dry-run the switch is refused: it can never produce a number that looks like a measurement
     r2 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], capture_output=True, text=True, timeout=300,
                         env=dict(env, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0"))
