@@ -121,6 +121,86 @@ def test_the_same_worker_as_two_processes_on_one_gpu_over_staged_gloo(tmp_path):
     _launch(tmp_path, 2, {"VITA_WORKER_BACKEND": "gloo-staged"})
 
 
+_WORKER_TP = r"""
+import os, sys, torch, torch.distributed as dist
+sys.path.insert(0, os.environ["VITA_ROOT"])
+rank, world = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+torch.cuda.set_device(rank % torch.cuda.device_count())
+dev = f"cuda:{rank % torch.cuda.device_count()}"
+dist.init_process_group("gloo")
+sys.path.insert(0, os.path.join(os.environ["VITA_ROOT"], "tools"))
+import gloo_staging
+gloo_staging.install()
+from long_vita_amd import gpt_vl_model, lib, parallel_state as mpu, tensor_parallel as tpar, training
+lib.load(allow_build=False)
+TP, CP, S = 2, world // 2, 2048
+cfg = gpt_vl_model.GPTConfig(num_layers=2, hidden=1024, heads=8, kv_groups=4, head_dim=128, ffn=2816, vocab=1024)
+def rel(a, b): return float((a.float() - b.float()).norm() / (b.float().norm() + 1e-30))
+g = torch.Generator().manual_seed(7)
+tokens = torch.randint(0, cfg.vocab, (1, S), generator=g).to(dev)
+labels = torch.randint(0, cfg.vocab, (1, S), generator=g).to(dev)
+loss_mask = torch.zeros(1, S, device=dev); loss_mask[0, S - 200:] = 1; loss_mask[0, 300:320] = 1
+full = gpt_vl_model.GPTVLModel.random_init(cfg, seed=5, device=dev)
+mpu.destroy_model_parallel()
+ref_loss, ref_grads = training.TrainStep(full).forward_backward(tokens, labels, loss_mask)      # TP = CP = 1, no group in the way
+# ---- TP = 2 x CP = world / 2 over real process groups (rank = cp_rank * TP + tp_rank, every rank creates every group) ----
+mpu.initialize_model_parallel(context_parallel_size=CP, tensor_model_parallel_size=TP)
+assert mpu.get_tensor_model_parallel_world_size() == TP and mpu.get_context_parallel_world_size() == CP
+assert mpu.get_tensor_model_parallel_rank() == rank % TP and mpu.get_context_parallel_rank() == rank // TP
+shard, cfg_l = tpar.shard_llm_params(full.p, cfg, TP, rank % TP)
+want, _ = tpar.shard_llm_params(ref_grads, cfg, TP, rank % TP)          # the gradients this rank should hold
+model = gpt_vl_model.GPTVLModel(cfg_l, shard)
+loss, grads = training.TrainStep(model).forward_backward(tokens, labels, loss_mask)
+training.allreduce_grads(grads)                                          # over the CP group
+assert abs(float(loss) - float(ref_loss)) < 1e-2 * abs(float(ref_loss)), (float(loss), float(ref_loss))
+worst = 0.0
+for k in ("embed", "lm_head", "final_ln"):
+    worst = max(worst, rel(grads[k], want[k]))
+for gl, wl in zip(grads["layers"], want["layers"]):
+    for k in wl:
+        worst = max(worst, rel(gl[k], wl[k]))
+assert worst < 2.2e-2, worst
+vals = [None] * world
+dist.all_gather_object(vals, (float(loss), worst))
+if rank == 0:
+    import json
+    assert len({round(v[0], 6) for v in vals}) == 1, vals             # every rank reports the same loss
+    path = os.path.join(os.environ["VITA_ROOT"], "gpurun_out", "r05_parity_rccl.json")
+    try:
+        os.makedirs(os.path.dirname(path), exist_ok=True)
+        data = json.load(open(path)) if os.path.exists(path) else {}
+        data[f"test_multigpu_gpu.py::tp2_x_cp{CP}_processes_staged_gloo_world{world}"] = {
+            "loss vs TP = CP = 1 (relative)": abs(vals[0][0] - float(ref_loss)) / abs(float(ref_loss)), "worst gradient rel-L2 over the ranks": max(v[1] for v in vals)}
+        json.dump(data, open(path, "w"), indent=1, sort_keys=True)
+    except (OSError, ValueError):
+        pass
+dist.barrier()
+dist.destroy_process_group()
+print("OK", rank)
+"""
+
+
+def test_config5_shaped_step_as_four_processes_tp2_x_cp2_over_staged_gloo(tmp_path):
+    """BASELINE config 5's structure (TP = 2 x CP = N / 2, Megatron's rank order) as FOUR real processes on this one GPU over the
+    diagnostic transport: `initialize_model_parallel` building the TP and CP groups with `dist.new_group` on every rank, the
+    tensor-parallel all-reduces and the vocabulary-parallel head inside the step, the K / V all-gather and dK / dV reduce-scatter over
+    the CP group, the gradient all-reduce — loss and every local gradient shard against the unsharded step computed by the same process."""
+    script = tmp_path / "worker_tp.py"
+    script.write_text(_WORKER_TP)
+    world = 4
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(world):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(world), MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port),
+                   VITA_ROOT=ROOT)
+        procs.append(subprocess.Popen([sys.executable, str(script)], env=env, stdout=subprocess.PIPE, stderr=subprocess.STDOUT, text=True))
+    for p in procs:
+        out, _ = p.communicate(timeout=900)
+        assert p.returncode == 0 and "OK" in out, out[-4000:]
+
+
 def test_the_same_worker_on_one_real_rccl_rank(tmp_path):
     """The worker script itself on a world of ONE real RCCL rank (prefill forced through the context-parallel code path:
     K/V pack, RCCL all-gather, chunk tables, logits gather) — what a 1-GPU box can run of it."""
