@@ -574,9 +574,13 @@ constexpr int LINE = 1040, HALF = 16 * LINE, OPB = 2 * HALF, STAGE = 2 * OPB, LD
 // OPM = 2 (r04, vita_gemm_bf16_nn): A as in the NT kernel ([M][K], row-major), W contraction-major ([K][N]) as in the TN kernel —
 // C = A W, which is what an input gradient is (dX [tokens, K_in] = dY [tokens, N] W [N, K_in] with the weight as the forward holds it),
 // so dgrad needs no vita_transpose_bf16 pass over the weight either.  A's half of a stage is the NT image, W's half the TN image.
+#ifndef VITA_GEMM_EARLY_NEXT
+#define VITA_GEMM_EARLY_NEXT 1
+#endif
 template <int EPI, bool INTERIOR, int OPM = 0>
 __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   using namespace w4;
+  constexpr bool EARLY_NEXT = VITA_GEMM_EARLY_NEXT != 0;      // (0: the r02 - r04 placement, kept for same-box A / B builds)
   constexpr bool TN = OPM == 1, TA = OPM == 1, TW = OPM != 0;          // TN: both operands contraction-major; TA / TW: per operand
   constexpr int STG = TN ? 65536 : STAGE, OPBS = TA ? 32768 : OPB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -757,11 +761,25 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
       if (s <= 30 && (s & 1) == 0) frag_read(cur, 1, s >> 1);
       if (s == 36) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       if (DMA && s >= 40 && s <= 100 && (s & 3) == 0) dma_piece(cur, (s - 40) >> 2);
-      if (NEXT && s == 103) {
-        if (DMA) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
-        else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+      if (EARLY_NEXT) {
+        // r05: the next tile's first-half fragments are read at the LDS port's pace — one ds_read_b128 every other slot from slot 64 on,
+        // where the first-half registers are dead (slots 0 .. 63 were their last readers) — instead of 16 back to back behind slot
+        // 103: four waves x 16 KiB in one burst take the port 256 - 512 cycles, of which only the 8 slots up to the tile's end covered 128.
+        // The pieces of tile t + 1 (issued during tile t - 1) must have landed by then: all but the 6 pieces of tile t + 2 issued so far.
+        // Same-box A / B at 128K rows: fc2 13.44 -> 12.96 ms, fc1 + SwiGLU 26.3 -> 25.5, o 4.91 -> 4.81, qkv at 16K 0.859 -> 0.851.
+        // (Going on to ONE barrier per tile — at slot 63, the DMA of tile t + 2 issued behind it — was mixed: fc1 - 3 %, fc2 + 1 %.)
+        if (NEXT && s == 63) {
+          if (DMA) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if (NEXT && s >= 64 && s < 96 && (s & 1) == 0) frag_read(nxt, 0, (s - 64) >> 1);
+      } else {
+        if (NEXT && s == 103) {
+          if (DMA) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
+          else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
+        }
+        if (NEXT && s >= 104 && s < 120) frag_read(nxt, 0, s - 104);
       }
-      if (NEXT && s >= 104 && s < 120) frag_read(nxt, 0, s - 104);
       __builtin_amdgcn_sched_barrier(0);
     };
     // (two loops: the TN fragment assembly sits between them, outside either body — with it inside, the fully unrolled 128-slot
