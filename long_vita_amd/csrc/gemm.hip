@@ -760,6 +760,8 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
       asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[nb][mb]) : "v"(wf[ks][nb]), "v"(af[ks][mb]));
       if (s <= 30 && (s & 1) == 0) frag_read(cur, 1, s >> 1);
       if (s == 36) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      // (r05 null: wave w issuing its piece at slot 40 + 4 j + w instead of all four waves in the same slot — so that the four requests do
+      // not queue in the CU's one texture addresser — is 19 % SLOWER: the 64 wave-dependent scalar branches per tile cost more than the queue.)
       if (DMA && s >= 40 && s <= 100 && (s & 3) == 0) dma_piece(cur, (s - 40) >> 2);
       if (EARLY_NEXT) {
         // r05: the next tile's first-half fragments are read at the LDS port's pace — one ds_read_b128 every other slot from slot 64 on,
