@@ -349,6 +349,8 @@ __device__ __forceinline__ void fwd64v_body(const AttnArgs& p, const unsigned ld
   // ---- main loop: full(par) — tile t sits in S / P buffer par = t & 1 (a compile-time constant): K(t + 3) and V(t + 2) -> their ring slots
   // (those of K(t - 1), V(t - 2): last read before the previous barrier), S(t + 1) -> buffer par ^ 1 under the rest of tile t's softmax, then
   // O += V(t)^T P(t)^T under the start of tile t + 1's softmax.  Tiles 0 .. n - 2 go through full(); the last tile finishes alone. ----------
+  // (r05 null: issuing these pieces one behind every fourth MFMA of the S = K Q^T phase, which pays 1.5 - 3 % in attn64.hip, costs here —
+  // new / r01 kernel on the same box 0.88 - 0.89 with the burst, 0.95 - 0.98 spread: at this head size the phase's slots are full of VALU.)
   int t = 0;
   auto full = [&](int par) __attribute__((always_inline)) {
     const bool more = t + 3 < n_tiles;                 // (n_tiles <= 2: V(1) is still to come)
