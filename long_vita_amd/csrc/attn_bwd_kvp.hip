@@ -57,6 +57,10 @@ constexpr int PF_NONE = 0, PF_FRAG = 1, PF_TR = 2;
 #define KVP_ABL 0
 #endif
 constexpr int ABL = KVP_ABL;
+#ifndef KVP_DMA_SPREAD
+#define KVP_DMA_SPREAD 1
+#endif
+constexpr bool DMA_SPREAD = KVP_DMA_SPREAD != 0;       // (0: the nine pieces of a tile in a burst at the top of the iteration, for A / B builds)
 
 typedef __attribute__((address_space(3))) const bf16x8 lds_bf16x8;
 typedef __attribute__((address_space(3))) const f32x4 lds_f32x4;
@@ -139,6 +143,21 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
     // 64 lse (wave 0) / 64 delta (wave 1) of the tile's rows: lane -> row
     if (wave == 0) vita_lds_dma4(vita_make_rsrc_uniform(p.lse + t.stat), (unsigned)(lane * 4), lds0 + LDS_ST + slot3 * 512);
     if (wave == 1) vita_lds_dma4(vita_make_rsrc_uniform(p.delta + t.stat), (unsigned)(lane * 4), lds0 + LDS_ST + slot3 * 512 + 256);
+  };
+
+  // the same tile one piece at a time (r05, KVP_DMA_SPREAD): piece i = 0 .. 3 Q line i, 4 .. 7 dO line i - 4, 8 the lse / delta row of waves
+  // 0 / 1 — issued one per MFMA slot behind the first MFMAs of a trip instead of nine in a burst behind the barrier (attn64.hip r05)
+  QTileIt it;                                            // the pipeline's cursor (described with the iteration below)
+  int dma_slot3 = 0;
+  auto dma_tile_piece = [&](const QTileIt& t, int i) __attribute__((always_inline)) {
+    unsigned base = lds_w + dma_slot3 * TILEB;
+    asm volatile("" : "+s"(base));
+    if (i < 4) vita_lds_dma16(vita_make_rsrc_uniform(t.qp), off_q[i], base + LDS_Q + i * 1024);
+    else if (i < 8) vita_lds_dma16(vita_make_rsrc_uniform(t.dop), off_do[i - 4], base + LDS_DO + (i - 4) * 1024);
+    else {
+      if (wave == 0) vita_lds_dma4(vita_make_rsrc_uniform(p.lse + t.stat), (unsigned)(lane * 4), lds0 + LDS_ST + dma_slot3 * 512);
+      if (wave == 1) vita_lds_dma4(vita_make_rsrc_uniform(p.delta + t.stat), (unsigned)(lane * 4), lds0 + LDS_ST + dma_slot3 * 512 + 256);
+    }
   };
 
   // ---- iteration space: (query chunks that see the key block) x (64-row tiles) x (query heads of the group, innermost) ------------------
@@ -286,13 +305,16 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
     if (pf == PF_TR) { fr_pre[0] = tr_frag(pf_img, 2 * pf_qh, 0); fr_pre[1] = tr_frag(pf_img, 2 * pf_qh, 1); }
   };
   auto x_group = [&](int par, unsigned img, int qh_n, bool fill, bool use_pre, int pf, unsigned pf_img, int pf_qh, bool pf_stat,
-                     unsigned pf_st, int pf_st_qh) __attribute__((always_inline)) {
+                     unsigned pf_st, int pf_st_qh, const bool dma = false) __attribute__((always_inline)) {
     bf16x8 fr[4];
     if (use_pre) { fr[0] = fr_pre[0]; fr[1] = fr_pre[1]; }
     else { fr[0] = frag(img, 0, qh_n); fr[1] = frag(img, 1, qh_n); }
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int ds = s >> 1, kb = s & 1;
+      if (KVP_DMA_SPREAD == 1 && dma && s >= 1 && s <= 9) dma_tile_piece(it, s - 1);
+      if (KVP_DMA_SPREAD == 2 && dma && (s & 1)) dma_tile_piece(it, s >> 1);
+      if (KVP_DMA_SPREAD == 2 && dma && s == 14) dma_tile_piece(it, 8);
       if (kb == 0 && ds + 2 < 8) fr[(ds + 2) & 3] = frag(img, ds + 2, qh_n);
       if (s == 12) { prefetch(pf, pf_img, pf_qh); if (pf_stat) stat_fetch(pf_st, pf_st_qh); }
       if (ds == 0) {
@@ -321,13 +343,16 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
   // A with FILL: exp2 of pairs 0 .. 7 of buffer par ^ 1 (even slots) and their bf16 pack (odd slots: an exp2 result is never consumed
   // by the next instruction) behind the MFMAs
   auto g_group = [&](int par, unsigned img, int qh, bool fill, bool use_pre, int pf, unsigned pf_img, int pf_qh, bool pf_stat,
-                     unsigned pf_st, int pf_st_qh) __attribute__((always_inline)) {
+                     unsigned pf_st, int pf_st_qh, const bool dma = false) __attribute__((always_inline)) {
     bf16x8 tr[4];
     if (use_pre) { tr[0] = fr_pre[0]; tr[1] = fr_pre[1]; }
     else { tr[0] = tr_frag(img, 2 * qh, 0); tr[1] = tr_frag(img, 2 * qh, 1); }
 #pragma unroll
     for (int s = 0; s < 16; ++s) {
       const int i = s >> 1, kb = s & 1, t2 = i >> 2, db = i & 3;
+      if (KVP_DMA_SPREAD == 1 && dma && s >= 1 && s <= 9) dma_tile_piece(it, s - 1);
+      if (KVP_DMA_SPREAD == 2 && dma && (s & 1)) dma_tile_piece(it, s >> 1);
+      if (KVP_DMA_SPREAD == 2 && dma && s == 14) dma_tile_piece(it, 8);
       if (kb == 0 && i + 2 < 8) tr[(i + 2) & 3] = tr_frag(img, 2 * qh + ((i + 2) >> 2), (i + 2) & 3);
       if (s == 12) { prefetch(pf, pf_img, pf_qh); if (pf_stat) stat_fetch(pf_st, pf_st_qh); }
       const u32x4 pw = {pk[par][kb][t2][0], pk[par][kb][t2][1], pk[par][kb][t2][2], pk[par][kb][t2][3]};
@@ -356,7 +381,6 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
 
   // ---- the tile pipeline's cursor: ONE full iterator (two tiles ahead of the arithmetic: it feeds the LDS-DMA) + the mask rows of the
   // tiles in flight ------------------------------------------------------------------------------------------------------------------------
-  QTileIt it;
   int m_cur = -1, m_nx1 = -1, m_nx2 = -1;                // mask_row of tile t / t + 1 / t + 2
   int s3 = 0, s3n = 1, s3nn = 2, s3n3 = 3;               // ring slots of tiles t, t+1, t+2, t+3
   const unsigned IMG_X = ROLE_B ? LDS_DO : LDS_Q;        // the image this role reads as fragments (dO for dP, Q for S)
@@ -371,7 +395,8 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
   // the longer ring is kept for the context-parallel case, where a tile of a remote chunk may come from further away.
   auto iteration = [&](const bool has1, const bool has3) __attribute__((always_inline)) {
     int m_nx3 = -1;
-    if (has3) dma_tile(it, s3n3);                        // tile t + 3 -> the slot that held tile t - 1 (last read before the previous tile barrier)
+    if (DMA_SPREAD) dma_slot3 = s3n3;
+    else if (has3) dma_tile(it, s3n3);                   // tile t + 3 -> the slot that held tile t - 1 (last read before the previous tile barrier)
     // the cursor's own step (compares, 64-bit adds, two branches: ~15 scalar instructions, more at a chunk boundary) goes BEHIND the first
     // 16-MFMA group of the trip, where the matrix pipe is still draining: at the top of the trip — straight after the barrier, in all four
     // waves at once — it sat on the critical path of every tile (r05 first form: + 5 % SQ_WAVE_CYCLES)
@@ -385,14 +410,14 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
     if (ROLE_B) {
       take_over(0);                                      // P(u), written by A before the last barrier
       stat_finish();                                     // delta of half u (fetched under the previous trip's dK group)
-      x_group(0, x_cur, 1, true, true, PF_TR, g_cur, 0, false, 0, 0);                              // dP(u + 1)  ||  dS(u)
+      x_group(0, x_cur, 1, true, true, PF_TR, g_cur, 0, false, 0, 0, has3);                        // dP(u + 1)  ||  dS(u)  [+ the DMA of tile t + 3]
       step_cursor();
       settle(0);
       g_group(0, g_cur, 0, true, true, has1 ? PF_FRAG : PF_TR, has1 ? x_nxt : g_cur, has1 ? 0 : 1, true, st_cur, 1);   // dK^T += Q^T dS(u)  ||  dS(u), k-step 1
     } else {
       // A holds P(u) packed in pk[0] and the raw (masked) S(u + 1) in buffers 1
       stat_finish();                                     // lse of half u + 1
-      g_group(0, g_cur, 0, true, true, has1 ? PF_FRAG : PF_TR, has1 ? x_nxt : g_cur, has1 ? 0 : 1, false, 0, 0);   // dV^T += dO^T P(u) || exp2 0 .. 7 of S(u + 1)
+      g_group(0, g_cur, 0, true, true, has1 ? PF_FRAG : PF_TR, has1 ? x_nxt : g_cur, has1 ? 0 : 1, false, 0, 0, has3);   // dV^T += dO^T P(u) || exp2 0 .. 7 of S(u + 1)
       step_cursor();
       if (has1) {
         x_group(1, x_nxt, 0, true, true, PF_TR, g_cur, 1, true, st_nxt, 0);                      // S(u + 2) -> buffers 0  ||  pairs 8 .. 15 of S(u + 1)
