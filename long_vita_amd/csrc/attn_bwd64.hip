@@ -20,7 +20,12 @@
 #include "attn_bwd_args.h"
 #include <stdlib.h>
 
+#ifndef DQ64_DMA_SPREAD
+#define DQ64_DMA_SPREAD 1
+#endif
+
 namespace {
+constexpr bool DMA_SPREAD = DQ64_DMA_SPREAD != 0;     // (0: the eight pieces of a tile in a burst at the top of the iteration, for A / B builds)
 
 constexpr int D = 128, KVT = 64, QTILE = 256, ROWB = D * 2, TILEB = KVT * ROWB;       // 16 KiB per image of a 64-key tile
 // r04: ONE image per K tile serves the fragment reads (S^T = K Q^T) and the transposed reads (dQ^T += K^T dS^T): 16-byte slots XOR-ed with
@@ -134,6 +139,15 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(BwdArgs p) {
     }
   };
 
+  // one piece of the same (r05, DQ64_DMA_SPREAD: issued one per MFMA slot behind the first MFMAs of the tile instead of eight in a burst behind
+  // the barrier, as attn64.hip / attn_bwd_kvp.hip): i = 0 .. 3 K line i, 4 .. 7 V line i - 4
+  auto dma_kv_piece = [&](const TileIt& t, int slot3, int i) __attribute__((always_inline)) {
+    unsigned base = lds_w + slot3 * TILEB;
+    asm volatile("" : "+s"(base));
+    if (i < 4) vita_lds_dma16(vita_make_rsrc_uniform(t.kp), off_kf[i], base + LDS_KF + i * 1024);
+    else vita_lds_dma16(vita_make_rsrc_uniform(t.vp), off_vf[i - 4], base + LDS_VF + (i - 4) * 1024);
+  };
+
   // ---- tile iterator (as attn64.hip) ---------------------------------------------------------------------------------------------
   const int kv_tiles_per_chunk = p.chunk_len / KVT;
   auto enter_chunk = [&](TileIt& t) __attribute__((always_inline)) {
@@ -226,7 +240,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(BwdArgs p) {
     }
   };
   // slots 0..15: S^T of the next half (kb_n of the tile at kf) into buffer par ^ 1; FILL: dS(par) behind them
-  auto s_group = [&](int par, unsigned kf, int kb_n, bool fill) __attribute__((always_inline)) {
+  auto s_group = [&](int par, unsigned kf, int kb_n, bool fill, const TileIt* dma_t = nullptr, int dma_slot = 0) __attribute__((always_inline)) {
     bf16x8 fr[4];
     fr[0] = frag(kf, 0, kb_n); fr[1] = frag(kf, 1, kb_n);
 #pragma unroll
@@ -242,6 +256,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(BwdArgs p) {
         sb[par ^ 1][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[ds & 3], qf[qb][ds], sb[par ^ 1][qb], 0, 0, 0);
       }
       if (fill) part2_pair(par, s);
+      if (dma_t && s >= 1 && s <= 8) dma_kv_piece(*dma_t, dma_slot, s - 1);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
@@ -265,8 +280,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(BwdArgs p) {
       __builtin_amdgcn_sched_barrier(0);
     }
   };
-  auto sp_group = [&](int par, unsigned kf, unsigned vf, int kb_n, bool fill, bool masked, int mask_off) __attribute__((always_inline)) {
-    s_group(par, kf, kb_n, fill);
+  auto sp_group = [&](int par, unsigned kf, unsigned vf, int kb_n, bool fill, bool masked, int mask_off, const TileIt* dma_t = nullptr,
+                      int dma_slot = 0) __attribute__((always_inline)) {
+    s_group(par, kf, kb_n, fill, dma_t, dma_slot);
     if (masked) mask_half(par ^ 1, mask_off);          // wave-uniform, diagonal tiles only; between the groups, not inside one
     if constexpr (PACKED) {
       if (mask_off < seg_lo_max) seg_mask_half(par ^ 1, mask_off);
@@ -310,11 +326,11 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(BwdArgs p) {
   int tpar = 0;                                      // t & 1: the K^T ring slot of tile t
   // has1 / has2 (tile t+1 / t+2 exists) are compile-time constants of each call: no data-dependent branch inside the pipeline
   auto iteration = [&](const bool has1, const bool has2) __attribute__((always_inline)) {
-    if (has2) dma_kv(nx2, s3nn);                     // that slot held tile t-1 (last read before the previous barrier)
+    if (!DMA_SPREAD && has2) dma_kv(nx2, s3nn);      // that slot held tile t-1 (last read before the previous barrier)
     const unsigned kf = lds0 + LDS_KF + s3 * TILEB, vf = lds0 + LDS_VF + s3 * TILEB, kt = kf;      // K^T out of tile t's K image
     const unsigned kfn = lds0 + LDS_KF + s3n * TILEB, vfn = lds0 + LDS_VF + s3n * TILEB;
     // trip A: u = 2 t (buffers 0): next half = (tile t, kb 1)
-    sp_group(0, kf, vf, 1, true, needs_mask(cur), cur.j * KVT + 32);
+    sp_group(0, kf, vf, 1, true, needs_mask(cur), cur.j * KVT + 32, DMA_SPREAD && has2 ? &nx2 : nullptr, s3nn);
     dq_group(0, kt, 0, true);
     // trip B: u = 2 t + 1 (buffers 1): next half = (tile t+1, kb 0)
     if (has1) {

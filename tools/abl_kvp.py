@@ -14,11 +14,12 @@ if os.environ.get("ABL_PERIODIC") == "1":        # the DATA of the KVP_ABL = 8 a
 if os.environ.get("ABL_HEADMAJOR") == "1":       # the same values, Q and dO stored head-major ([heads, rows, d]: a tile = 16 KB contiguous) behind strided views
     q = q.transpose(1, 2).contiguous().transpose(1, 2); d_o = d_o.transpose(1, 2).contiguous().transpose(1, 2)
     dq = torch.empty_like(q)
-os.environ["VITA_ATTN_BWD_ONLY"] = "dkv"
+PASS = os.environ.get("ABL_PASS", "dkv")            # "dkv" (attn_bwd_kvp) or "dq" (attn_bwd_dq64)
+os.environ["VITA_ATTN_BWD_ONLY"] = PASS
 f = lambda: ops.flash_attn_bwd(q, k, v, o, d_o, lse, dq5=dq, dk=dk, dv=dv)
 f(); torch.cuda.synchronize()
 ts = []
 for _ in range(5):
     a, b = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     a.record(); f(); b.record(); torch.cuda.synchronize(); ts.append(a.elapsed_time(b))
-print(os.environ.get("VITA_HIP_LIB", "default"), "dkv 16K ms:", " ".join(f"{t:.3f}" for t in sorted(ts)))
+print(os.environ.get("VITA_HIP_LIB", "default"), PASS, "16K ms:", " ".join(f"{t:.3f}" for t in sorted(ts)))
