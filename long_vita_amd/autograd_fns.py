@@ -484,8 +484,8 @@ class FlashAttnFn(torch.autograd.Function):
 
 class FlashAttnNonCausalFn(torch.autograd.Function):
     """The ViT's core attention (flash_attn_func(causal=False), M/core/transformer/dot_product_attention.py:312-329) under autograd.
-    q / k / v [B, S, H, D] views (B = frames, S = 1025, D = 64 for InternViT).  Forward = the non-causal d = 64 kernel.  Backward =
-    the general backward kernels at the NATIVE head size (r04: attn_bwd.hip's kernels are templates on d = 64 | 128; through r03 the
+    q / k / v [B, S, H, D] views (B = frames, S = 1025, D = 64 for InternViT; SigLIP: 729 rows, D = 72 zero-padded to 96 by the caller).  Forward = the non-causal d = 64 kernel.  Backward =
+    the general backward kernels at the NATIVE head size (r04: attn_bwd.hip's kernels are templates on d = 64 | 128, r05: | 96; through r03 the
     d = 64 tensors were zero-padded to 128: twice the flops and bytes), un-masked through their chunk tables (query chunk id 1 > key
     chunk id 0: every key is visible, there is no diagonal) on copies [S_pad, B * H, D] whose sequence is padded to a multiple of 128:
     frames x heads become the kernel's head index (Megatron's [s, b, np, hn] layout), padded KEYS have K = V = 0 (they add nothing to
@@ -505,8 +505,8 @@ class FlashAttnNonCausalFn(torch.autograd.Function):
         if k.shape[2] != H:
             raise NotImplementedError("the ViT attention backward is built for multi-head attention (ng == np)")
         import os
-        native = D == 64 and os.environ.get("VITA_VIT_BWD_PAD128", "0") != "1"      # 1: the r03 path (zero-padded d = 128), A/B timing only
-        sp, dp, nh = -(-S // 128) * 128, (64 if native else 128), B * H
+        native = D in (64, 96) and os.environ.get("VITA_VIT_BWD_PAD128", "0") != "1"      # 1: the r03 path (zero-padded d = 128), A/B timing only
+        sp, dp, nh = -(-S // 128) * 128, (D if native else 128), B * H
 
         def pad(t):                                   # [B, S, H, D] -> [1, S_pad, B * H, 128], zero-filled
             buf = torch.zeros(sp, B, H, dp, dtype=t.dtype, device=t.device)

@@ -49,12 +49,20 @@ __device__ __forceinline__ float swap32_sum(float x) {
 template <int D>
 __device__ __forceinline__ int k_lds_off(int row, int slot) {
   if (D == 128) return row * 256 + ((slot ^ (row & 15)) << 4);
+  else if (D == 96) return row * 192 + (((slot + ((row >> 2) & 3)) % 12) << 4);    // see the note on d = 96 below
   else return row * 128 + ((slot ^ ((row >> 1) & 7)) << 4);
 }
+// d = 96 (r05: SigLIP's head size 72 zero-padded to 96 instead of 128): a row is 192 bytes = 12 slots = 3/4 of a bank period, so an XOR
+// swizzle does not fit.  K fragments (ds_read_b128, 16 consecutive rows per pass): 16-byte unit = (12 row + pslot) mod 16 with pslot =
+// (slot + (row >> 2 & 3)) mod 12 is a permutation of 0 .. 15 over 16 consecutive rows (12 = -4 mod 16: rows r, r + 1, r + 2, r + 3 start
+// 0, 12, 8, 4 units in; the +0 .. 3 rotation of rows r + 4 k fills each group of four; a wrap mod 12 moves a whole group by +4).
+// V^T fragments (ds_read_b64_tr_b16, 4 rows x 64 bytes per 32-lane pass): 192 = -64 mod 256, so rows r .. r + 3 already sit in four
+// different 64-byte windows of the bank period: no swizzle at all.
 // LDS byte offset of V (row, 32-byte chunk c, byte b within chunk)
 template <int D>
 __device__ __forceinline__ int v_lds_off(int row, int chunk, int b) {
   if (D == 128) return row * 256 + ((chunk ^ ((row & 3) << 1)) << 5) + b;
+  else if (D == 96) return row * 192 + (chunk << 5) + b;
   else return row * 128 + ((chunk ^ (row & 2)) << 5) + b;
 }
 
@@ -86,6 +94,7 @@ __global__ __launch_bounds__(512, 2) void flash_fwd_kernel(AttnArgs p) {
   constexpr int SLOTS = ROWB / 16;        // 16-byte slots per row
   constexpr int LD_PER_THR = (KVT * SLOTS) / 512;  // 16-byte loads per thread per operand
   constexpr bool GLDS = !(VARIANT & 1);
+  static_assert(GLDS || (KVT * SLOTS) % 512 == 0, "register staging deals whole 16-byte pieces to 512 threads (d = 96: LDS-DMA only)");
   constexpr int QK_AHEAD = (VARIANT >> 1) & 3;          // 0 = compiler's own schedule
 
   extern __shared__ __attribute__((aligned(16))) char smem[];  // [2][K tile | V tile]
@@ -193,19 +202,25 @@ __global__ __launch_bounds__(512, 2) void flash_fwd_kernel(AttnArgs p) {
 
   // LDS-DMA path: wave w issues pieces q = 0..PIECES-1 of K and of V; piece (w, q) = rows
   // 4*(w*PIECES+q)*(256/ROWB).. of the tile (1 KiB), lane i lands at byte 16*i of the piece.
-  constexpr int PIECES = TILEB / 1024 / 8;             // wave-instructions per operand per wave
-  constexpr int RPP = 1024 / ROWB;                      // tile rows per 1-KiB piece
+  // (d = 96: a piece is 5 1/3 rows and an operand 12 pieces; the 24 pieces of a slot are dealt three per wave — waves 0 .. 3 K, 4 .. 7 V —
+  // and lane i of piece x fills the 16-byte unit u = 64 x + i = (row u / 12, physical slot u % 12).)
+  constexpr bool D96 = D == 96;
+  constexpr int PIECES = D96 ? 3 : TILEB / 1024 / 8;   // wave-instructions per operand per wave (d = 96: per wave, of ITS operand)
+  constexpr int RPP = 1024 / ROWB;                      // tile rows per 1-KiB piece (d = 96: unused)
+  const bool v_wave = D96 && wave >= 4;
   typedef __attribute__((address_space(1))) const void gvoid;
   typedef __attribute__((address_space(3))) void lvoid;
   unsigned dk_off[PIECES], dv_off[PIECES];             // per-lane source offsets (elements) inside a tile
   int d_row[PIECES], d_ks[PIECES], d_vs[PIECES];
 #pragma unroll
   for (int q = 0; q < PIECES; ++q) {
-    const int row = (wave * PIECES + q) * RPP + lane / SLOTS;   // tile row this lane fills
-    const int ps = lane % SLOTS;                                 // physical 16-byte slot in the row
+    const int unit = (D96 ? (wave & 3) * PIECES + q : 0) * 64 + lane;
+    const int row = D96 ? unit / SLOTS : (wave * PIECES + q) * RPP + lane / SLOTS;   // tile row this lane fills
+    const int ps = D96 ? unit % SLOTS : lane % SLOTS;           // physical 16-byte slot in the row
     // logical slot whose data must land at physical slot ps (inverse of the read swizzles)
-    d_ks[q] = (D == 128) ? (ps ^ (row & 15)) : (ps ^ ((row >> 1) & 7));
+    d_ks[q] = (D == 128) ? (ps ^ (row & 15)) : D96 ? (ps + 12 - ((row >> 2) & 3)) % 12 : (ps ^ ((row >> 1) & 7));
     d_vs[q] = (D == 128) ? ((((ps >> 1) ^ ((row & 3) << 1)) << 1) | (ps & 1))
+              : D96      ? ps
                          : ((((ps >> 1) ^ (row & 2)) << 1) | (ps & 1));
     d_row[q] = row;
     dk_off[q] = (unsigned)(row * p.k_rs + d_ks[q] * 8);
@@ -216,7 +231,17 @@ __global__ __launch_bounds__(512, 2) void flash_fwd_kernel(AttnArgs p) {
     const bf16_t* kp = kbase + row0 * p.k_rs;           // wave-uniform bases + 32-bit lane offsets
     const bf16_t* vp = vbase + row0 * p.v_rs;
     const int left = t.rows - t.j * KVT;               // valid rows in this tile (>= 1)
-    if (left >= KVT) {
+    if constexpr (D96) {                               // this wave's three pieces of ITS operand; rows past the end clamped (masked later)
+      const bf16_t* xp = v_wave ? vp : kp;
+      const int64_t rs = v_wave ? p.v_rs : p.k_rs;
+      const unsigned dst = sl + (v_wave ? TILEB : 0) + (wave & 3) * PIECES * 1024;
+#pragma unroll
+      for (int q = 0; q < PIECES; ++q) {
+        const int row = d_row[q] < left ? d_row[q] : left - 1;
+        __builtin_amdgcn_global_load_lds((gvoid*)(xp + (int64_t)row * rs + (v_wave ? d_vs[q] : d_ks[q]) * 8),
+                                         (lvoid*)(uintptr_t)(dst + q * 1024), 16, 0, 0);
+      }
+    } else if (left >= KVT) {
 #pragma unroll
       for (int q = 0; q < PIECES; ++q) {
         const int piece = wave * PIECES + q;
@@ -467,17 +492,21 @@ inline int attn_variant() {
 template <int D, bool CAUSAL>
 int launch_attn(const AttnArgs& a, int64_t nblocks, hipStream_t st) {
   const int v = attn_variant();
-  if ((v & 16) && D == 128 && CAUSAL) {
-    switch (v & 15) {
-      case 1: return launch_attn_v<128, true, 1, true>(a, nblocks, st);
-      case 0: return launch_attn_v<128, true, 0, true>(a, nblocks, st);
-      default: return launch_attn_v<128, true, 6, true>(a, nblocks, st);
+  if constexpr (D == 96) {
+    return launch_attn_v<D, CAUSAL, 6>(a, nblocks, st);                           // LDS-DMA staging only (see the kernel's static_assert)
+  } else {
+    if ((v & 16) && D == 128 && CAUSAL) {
+      switch (v & 15) {
+        case 1: return launch_attn_v<128, true, 1, true>(a, nblocks, st);
+        case 0: return launch_attn_v<128, true, 0, true>(a, nblocks, st);
+        default: return launch_attn_v<128, true, 6, true>(a, nblocks, st);
+      }
     }
-  }
-  switch (v & 15) {
-    case 1: return launch_attn_v<D, CAUSAL, 1>(a, nblocks, st);
-    case 0: return launch_attn_v<D, CAUSAL, 0>(a, nblocks, st);
-    default: return launch_attn_v<D, CAUSAL, 6>(a, nblocks, st);
+    switch (v & 15) {
+      case 1: return launch_attn_v<D, CAUSAL, 1>(a, nblocks, st);
+      case 0: return launch_attn_v<D, CAUSAL, 0>(a, nblocks, st);
+      default: return launch_attn_v<D, CAUSAL, 6>(a, nblocks, st);
+    }
   }
 }
 
@@ -546,7 +575,7 @@ extern "C" int vita_flash_attn_fwd(const vita_attn_params* p, void* stream) {
       p->n_q_chunks <= 0 || p->n_kv_chunks <= 0 || !p->q_chunk_gid || !p->kv_chunk_gid ||
       !p->kv_chunk_row)
     return VITA_ERR_INVALID_ARG;
-  if (p->head_dim != 64 && p->head_dim != 128) return VITA_ERR_UNSUPPORTED;
+  if (p->head_dim != 64 && p->head_dim != 96 && p->head_dim != 128) return VITA_ERR_UNSUPPORTED;
   if (p->n_q_heads % p->n_kv_heads) return VITA_ERR_INVALID_ARG;
   if (p->n_q_chunks > kMaxChunks || p->n_kv_chunks > kMaxChunks) return VITA_ERR_UNSUPPORTED;
   if (p->chunk_len > 0x7fffff00LL) return VITA_ERR_UNSUPPORTED;
@@ -593,5 +622,6 @@ extern "C" int vita_flash_attn_fwd(const vita_attn_params* p, void* stream) {
   // d = 64 non-causal (the vision towers): the same structure at head size 64, ragged rows / keys (attn64v.hip)
   if (vita_attn64v_eligible(a, p->head_dim, p->causal != 0)) return vita_attn64v_launch(a, st);
   if (p->head_dim == 128) return p->causal ? launch_attn<128, true>(a, nblocks, st) : launch_attn<128, false>(a, nblocks, st);
+  if (p->head_dim == 96) return p->causal ? launch_attn<96, true>(a, nblocks, st) : launch_attn<96, false>(a, nblocks, st);
   return p->causal ? launch_attn<64, true>(a, nblocks, st) : launch_attn<64, false>(a, nblocks, st);
 }

@@ -38,8 +38,17 @@ typedef __attribute__((ext_vector_type(8))) short s16x8;
 
 template <int HD> __device__ __forceinline__ int frag_key(int row) { return HD == 128 ? (row & 15) : ((row >> 1) & 7); }
 template <int HD> __device__ __forceinline__ int tr_key(int row) { return HD == 128 ? ((row & 3) << 1) : (((row >> 1) & 1) << 1); }
-template <int HD> __device__ __forceinline__ int frag_off(int row, int slot) { return row * (2 * HD) + ((slot ^ frag_key<HD>(row)) << 4); }
-template <int HD> __device__ __forceinline__ int tr_off(int row, int chunk, int b) { return row * (2 * HD) + ((chunk ^ tr_key<HD>(row)) << 5) + b; }
+// r05: HD = 96 (SigLIP's 72, zero-padded to 96 instead of 128).  A 192-byte row is 3/4 of a bank period and has 12 slots, so the XOR keys do
+// not apply: the fragment layout ROTATES the slot by (row >> 2) & 3 (mod 12), the transposed layout needs no swizzle (derivation: attn.hip).
+template <int HD> __device__ __forceinline__ int frag_slot(int row, int slot) {          // logical -> physical 16-byte slot
+  return HD == 96 ? (slot + ((row >> 2) & 3)) % 12 : (slot ^ frag_key<HD>(row));
+}
+template <int HD> __device__ __forceinline__ int frag_slot_inv(int row, int ps) {        // physical -> logical (the XOR forms are involutions)
+  return HD == 96 ? (ps + 12 - ((row >> 2) & 3)) % 12 : (ps ^ frag_key<HD>(row));
+}
+template <int HD> __device__ __forceinline__ int tr_chunk(int row, int chunk) { return HD == 96 ? chunk : (chunk ^ tr_key<HD>(row)); }
+template <int HD> __device__ __forceinline__ int frag_off(int row, int slot) { return row * (2 * HD) + (frag_slot<HD>(row, slot) << 4); }
+template <int HD> __device__ __forceinline__ int tr_off(int row, int chunk, int b) { return row * (2 * HD) + (tr_chunk<HD>(row, chunk) << 5) + b; }
 
 // DMA one 1-KiB piece (4 rows x 256 B) of a [rows][128] bf16 tile into LDS; tile = descriptor of its first row (wave-uniform),
 // rows_valid = rows that exist (later ones are clamped, masked afterwards); lane -> (row piece*4 + lane/16, physical 16-B slot
@@ -49,10 +58,11 @@ template <int HD> __device__ __forceinline__ int tr_off(int row, int chunk, int 
 template <int HD>
 __device__ __forceinline__ void dma_piece(vita_rsrc_t tile, int64_t rs, int rows_valid, int piece, int lane, bool tr,
                                           unsigned lds_dst) {
-  constexpr int LPR = HD / 8;                              // lanes (16-byte slots) per row: a 1-KiB piece is 64 / LPR rows
-  int row = piece * (64 / LPR) + lane / LPR;
-  const int ps = lane % LPR;
-  const int ls = tr ? ((((ps >> 1) ^ tr_key<HD>(row)) << 1) | (ps & 1)) : (ps ^ frag_key<HD>(row));
+  constexpr int LPR = HD / 8;                              // lanes (16-byte slots) per row: a 1-KiB piece is 64 / LPR rows (HD = 96: 5 1/3)
+  const int unit = piece * 64 + lane;                      // 16-byte unit of the image this lane fills
+  const int row = unit / LPR;
+  const int ps = unit % LPR;
+  const int ls = tr ? ((tr_chunk<HD>(row, ps >> 1) << 1) | (ps & 1)) : frag_slot_inv<HD>(row, ps);
   const int r = row < rows_valid ? row : rows_valid - 1;
   vita_lds_dma16(tile, (unsigned)(r * rs * 2 + ls * 16), (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_dst + piece * 1024)));
 }
@@ -256,6 +266,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
 
   // the inline-asm MFMAs are invisible to the compiler's hazard tracking: wait for the matrix pipe, accumulators tied to the wait
   if constexpr (NDB == 4) asm volatile("s_nop 15\n\ts_nop 15" : "+a"(dq_acc[0]), "+a"(dq_acc[1]), "+a"(dq_acc[2]), "+a"(dq_acc[3]));
+  else if constexpr (NDB == 3) asm volatile("s_nop 15\n\ts_nop 15" : "+a"(dq_acc[0]), "+a"(dq_acc[1]), "+a"(dq_acc[2]));
   else asm volatile("s_nop 15\n\ts_nop 15" : "+a"(dq_acc[0]), "+a"(dq_acc[1]));
   bf16_t* op = p.dq + q_row * p.dq_rs + (int64_t)kvh * p.dq_gs + (int64_t)hq * p.dq_hs;
 #pragma unroll
@@ -283,8 +294,10 @@ template <int HD>
 __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
   constexpr int ROWB = 2 * HD, NDS = HD / 16, NDB = HD / 32;
   constexpr int KV_STAGE = 4 * QT_KV * ROWB + 2048;
-  constexpr int PPW = QT_KV * ROWB / 1024 / 4;             // 1-KiB pieces of a 32-row image per wave (2 / 1)
-  constexpr int KV_DMA_PER_STAGE = 4 * PPW + 2;            // LDS-DMA instructions a wave issues per stage (4 images + two statistics pieces)
+  constexpr int NPI = QT_KV * ROWB / 1024;                 // 1-KiB pieces of a 32-row image (8 / 6 / 4)
+  constexpr bool WAVE_IMAGE = NPI % 4 != 0;                // HD = 96: six pieces do not deal to four waves — wave w stages image w whole
+  constexpr int PPW = NPI / 4;                             // pieces of an image per wave otherwise (2 / 1)
+  constexpr int KV_DMA_PER_STAGE = (WAVE_IMAGE ? NPI : 4 * PPW) + 2;   // LDS-DMA instructions a wave issues per stage (+ two statistics pieces)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
   const int tid = threadIdx.x, lane = tid & 63;
@@ -337,14 +350,21 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
     const int64_t row0 = (int64_t)qc * p.chunk_len + qt * QT_KV;
     const vita_rsrc_t qb = vita_make_rsrc(p.q + (int64_t)kvh * p.q_gs + (int64_t)hq * p.q_hs + row0 * p.q_rs);
     const vita_rsrc_t db = vita_make_rsrc(p.d_o + (int64_t)head * p.do_hs + row0 * p.do_rs);
-    // 8 (HD = 64: 4) pieces per 32-row image: 4 waves x PPW
+    if constexpr (WAVE_IMAGE) {                          // images in LDS order: Q frag, Q tr, dO frag, dO tr = waves 0 .. 3
+      const vita_rsrc_t src = wave < 2 ? qb : db;
+      const int64_t rs = wave < 2 ? p.q_rs : p.do_rs;
 #pragma unroll
-    for (int q = 0; q < PPW; ++q) {
-      const int piece = wave * PPW + q;
-      dma_piece<HD>(qb, p.q_rs, QT_KV, piece, lane, false, sl);
-      dma_piece<HD>(qb, p.q_rs, QT_KV, piece, lane, true, sl + QT_KV * ROWB);
-      dma_piece<HD>(db, p.do_rs, QT_KV, piece, lane, false, sl + 2 * QT_KV * ROWB);
-      dma_piece<HD>(db, p.do_rs, QT_KV, piece, lane, true, sl + 3 * QT_KV * ROWB);
+      for (int q = 0; q < NPI; ++q) dma_piece<HD>(src, rs, QT_KV, q, lane, (wave & 1) != 0, sl + wave * QT_KV * ROWB);
+    } else {
+      // 8 (HD = 64: 4) pieces per 32-row image: 4 waves x PPW
+#pragma unroll
+      for (int q = 0; q < PPW; ++q) {
+        const int piece = wave * PPW + q;
+        dma_piece<HD>(qb, p.q_rs, QT_KV, piece, lane, false, sl);
+        dma_piece<HD>(qb, p.q_rs, QT_KV, piece, lane, true, sl + QT_KV * ROWB);
+        dma_piece<HD>(db, p.do_rs, QT_KV, piece, lane, false, sl + 2 * QT_KV * ROWB);
+        dma_piece<HD>(db, p.do_rs, QT_KV, piece, lane, true, sl + 3 * QT_KV * ROWB);
+      }
     }
     // statistics of the 32 rows, by DMA as well (no register round trip, so nothing waits on it).  Every wave issues two pieces,
     // so that one counted vmcnt serves all waves: wave 0 the ones that are read (lse at +0, delta at +256), wave 1 the segment starts
@@ -470,6 +490,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
   if constexpr (NDB == 4)
     asm volatile("s_nop 15\n\ts_nop 15" : "+a"(dk_acc[0]), "+a"(dk_acc[1]), "+a"(dk_acc[2]), "+a"(dk_acc[3]), "+a"(dv_acc[0]),
                  "+a"(dv_acc[1]), "+a"(dv_acc[2]), "+a"(dv_acc[3]));
+  else if constexpr (NDB == 3)
+    asm volatile("s_nop 15\n\ts_nop 15" : "+a"(dk_acc[0]), "+a"(dk_acc[1]), "+a"(dk_acc[2]), "+a"(dv_acc[0]), "+a"(dv_acc[1]), "+a"(dv_acc[2]));
   else asm volatile("s_nop 15\n\ts_nop 15" : "+a"(dk_acc[0]), "+a"(dk_acc[1]), "+a"(dv_acc[0]), "+a"(dv_acc[1]));
   const int64_t orow = k_row0 + wave * 32 + l31;
   bf16_t* okp = p.dk + orow * p.dk_rs + (int64_t)kvh * p.dk_hs;
@@ -502,7 +524,7 @@ extern "C" int vita_flash_attn_bwd_parts(const vita_attn_bwd_params* p, int part
   if (!(parts & (VITA_ATTN_BWD_DQ | VITA_ATTN_BWD_DKV))) return VITA_ERR_INVALID_ARG;
   if (!p || !p->q || !p->k || !p->v || !p->d_o || !p->lse || !p->delta) return VITA_ERR_INVALID_ARG;
   if (((parts & VITA_ATTN_BWD_DQ) && !p->dq) || ((parts & VITA_ATTN_BWD_DKV) && (!p->dk || !p->dv))) return VITA_ERR_INVALID_ARG;
-  if (p->head_dim != 128 && p->head_dim != 64) return VITA_ERR_UNSUPPORTED;
+  if (p->head_dim != 128 && p->head_dim != 96 && p->head_dim != 64) return VITA_ERR_UNSUPPORTED;
   if (p->n_q_heads <= 0 || p->n_kv_heads <= 0 || p->n_q_heads % p->n_kv_heads) return VITA_ERR_INVALID_ARG;
   if (p->n_q_chunks <= 0 || p->n_kv_chunks <= 0 || p->n_q_chunks > kMaxChunks || p->n_kv_chunks > kMaxChunks)
     return VITA_ERR_UNSUPPORTED;
@@ -543,6 +565,8 @@ extern "C" int vita_flash_attn_bwd_parts(const vita_attn_bwd_params* p, int part
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<128>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_dq);
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<64>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dq_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_dq);
+    (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&attn_bwd_dkv_kernel<96>), hipFuncAttributeMaxDynamicSharedMemorySize, lds_kv);
   });
   const int64_t n_dq = (int64_t)p->n_q_heads * p->n_q_chunks * (p->chunk_len / QT_DQ);
   const int64_t n_kv = (int64_t)p->n_kv_heads * p->n_kv_chunks * (p->chunk_len / KT_KV);
@@ -557,6 +581,8 @@ extern "C" int vita_flash_attn_bwd_parts(const vita_attn_bwd_params* p, int part
       if (rc != VITA_OK) return rc;
     } else if (p->head_dim == 64) {
       hipLaunchKernelGGL(attn_bwd_dkv_kernel<64>, dim3((unsigned)n_kv), dim3(256), lds_kv, st, a);
+    } else if (p->head_dim == 96) {
+      hipLaunchKernelGGL(attn_bwd_dkv_kernel<96>, dim3((unsigned)n_kv), dim3(256), lds_kv, st, a);
     } else {
       hipLaunchKernelGGL(attn_bwd_dkv_kernel<128>, dim3((unsigned)n_kv), dim3(256), lds_kv, st, a);
     }
@@ -567,6 +593,8 @@ extern "C" int vita_flash_attn_bwd_parts(const vita_attn_bwd_params* p, int part
       if (rc != VITA_OK) return rc;
     } else if (p->head_dim == 64) {
       hipLaunchKernelGGL(attn_bwd_dq_kernel<64>, dim3((unsigned)n_dq), dim3(256), lds_dq, st, a);
+    } else if (p->head_dim == 96) {
+      hipLaunchKernelGGL(attn_bwd_dq_kernel<96>, dim3((unsigned)n_dq), dim3(256), lds_dq, st, a);
     } else {
       hipLaunchKernelGGL(attn_bwd_dq_kernel<128>, dim3((unsigned)n_dq), dim3(256), lds_dq, st, a);
     }

@@ -18,6 +18,8 @@ import torch.distributed as dist
 
 from . import ops, parallel_state as mpu, recompute_cache, training_utils
 
+HEAD_SIZES = (64, 96, 128)         # head sizes the attention kernels are instantiated for (attn.hip, attn_bwd.hip)
+
 
 class HipDotProductAttention(torch.nn.Module):
     """`core_attention` submodule for the layer specs (gpt_layer_specs.py): Megatron's constructor
@@ -55,7 +57,7 @@ class HipDotProductAttention(torch.nn.Module):
         sq, b, np_, hn = query.shape
         if not self._impl.causal:                      # the ViT layers (AttnMaskType.no_mask): batch = frames
             scale = self._impl.softmax_scale if self._impl.softmax_scale is not None else 1.0 / hn ** 0.5
-            q, k, v = (_pad_head_dim(t.transpose(0, 1)) for t in (query, key, value))      # SigLIP: 72 -> 128 zero columns
+            q, k, v = (_pad_head_dim(t.transpose(0, 1)) for t in (query, key, value))      # SigLIP: 72 -> 96 zero columns
             out = FlashAttnNonCausalFn.apply(q, k, v, scale)[..., :hn]
             return out.transpose(0, 1).reshape(sq, b, np_ * hn)
         if b != 1:
@@ -94,15 +96,15 @@ class HipDotProductAttention(torch.nn.Module):
 
 
 def _pad_head_dim(t: torch.Tensor) -> torch.Tensor:
-    """[..., hn] -> [..., 64 | 128] with zero columns when hn is neither (SigLIP-400M: kv_channels = 72, M/pretrain_long_vita.py:276):
-    zero columns of Q / K add nothing to a score, zero columns of V give zero output columns, which the caller drops; the softmax
-    scale stays 1 / sqrt(hn).  A no-op for the sizes the kernels tile."""
+    """[..., hn] -> [..., 64 | 96 | 128] with zero columns when hn is none of them (SigLIP-400M: kv_channels = 72 -> 96,
+    M/pretrain_long_vita.py:276; through r04: -> 128): zero columns of Q / K add nothing to a score, zero columns of V give zero output
+    columns, which the caller drops; the softmax scale stays 1 / sqrt(hn).  A no-op for the sizes the kernels tile."""
     hn = t.shape[-1]
-    if hn in (64, 128):
+    if hn in HEAD_SIZES:
         return t
     if hn > 128:
-        raise NotImplementedError(f"head size {hn}: the attention kernels are built for 64 and 128 (smaller sizes are zero-padded)")
-    return torch.nn.functional.pad(t, (0, (64 if hn < 64 else 128) - hn))
+        raise NotImplementedError(f"head size {hn}: the attention kernels are built for 64, 96 and 128 (smaller sizes are zero-padded)")
+    return torch.nn.functional.pad(t, (0, min(d for d in HEAD_SIZES if d > hn) - hn))
 
 
 class DotProductAttention:
@@ -154,7 +156,7 @@ class DotProductAttention:
             seg = training_utils.get_packed_segments() if self.causal else None
             if seg is not None and (b != 1 or cp > 1):
                 raise NotImplementedError("packed samples run micro-batch 1, CP = 1 (reference stage 2)")
-            if not self.causal and hn not in (64, 128):
+            if not self.causal and hn not in HEAD_SIZES:
                 scale = self.softmax_scale if self.softmax_scale is not None else 1.0 / hn ** 0.5
                 out = ops.flash_attn(_pad_head_dim(q), _pad_head_dim(k), _pad_head_dim(v), causal=False, softmax_scale=scale)[..., :hn]
             else:

@@ -44,8 +44,8 @@ class VisionConfig:
         return cls(**args)
 
     @property
-    def head_dim_pad(self):            # the flash kernel runs d = 64 / 128: other head sizes are zero-padded at load time
-        return self.head_dim if self.head_dim in (64, 128) else (64 if self.head_dim < 64 else 128)
+    def head_dim_pad(self):            # the flash kernel runs d = 64 / 96 / 128: other head sizes are zero-padded at load time
+        return min(d for d in (64, 96, 128) if d >= self.head_dim)
 
     @property
     def ffn_pad(self):                 # fc2's K must be a multiple of the GEMM's BK = 64
@@ -67,7 +67,7 @@ class MegatronVisionModel:
     @classmethod
     def from_oracle_layout(cls, cfg: VisionConfig, p: dict, device="cuda"):
         """p: dict produced by oracle.vit.init_vit_params / checkpoint.hf_vit_to_params (plain tensors, Megatron layout).
-        Head size and FFN width are zero-padded to what the kernels tile (72 -> 128, 4304 -> 4352 for SigLIP): padded q / k
+        Head size and FFN width are zero-padded to what the kernels tile (72 -> 96 [r05; 128 before], 4304 -> 4352 for SigLIP): padded q / k
         columns contribute 0 to the scores, padded v columns produce 0 context that meets zero proj_w columns, padded
         fc1 rows give gelu(0) = 0 that meets zero fc2_w columns — the function is unchanged."""
         def d(t):

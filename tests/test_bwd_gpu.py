@@ -131,9 +131,9 @@ def _attn_grads_ref(q, k, v, d_o, q_pos=None, k_pos=None):
     return o.detach(), qf.grad, kf.grad, vf.grad
 
 
-@pytest.mark.parametrize("S,Hq,Hkv", [(128, 2, 1), (256, 5, 1), (512, 10, 2), (1024, 5, 1)])
-def test_flash_attn_bwd_single_chunk(ops, S, Hq, Hkv):
-    Dh = 128
+@pytest.mark.parametrize("S,Hq,Hkv,Dh", [(128, 2, 1, 128), (256, 5, 1, 128), (512, 10, 2, 128), (1024, 5, 1, 128), (384, 4, 2, 96), (1024, 3, 3, 96),
+                                        (256, 4, 2, 64)])
+def test_flash_attn_bwd_single_chunk(ops, S, Hq, Hkv, Dh):
     q = torch.randn(1, S, Hq, Dh, generator=g(20)).bfloat16()
     k = torch.randn(1, S, Hkv, Dh, generator=g(21)).bfloat16()
     v = torch.randn(1, S, Hkv, Dh, generator=g(22)).bfloat16()
@@ -309,7 +309,7 @@ def test_gelu_fwd_and_bias_scale_residual(ops):
             tol("d_scale", rel_l2(d_s, sb.grad), 6e-3)
 
 
-@pytest.mark.parametrize("B,S,H,D", [(3, 1025, 16, 64), (2, 1024, 4, 64), (1, 300, 2, 128)])
+@pytest.mark.parametrize("B,S,H,D", [(3, 1025, 16, 64), (2, 1024, 4, 64), (1, 300, 2, 128), (2, 729, 16, 96), (1, 1024, 3, 96), (1, 200, 2, 96)])
 def test_non_causal_attention_backward_through_the_padded_chunk_tables(ops, B, S, H, D):
     """autograd_fns.FlashAttnNonCausalFn: the ViT's attention gradient from the d = 128 causal backward kernels, un-masked through
     their chunk tables on zero-padded [S_pad, B * H, 128] copies, vs fp32 autograd through the oracle (non-causal)."""

@@ -280,9 +280,11 @@ def _attn_ref(q, k, v, causal, q_pos=None, k_pos=None):
 @pytest.mark.parametrize("S,Hq,Hkv,D,causal", [
     (256, 5, 1, 128, True), (512, 10, 2, 128, True), (1024, 40, 8, 128, True), (320, 5, 1, 128, True),
     (1025, 16, 16, 64, False), (192, 4, 4, 64, False), (2048, 5, 1, 128, True), (704, 2, 2, 128, False),
+    # r05: head size 96 (SigLIP's 72 zero-padded): 12-slot rows, rotated LDS layout; ragged rows and keys, GQA, causal
+    (729, 16, 16, 96, False), (1024, 4, 4, 96, False), (333, 6, 2, 96, False), (640, 4, 2, 96, True), (61, 2, 2, 96, False),
 ])
 def test_flash_attention_single_chunk(ops, S, Hq, Hkv, D, causal):
-    B = 2 if D == 64 else 1
+    B = 2 if D in (64, 96) else 1
     q = torch.randn(B, S, Hq, D, generator=g(30)).bfloat16()
     k = torch.randn(B, S, Hkv, D, generator=g(31)).bfloat16()
     v = torch.randn(B, S, Hkv, D, generator=g(32)).bfloat16()
