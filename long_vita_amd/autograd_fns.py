@@ -505,10 +505,18 @@ class FlashAttnNonCausalFn(torch.autograd.Function):
         if k.shape[2] != H:
             raise NotImplementedError("the ViT attention backward is built for multi-head attention (ng == np)")
         import os
-        native = D in (64, 96) and os.environ.get("VITA_VIT_BWD_PAD128", "0") != "1"      # 1: the r03 path (zero-padded d = 128), A/B timing only
-        sp, dp, nh = -(-S // 128) * 128, (D if native else 128), B * H
+        mode = os.environ.get("VITA_VIT_BWD_PAD128", "0")                 # developer A / B: 1 = the r03 path (everything zero-padded to d = 128)
+        sp, nh = -(-S // 128) * 128, B * H
+        # Head size of the padded copies (dp) and of the dQ pass (dq_d).  d = 64: both general kernels at 64.  d = 96 (SigLIP, r05): measured at
+        # 64 frames x 16 heads x 1024 tokens — dQ (general kernel) 1.43 ms at 128 -> 1.20 ms at 96; dK + dV 1.30 ms at 128 (the pair kernel of
+        # attn_bwd_kvp.hip takes whole 256-row sequences at d = 128) against 2.08 ms through the general kernel at 96.  So: copies padded to 128
+        # for the pair kernel whenever it is eligible, and the dQ pass reads the SAME buffers as d = 96 views (strides are free, the columns
+        # 96 .. 127 are zero and are not read); otherwise both general kernels at 96.
+        pair = D == 96 and sp % 256 == 0 and mode != "96"
+        dp = 128 if (mode == "1" or D not in (64, 96) or pair) else D
+        dq_d = D if (D in (64, 96) and mode != "1") else dp
 
-        def pad(t):                                   # [B, S, H, D] -> [1, S_pad, B * H, 128], zero-filled
+        def pad(t):                                   # [B, S, H, D] -> [1, S_pad, B * H, dp], zero-filled
             buf = torch.zeros(sp, B, H, dp, dtype=t.dtype, device=t.device)
             buf[:S, :, :, :D].copy_(t.transpose(0, 1))
             return buf.view(1, sp, nh, dp)
@@ -517,8 +525,14 @@ class FlashAttnNonCausalFn(torch.autograd.Function):
         lse_p = torch.full((1, nh, sp), float("inf"), dtype=torch.float32, device=q.device)
         lse_p[0, :, :S].copy_(lse.reshape(nh, S))
         scale = ctx.softmax_scale if ctx.softmax_scale is not None else 1.0 / (D ** 0.5)
-        dq, dk, dv = ops.flash_attn_bwd(qp, kp, vp, op_, dop, lse_p, chunk_len=sp, q_chunk_gid=[1], kv_chunk_gid=[0], kv_chunk_row=[0],
-                                        softmax_scale=scale)
+        geo = dict(chunk_len=sp, q_chunk_gid=[1], kv_chunk_gid=[0], kv_chunk_row=[0], softmax_scale=scale)
+        if dq_d == dp:
+            dq, dk, dv = ops.flash_attn_bwd(qp, kp, vp, op_, dop, lse_p, **geo)
+        else:
+            _, dk, dv, delta = ops.flash_attn_bwd(qp, kp, vp, op_, dop, lse_p, parts=ops.ATTN_BWD_DKV, **geo)
+            dq = torch.empty_like(qp)                 # columns dq_d .. dp - 1 are never written and never read (unpad takes :D)
+            ops.flash_attn_bwd(qp[..., :dq_d], kp[..., :dq_d], vp[..., :dq_d], op_[..., :dq_d], dop[..., :dq_d], lse_p, parts=ops.ATTN_BWD_DQ,
+                               delta=delta, dq5=dq[..., :dq_d], **geo)
 
         def unpad(t):
             return t.view(sp, B, H, dp)[:S, :, :, :D].transpose(0, 1)

@@ -56,15 +56,19 @@ template <int HD> __device__ __forceinline__ int tr_off(int row, int chunk, int 
 // builtin hipcc put an s_waitcnt vmcnt(0) in front of the first ds_read_b64_tr_b16 of every tile — the prefetch of the next tile was
 // a blocking load, the reason the round-1 kernels ran at 0.39 / 0.52 PFLOP/s.
 template <int HD>
-__device__ __forceinline__ void dma_piece(vita_rsrc_t tile, int64_t rs, int rows_valid, int piece, int lane, bool tr,
-                                          unsigned lds_dst) {
+__device__ __forceinline__ unsigned dma_piece_voff(int64_t rs, int rows_valid, int piece, int lane, bool tr) {   // the lane's source offset (bytes)
   constexpr int LPR = HD / 8;                              // lanes (16-byte slots) per row: a 1-KiB piece is 64 / LPR rows (HD = 96: 5 1/3)
   const int unit = piece * 64 + lane;                      // 16-byte unit of the image this lane fills
   const int row = unit / LPR;
   const int ps = unit % LPR;
   const int ls = tr ? ((tr_chunk<HD>(row, ps >> 1) << 1) | (ps & 1)) : frag_slot_inv<HD>(row, ps);
   const int r = row < rows_valid ? row : rows_valid - 1;
-  vita_lds_dma16(tile, (unsigned)(r * rs * 2 + ls * 16), (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_dst + piece * 1024)));
+  return (unsigned)(r * rs * 2 + ls * 16);
+}
+template <int HD>
+__device__ __forceinline__ void dma_piece(vita_rsrc_t tile, int64_t rs, int rows_valid, int piece, int lane, bool tr,
+                                          unsigned lds_dst) {
+  vita_lds_dma16(tile, dma_piece_voff<HD>(rs, rows_valid, piece, lane, tr), (unsigned)__builtin_amdgcn_readfirstlane((int)(lds_dst + piece * 1024)));
 }
 // 64 floats / ints: lane -> element lane % 32 of a wave-uniform array (both halves of the wave fetch the same 32)
 __device__ __forceinline__ void dma_words32(vita_rsrc_t base, int lane, unsigned lds_dst) {
@@ -169,18 +173,35 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq_kernel(BwdArgs p) {
     if (gk > gq) return 0;
     return min(all, q_last_wg / KT_DQ + 1);
   };
+  // HD = 96: the lane's source offsets hold divisions by 12 — computed once (every tile is whole: chunk_len % 128 == 0)
+  unsigned pre_kf[PPW], pre_kt[PPW], pre_vf[PPW];
+  if constexpr (HD == 96) {
+#pragma unroll
+    for (int q = 0; q < PPW; ++q) {
+      pre_kf[q] = dma_piece_voff<HD>(p.k_rs, KT_DQ, wave * PPW + q, lane, false);
+      pre_kt[q] = dma_piece_voff<HD>(p.k_rs, KT_DQ, wave * PPW + q, lane, true);
+      pre_vf[q] = dma_piece_voff<HD>(p.v_rs, KT_DQ, wave * PPW + q, lane, false);
+    }
+  }
   auto stage_tile = [&](int c, int j, unsigned sl) __attribute__((always_inline)) {
     const int64_t row0 = p.kv_row[c] + (int64_t)j * KT_DQ;
     const int valid = p.chunk_len - j * KT_DQ;
     const vita_rsrc_t kt0 = vita_make_rsrc(kbase + row0 * p.k_rs);
     const vita_rsrc_t vt0 = vita_make_rsrc(vbase + row0 * p.v_rs);
-    // 16 (HD = 64: 8) pieces per 64-row image; 4 waves -> PPW pieces each per image
+    // 16 (HD = 96: 12, HD = 64: 8) pieces per 64-row image; 4 waves -> PPW pieces each per image
 #pragma unroll
     for (int q = 0; q < PPW; ++q) {
       const int piece = wave * PPW + q;
-      dma_piece<HD>(kt0, p.k_rs, valid, piece, lane, false, sl);
-      dma_piece<HD>(kt0, p.k_rs, valid, piece, lane, true, sl + KT_DQ * ROWB);
-      dma_piece<HD>(vt0, p.v_rs, valid, piece, lane, false, sl + 2 * KT_DQ * ROWB);
+      if constexpr (HD == 96) {
+        const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(sl + piece * 1024));
+        vita_lds_dma16(kt0, pre_kf[q], dst);
+        vita_lds_dma16(kt0, pre_kt[q], dst + KT_DQ * ROWB);
+        vita_lds_dma16(vt0, pre_vf[q], dst + 2 * KT_DQ * ROWB);
+      } else {
+        dma_piece<HD>(kt0, p.k_rs, valid, piece, lane, false, sl);
+        dma_piece<HD>(kt0, p.k_rs, valid, piece, lane, true, sl + KT_DQ * ROWB);
+        dma_piece<HD>(vt0, p.v_rs, valid, piece, lane, false, sl + 2 * KT_DQ * ROWB);
+      }
     }
   };
 
@@ -345,6 +366,12 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
     if (gq < gk) return qt_per_chunk;
     return k_off / QT_KV;                               // rows >= first key of the workgroup
   };
+  // HD = 96 (wave w stages image w): the lane's source offsets hold divisions by 12 — computed once
+  unsigned pre_img[WAVE_IMAGE ? NPI : 1];
+  if constexpr (WAVE_IMAGE) {
+#pragma unroll
+    for (int q = 0; q < NPI; ++q) pre_img[q] = dma_piece_voff<HD>(wave < 2 ? p.q_rs : p.do_rs, QT_KV, q, lane, (wave & 1) != 0);
+  }
   auto stage_q = [&](int hq, int qc, int qt, unsigned sl) __attribute__((always_inline)) {
     const int head = kvh * G + hq;
     const int64_t row0 = (int64_t)qc * p.chunk_len + qt * QT_KV;
@@ -352,9 +379,9 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dkv_kernel(BwdArgs p) {
     const vita_rsrc_t db = vita_make_rsrc(p.d_o + (int64_t)head * p.do_hs + row0 * p.do_rs);
     if constexpr (WAVE_IMAGE) {                          // images in LDS order: Q frag, Q tr, dO frag, dO tr = waves 0 .. 3
       const vita_rsrc_t src = wave < 2 ? qb : db;
-      const int64_t rs = wave < 2 ? p.q_rs : p.do_rs;
+      const unsigned dst = (unsigned)__builtin_amdgcn_readfirstlane((int)(sl + wave * QT_KV * ROWB));
 #pragma unroll
-      for (int q = 0; q < NPI; ++q) dma_piece<HD>(src, rs, QT_KV, q, lane, (wave & 1) != 0, sl + wave * QT_KV * ROWB);
+      for (int q = 0; q < NPI; ++q) vita_lds_dma16(src, pre_img[q], dst + q * 1024);
     } else {
       // 8 (HD = 64: 4) pieces per 32-row image: 4 waves x PPW
 #pragma unroll

@@ -309,10 +309,12 @@ def test_gelu_fwd_and_bias_scale_residual(ops):
             tol("d_scale", rel_l2(d_s, sb.grad), 6e-3)
 
 
-@pytest.mark.parametrize("B,S,H,D", [(3, 1025, 16, 64), (2, 1024, 4, 64), (1, 300, 2, 128), (2, 729, 16, 96), (1, 1024, 3, 96), (1, 200, 2, 96)])
+@pytest.mark.parametrize("B,S,H,D", [(3, 1025, 16, 64), (2, 1024, 4, 64), (1, 300, 2, 128), (2, 729, 16, 96), (1, 1024, 3, 96), (1, 300, 2, 96)])
 def test_non_causal_attention_backward_through_the_padded_chunk_tables(ops, B, S, H, D):
-    """autograd_fns.FlashAttnNonCausalFn: the ViT's attention gradient from the d = 128 causal backward kernels, un-masked through
-    their chunk tables on zero-padded [S_pad, B * H, 128] copies, vs fp32 autograd through the oracle (non-causal)."""
+    """autograd_fns.FlashAttnNonCausalFn: the ViT's attention gradient from the causal backward kernels, un-masked through their chunk
+    tables on zero-padded [S_pad, B * H, d] copies, vs fp32 autograd through the oracle (non-causal).  d = 96 (SigLIP's 72, padded): S_pad a
+    multiple of 256 (729 -> 768, 1024) takes the pair kernel at d = 128 for dK + dV and the d = 96 general kernel on views of the same buffers
+    for dQ; S_pad = 384 takes both general kernels at d = 96."""
     from long_vita_amd.autograd_fns import FlashAttnNonCausalFn
     q = torch.randn(B, S, H, D, generator=g(50)).bfloat16()
     k = torch.randn(B, S, H, D, generator=g(51)).bfloat16()

@@ -38,6 +38,19 @@ for D in (96, 128):
     rows.append({"what": "attention backward (copies + delta + dK/dV + dQ)", "frames": B, "tokens": S, "heads": H, "head_size": hn,
                  "padded_to": D, "ms_best": best, "ms_median": med, "algorithmic_pflops": 2.5 * flops / best / 1e12})
     del qd, kd, vd, out
+    # the two backward kernels alone, on the [1, S, frames x heads, D] layout the autograd path builds (query chunk id 1 > key chunk id 0: no mask)
+    qh, kh, vh, dh = (t.transpose(0, 1).reshape(1, S, B * H, D).contiguous() for t in (q, k, v, d_o))
+    o, lse = ops.flash_attn(qh, kh, vh, causal=False, softmax_scale=scale, return_lse=True)
+    dq, dk, dv = torch.empty_like(qh), torch.empty_like(kh), torch.empty_like(vh)
+    for part, name in ((ops.ATTN_BWD_DKV, "dK + dV kernel"), (ops.ATTN_BWD_DQ, "dQ kernel")):
+        _, _, _, delta = ops.flash_attn_bwd(qh, kh, vh, o, dh, lse, chunk_len=S, q_chunk_gid=[1], kv_chunk_gid=[0], kv_chunk_row=[0], softmax_scale=scale,
+                                            dq5=dq, dk=dk, dv=dv, parts=part)
+        best, med = timed(lambda: ops.flash_attn_bwd(qh, kh, vh, o, dh, lse, chunk_len=S, q_chunk_gid=[1], kv_chunk_gid=[0], kv_chunk_row=[0],
+                                                     softmax_scale=scale, dq5=dq, dk=dk, dv=dv, parts=part, delta=delta))
+        units = 1.5 if part == ops.ATTN_BWD_DQ else 2.0            # recomputed S and dP + one (dQ) or two (dK, dV) products, in units of the forward (4 S^2 d)
+        rows.append({"what": name, "frames": B, "tokens": S, "heads": H, "head_size": hn, "padded_to": D, "ms_best": best, "ms_median": med,
+                     "algorithmic_pflops": units * flops / best / 1e12})
+    del qh, kh, vh, dh, o, lse, dq, dk, dv
 
 cfg = vision.VisionConfig.siglip_400m()
 imgs = torch.randn(16, 3, cfg.image, cfg.image, generator=g, device=DEV).bfloat16()
