@@ -208,7 +208,8 @@ int vita_gemm_skinny_bf16(const void* A, int64_t lda, const void* W, int64_t ldw
                           int64_t ldc, int M, int64_t N, int64_t K, int out_f32, void* stream);
 
 /* ---------------------------------------------------------------------------------------------
- * Flash attention forward (online softmax, fp32 statistics, bf16 I/O), head_dim 64 or 128.
+ * Flash attention forward (online softmax, fp32 statistics, bf16 I/O), head_dim 64, 96 or 128 (96: SigLIP's 72 zero-padded by the
+ * caller, M/core/models/vision/siglip_vit_model.py:29-86; anything else: VITA_ERR_UNSUPPORTED).
  * Replaces flash_attn_func (ViT, M/core/transformer/dot_product_attention.py:318-326),
  * transformers._flash_attention_forward (LLM CP=1, :374-390) and TransformerEngine's
  * AttnFuncWithCP ring (LLM CP>1, M/core/models/gpt/gpt_layer_specs.py:40).
@@ -445,7 +446,7 @@ int vita_attn_delta(const void* o, const void* d_o, float* delta, int64_t rows, 
                     int head_dim, int64_t o_row_stride, int64_t o_head_stride, int64_t do_row_stride,
                     int64_t do_head_stride, void* stream);
 
-/* Flash attention backward (head_dim 128, causal, batch 1) over the same chunk geometry as
+/* Flash attention backward (head_dim 128 | 96 | 64, causal through the chunk tables, batch 1) over the same chunk geometry as
  * vita_flash_attn_fwd (chunk_len % 128 == 0).  q/k/v are the forward's (rotated) inputs, lse its
  * log-sum-exp output [n_q_heads, n_q_rows], delta from vita_attn_delta.  dk/dv are written for EVERY
  * key row of the visible K/V buffer (under context parallelism: the gathered layout, to be

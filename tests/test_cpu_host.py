@@ -1048,11 +1048,13 @@ def test_vit_layer_specs_construct_on_cpu_with_the_references_parameter_names():
         bad = dm.TransformerConfig(hidden_size=1152, kv_channels=72, ffn_hidden_size=4304, activation_func=torch.nn.functional.silu, **base)
         with pytest.raises(NotImplementedError):
             dm.build_module(vls.get_vit_layer_local_spec_for_siglip(), config=bad, layer_number=1)
-        # head sizes the kernels do not tile are zero-padded (scores and the kept output columns unchanged); 64 / 128 pass through
+        # head sizes the kernels do not tile are zero-padded to the next one that is (scores and the kept output columns unchanged);
+        # 64 / 96 / 128 pass through (r05: SigLIP's 72 -> 96; through r04 -> 128)
         t = torch.randn(2, 5, 3, 72)
         p_ = _pad_head_dim(t)
-        assert p_.shape == (2, 5, 3, 128) and torch.equal(p_[..., :72], t) and float(p_[..., 72:].abs().max()) == 0.0
+        assert p_.shape == (2, 5, 3, 96) and torch.equal(p_[..., :72], t) and float(p_[..., 72:].abs().max()) == 0.0
         assert _pad_head_dim(torch.zeros(1, 1, 1, 64)).shape[-1] == 64 and _pad_head_dim(torch.zeros(1, 1, 1, 40)).shape[-1] == 64
+        assert _pad_head_dim(torch.zeros(1, 1, 1, 96)).shape[-1] == 96 and _pad_head_dim(torch.zeros(1, 1, 1, 100)).shape[-1] == 128
         with pytest.raises(NotImplementedError):
             _pad_head_dim(torch.zeros(1, 1, 1, 160))
     finally:
