@@ -98,7 +98,7 @@ def get_vit_layer_with_transformer_engine_spec_for_intern(use_te=True):
 
 def get_vit_layer_local_spec_for_siglip(use_te=True):
     """vit_layer_specs.py:30-53 — SigLIP-400M (M/pretrain_long_vita.py:268-307: hidden 1152, 16 heads x 72, FFN 4304, tanh GELU, no
-    LayerScale, no class token).  The sizes the MFMA kernels do not tile are padded where they are used: head size 72 -> 128 with zero
+    LayerScale, no class token).  The sizes the MFMA kernels do not tile are padded where they are used: head size 72 -> 96 with zero
     columns inside HipDotProductAttention (scores and outputs unchanged), the 4304-deep contractions of fc2 and of fc1's dgrad -> 4352
     with zero columns inside ops.gemm; parameters keep Megatron's shapes.  Biases of proj / fc1 / fc2 meet the bf16-rounded product in
     an op of their own (skip_bias_add, no fusion: `unfused_bias`), as the reference's modules do."""
