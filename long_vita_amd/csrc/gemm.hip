@@ -692,7 +692,17 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
     }
   }
   // read q (0..15) of k half ks: W block 0 first, then the eight A blocks, then W blocks 1..7 (the order the MFMAs need them)
-  auto frag_read = [&](unsigned stage, int ks, int q) __attribute__((always_inline)) {
+  // (r05 late: the plain reads take a per-tile base VGPR — stage + rd_a / rd_w, `StageBases` — and an IMMEDIATE offset; before, every one of the
+  // 32 reads of a K tile cost an s_add + v_add for its address: VALU 1.28 -> 1.03, SALU 0.45 -> 0.33 instructions per MFMA, the vendor kernel's
+  // figures in profiles/r05_gemm_vs_vendor_pmc.txt.  "i" and not "n": the offset is a constant only after inlining and unrolling.)
+  struct StageBases { unsigned stage, a, w; };
+  auto bases_of = [&](unsigned stage) __attribute__((always_inline)) {
+    StageBases b = {stage, stage + rd_a, stage + rd_w};
+    asm volatile("" : "+v"(b.a), "+v"(b.w));                                // computed HERE, once, and kept
+    return b;
+  };
+  auto frag_read = [&](const StageBases& sb, int ks, int q) __attribute__((always_inline)) {
+    const unsigned stage = sb.stage;
     const bool is_w = q == 0 || q > 8;
     if (is_w ? TW : TA) {                                                  // this operand is contraction-major: transposed reads
       const int x = is_w ? (q == 0 ? 0 : q - 8) : q - 1;
@@ -708,12 +718,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
     }
     if (q == 0 || q > 8) {
       const int nb = q == 0 ? 0 : q - 8;
-      const unsigned ad = stage + rd_w + nb * 128 + ks * 64;
-      asm volatile("ds_read_b128 %0, %1" : "=v"(wf[ks][nb]) : "v"(ad));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(wf[ks][nb]) : "v"(sb.w), "i"(nb * 128 + ks * 64));
     } else {
       const int mb = q - 1;
-      const unsigned ad = stage + rd_a + mb * 128 + ks * 64;
-      asm volatile("ds_read_b128 %0, %1" : "=v"(af[ks][mb]) : "v"(ad));
+      asm volatile("ds_read_b128 %0, %1 offset:%2" : "=v"(af[ks][mb]) : "v"(sb.a), "i"(mb * 128 + ks * 64));
     }
   };
   // TN: after the s_waitcnt that covers them, the 16 fragments of k half ks are assembled from their halves (the empty asm makes the
@@ -748,17 +756,21 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   } else {
     asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
   }
+  {
+    const StageBases b0 = bases_of(lds0);
 #pragma unroll
-  for (int q = 0; q < 16; ++q) frag_read(lds0, 0, q);
+    for (int q = 0; q < 16; ++q) frag_read(b0, 0, q);
+  }
   asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
   frag_commit(0);
 
   // one K tile: DMA = tile t+2 exists (goes into `cur`), NEXT = tile t+1 exists (its first-half fragments come from `nxt`)
   auto tile = [&](const bool DMA, const bool NEXT, unsigned cur, unsigned nxt) __attribute__((always_inline)) {
+    const StageBases bcur = bases_of(cur), bnxt = bases_of(NEXT ? nxt : cur);
     auto slot = [&](const int s) __attribute__((always_inline)) {
       const int ks = s >> 6, nb = (s >> 3) & 7, mb = s & 7;
       asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[nb][mb]) : "v"(wf[ks][nb]), "v"(af[ks][mb]));
-      if (s <= 30 && (s & 1) == 0) frag_read(cur, 1, s >> 1);
+      if (s <= 30 && (s & 1) == 0) frag_read(bcur, 1, s >> 1);
       if (s == 36) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       // (r05 null: wave w issuing its piece at slot 40 + 4 j + w instead of all four waves in the same slot — so that the four requests do
       // not queue in the CU's one texture addresser — is 19 % SLOWER: the 64 wave-dependent scalar branches per tile cost more than the queue.)
@@ -774,13 +786,13 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
           if (DMA) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
-        if (NEXT && s >= 64 && s < 96 && (s & 1) == 0) frag_read(nxt, 0, (s - 64) >> 1);
+        if (NEXT && s >= 64 && s < 96 && (s & 1) == 0) frag_read(bnxt, 0, (s - 64) >> 1);
       } else {
         if (NEXT && s == 103) {
           if (DMA) asm volatile("s_waitcnt vmcnt(16)\n\ts_barrier" ::: "memory");
           else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
-        if (NEXT && s >= 104 && s < 120) frag_read(nxt, 0, s - 104);
+        if (NEXT && s >= 104 && s < 120) frag_read(bnxt, 0, s - 104);
       }
       __builtin_amdgcn_sched_barrier(0);
     };
