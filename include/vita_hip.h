@@ -203,6 +203,11 @@ int vita_gemm_bf16_tn_splitk(const void* At, int64_t lda, const void* Wt, int64_
 /* ABI 15: out[c] += sum over rows of float(x[r][c]) — grad_bias = grad_output.sum(dim=0) (M/core/tensor_parallel/layers.py:524) in one
  * pass over grad_output.  out: fp32 [cols], zeroed by the caller; cols % 4 == 0. */
 int vita_colsum_bf16(const void* x, int64_t ldx, float* out, int64_t rows, int cols, void* stream);
+/* ABI 18: the same sums added in a FIXED order — bit-reproducible from run to run, as the reference's grad_output.sum(dim=0) is (the form
+ * above adds its row blocks with fp32 atomics, in arrival order).  workspace: vita_colsum_workspace_bytes(rows, cols) bytes, 16-byte aligned;
+ * out: fp32 [cols], 16-byte aligned, zeroed (or holding a running sum) on entry. */
+size_t vita_colsum_workspace_bytes(int64_t rows, int cols);
+int vita_colsum_bf16_ordered(const void* x, int64_t ldx, float* out, int64_t rows, int cols, void* workspace, void* stream);
 
 int vita_gemm_skinny_bf16(const void* A, int64_t lda, const void* W, int64_t ldw, void* C,
                           int64_t ldc, int M, int64_t N, int64_t K, int out_f32, void* stream);

@@ -1,7 +1,7 @@
 // ABI bookkeeping for libvita_hip.so.
 #include "vita_common.h"
 
-extern "C" int vita_abi_version(void) { return 17; }
+extern "C" int vita_abi_version(void) { return 18; }
 
 extern "C" const char* vita_error_string(int code) {
   switch (code) {

@@ -1194,6 +1194,36 @@ __global__ __launch_bounds__(256) void colsum_kernel(const bf16_t* __restrict__ 
   }
   atomicAdd(out + c4, a0); atomicAdd(out + c4 + 1, a1); atomicAdd(out + c4 + 2, a2); atomicAdd(out + c4 + 3, a3);
 }
+// The ORDERED form (r05): fp32 atomics add in arrival order, so two runs of the same step could differ in the last bit of a bias gradient
+// (seen: the recompute test's bit-identity assertion on linear_qkv.bias).  Row block y writes its partial sums to part[y][cols]; one thread
+// per four columns then adds the partials in block order.
+__global__ __launch_bounds__(256) void colsum_partial_kernel(const bf16_t* __restrict__ x, int64_t ldx, float* __restrict__ part, int64_t rows,
+                                                             int cols, int rows_per_block) {
+  const int c4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c4 >= cols) return;
+  const int64_t r0 = (int64_t)blockIdx.y * rows_per_block, r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
+  f32x4 a = {0.f, 0.f, 0.f, 0.f};
+  for (int64_t r = r0; r < r1; ++r) {
+    const u32x2 v = *reinterpret_cast<const u32x2*>(x + r * ldx + c4);
+    a[0] += bf16lo_to_f32(v[0]); a[1] += bf16hi_to_f32(v[0]); a[2] += bf16lo_to_f32(v[1]); a[3] += bf16hi_to_f32(v[1]);
+  }
+  *reinterpret_cast<f32x4*>(part + (int64_t)blockIdx.y * cols + c4) = a;
+}
+__global__ __launch_bounds__(256) void colsum_finish_kernel(const float* __restrict__ part, float* __restrict__ out, int blocks, int cols) {
+  const int c4 = (blockIdx.x * 256 + threadIdx.x) * 4;
+  if (c4 >= cols) return;
+  f32x4 s = *reinterpret_cast<const f32x4*>(out + c4);
+  for (int y = 0; y < blocks; ++y) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(part + (int64_t)y * cols + c4);
+    s[0] += t[0]; s[1] += t[1]; s[2] += t[2]; s[3] += t[3];
+  }
+  *reinterpret_cast<f32x4*>(out + c4) = s;
+}
+// rows per block / number of row blocks of both forms: <= 1024 blocks (enough workgroups to stream at HBM speed), >= 32 rows each
+inline int64_t colsum_rows_per_block(int64_t rows) {
+  const int64_t rpb = (rows + 1023) / 1024;
+  return rpb < 32 ? 32 : rpb;
+}
 }  // namespace
 
 // The same product with the contraction cut into `splits` ranges (r04): a weight gradient whose output is a handful of 256 x 256 tiles
@@ -1241,11 +1271,30 @@ extern "C" int vita_colsum_bf16(const void* x, int64_t ldx, float* out, int64_t 
   if ((cols & 3) || (ldx & 3)) return VITA_ERR_UNSUPPORTED;
   if (rows == 0) return VITA_OK;
   const int gx = (cols / 4 + 255) / 256;
-  int64_t rpb = (rows + 1023) / 1024;                    // <= 1024 row blocks: enough workgroups to stream at HBM speed, few atomics
-  if (rpb < 32) rpb = 32;
+  const int64_t rpb = colsum_rows_per_block(rows);       // <= 1024 row blocks: enough workgroups to stream at HBM speed, few atomics
   const int64_t gy = (rows + rpb - 1) / rpb;
   hipLaunchKernelGGL(colsum_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx, out, rows,
                      cols, (int)rpb);
+  return vita_check_launch();
+}
+
+// ABI 18: the same sums added in a FIXED order (bit-reproducible from run to run, as torch's sum is): workspace = fp32 [row blocks][cols]
+extern "C" size_t vita_colsum_workspace_bytes(int64_t rows, int cols) {
+  if (rows <= 0 || cols <= 0) return 0;
+  const int64_t rpb = colsum_rows_per_block(rows);
+  return (size_t)((rows + rpb - 1) / rpb) * (size_t)cols * sizeof(float);
+}
+extern "C" int vita_colsum_bf16_ordered(const void* x, int64_t ldx, float* out, int64_t rows, int cols, void* workspace, void* stream) {
+  if (!x || !out || rows < 0 || cols <= 0) return VITA_ERR_INVALID_ARG;
+  if ((cols & 3) || (ldx & 3) || ((uintptr_t)out & 15) || ((uintptr_t)workspace & 15)) return VITA_ERR_UNSUPPORTED;
+  if (rows == 0) return VITA_OK;
+  if (!workspace) return VITA_ERR_INVALID_ARG;
+  const int gx = (cols / 4 + 255) / 256;
+  const int64_t rpb = colsum_rows_per_block(rows);
+  const int64_t gy = (rows + rpb - 1) / rpb;
+  hipLaunchKernelGGL(colsum_partial_kernel, dim3((unsigned)gx, (unsigned)gy), dim3(256), 0, (hipStream_t)stream, (const bf16_t*)x, ldx,
+                     (float*)workspace, rows, cols, (int)rpb);
+  hipLaunchKernelGGL(colsum_finish_kernel, dim3((unsigned)gx), dim3(256), 0, (hipStream_t)stream, (const float*)workspace, out, (int)gy, cols);
   return vita_check_launch();
 }
 

@@ -23,7 +23,7 @@ if os.environ.get("VITA_HIP_LIB"):                    # developer A / B switch: 
     LIB_PATH = os.path.abspath(os.environ["VITA_HIP_LIB"])
 HEADER_PATH = os.path.join(os.path.dirname(_HERE), "include", "vita_hip.h")
 
-ABI_VERSION = 17
+ABI_VERSION = 18
 VITA_OK = 0
 VITA_ERR_INVALID_ARG = -1
 VITA_ERR_UNSUPPORTED = -2
@@ -150,6 +150,8 @@ PROTOTYPES = {
     "vita_gemm_tn_splitk_workspace_bytes": (C.c_size_t, [_l, _l, _i]),
     "vita_gemm_bf16_tn_splitk": (_i, [_p, _l, _p, _l, _p, _l, _l, _l, _l, _i, _p, _p]),
     "vita_colsum_bf16": (_i, [_p, _l, _p, _l, _i, _p]),
+    "vita_colsum_workspace_bytes": (C.c_size_t, [_l, _i]),
+    "vita_colsum_bf16_ordered": (_i, [_p, _l, _p, _l, _i, _p, _p]),
     "vita_gemm_skinny_bf16": (_i, [_p, _l, _p, _l, _p, _l, _i, _l, _l, _i, _p]),
     "vita_flash_attn_fwd": (_i, [C.POINTER(AttnParams), _p]),
     "vita_patchify14": (_i, [_p, _p, _l, _i, _i, _i, _p]),

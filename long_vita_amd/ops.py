@@ -402,8 +402,12 @@ def colsum(x: torch.Tensor) -> torch.Tensor:
     rows, cols = x.shape
     out = torch.zeros(cols, dtype=torch.float32, device=x.device)
     if rows:
-        _L.check(_L.load().vita_colsum_bf16(_dev(x, "x", BF16), x.stride(0), _dev(out, "out", torch.float32), rows, cols, _stream()),
-                 "vita_colsum_bf16")
+        h = _L.load()
+        # the ordered form (ABI 18): row-block partials in a workspace, added in block order — two runs give the same bits (the atomic form
+        # vita_colsum_bf16 adds in arrival order)
+        ws = torch.empty(max(1, h.vita_colsum_workspace_bytes(rows, cols) // 4), dtype=torch.float32, device=x.device)
+        _L.check(h.vita_colsum_bf16_ordered(_dev(x, "x", BF16), x.stride(0), _dev(out, "out", torch.float32), rows, cols,
+                                            _dev(ws, "workspace", torch.float32), _stream()), "vita_colsum_bf16_ordered")
     return out
 
 

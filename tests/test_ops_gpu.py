@@ -692,3 +692,10 @@ def test_colsum_is_the_bias_gradient(ops):
     big[:, 32:32 + 3072] = torch.randn(4099, 3072, generator=g(311)).bfloat16()
     tol("strided colsum", rel_l2(ops.colsum(big.to(DEV)[:, 32:32 + 3072]), big[:, 32:32 + 3072].float().sum(dim=0)), 1e-5)
     assert float(ops.colsum(torch.zeros(0, 256, dtype=torch.bfloat16, device=DEV)).abs().sum()) == 0.0
+    # r05 (ABI 18): the ordered form — row-block partials added in block order — gives the same BITS every run (the atomic form did not:
+    # the recompute test's bit-identity assertion on linear_qkv.bias failed on it once the GEMM in front of it got faster)
+    xd = (torch.randn(70001, 2048, generator=g(312)) * 3).bfloat16().to(DEV)
+    first = ops.colsum(xd)
+    for _ in range(5):
+        assert torch.equal(ops.colsum(xd), first)
+    tol("ordered colsum", rel_l2(first, xd.float().sum(dim=0)), 1e-5)
