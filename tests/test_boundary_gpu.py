@@ -671,7 +671,11 @@ def test_transformer_block_final_norm_recompute_and_loss_run_on_the_library(mega
         outs.append((o.detach(), xi.grad, {k: v.grad for k, v in b_.named_parameters()}))
     assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
     for k in outs[0][2]:
-        assert outs[1][2][k] is not None and torch.equal(outs[0][2][k], outs[1][2][k]), k
+        assert outs[1][2][k] is not None, k
+        if "norm" in k:                            # fp32 atomic sums over row blocks (arrival order): equal to one bf16 step, as in the tests below
+            torch.testing.assert_close(outs[0][2][k].float(), outs[1][2][k].float(), rtol=2 ** -7, atol=1e-6, msg=k)
+        else:
+            assert torch.equal(outs[0][2][k], outs[1][2][k]), k
     # the final norm against the oracle restatement of RMSNorm on the layer stack's output
     with torch.no_grad():
         pre = ref_blk.final_layernorm
