@@ -482,6 +482,20 @@ class FlashAttnFn(torch.autograd.Function):
         return dq, dk, dv, None, None, None, None, None
 
 
+def non_causal_backward_plan(S: int, D: int, mode: str = "0"):
+    """(padded sequence length, head size of the padded copies, head size of the dQ pass) of FlashAttnNonCausalFn.backward.
+    d = 64: both general kernels at 64.  d = 96 (SigLIP, r05): measured at 64 frames x 16 heads x 1024 tokens — dQ (general kernel) 1.43 ms
+    at 128 -> 1.20 ms at 96; dK + dV 1.30 ms at 128 (the pair kernel of attn_bwd_kvp.hip takes whole 256-row sequences at d = 128) against
+    2.08 ms through the general kernel at 96.  So: copies padded to 128 for the pair kernel whenever it is eligible, the dQ pass reading the
+    SAME buffers as d = 96 views (strides are free; columns 96 .. 127 are zero and are not read); otherwise both general kernels at 96.
+    mode (VITA_VIT_BWD_PAD128, developer A / B): "1" = the r03 path, everything zero-padded to 128; "96" = never the pair kernel."""
+    sp = -(-S // 128) * 128
+    pair = D == 96 and sp % 256 == 0 and mode != "96"
+    dp = 128 if (mode == "1" or D not in (64, 96) or pair) else D
+    dq_d = D if (D in (64, 96) and mode != "1") else dp
+    return sp, dp, dq_d
+
+
 class FlashAttnNonCausalFn(torch.autograd.Function):
     """The ViT's core attention (flash_attn_func(causal=False), M/core/transformer/dot_product_attention.py:312-329) under autograd.
     q / k / v [B, S, H, D] views (B = frames, S = 1025, D = 64 for InternViT; SigLIP: 729 rows, D = 72 zero-padded to 96 by the caller).  Forward = the non-causal d = 64 kernel.  Backward =
@@ -505,16 +519,8 @@ class FlashAttnNonCausalFn(torch.autograd.Function):
         if k.shape[2] != H:
             raise NotImplementedError("the ViT attention backward is built for multi-head attention (ng == np)")
         import os
-        mode = os.environ.get("VITA_VIT_BWD_PAD128", "0")                 # developer A / B: 1 = the r03 path (everything zero-padded to d = 128)
-        sp, nh = -(-S // 128) * 128, B * H
-        # Head size of the padded copies (dp) and of the dQ pass (dq_d).  d = 64: both general kernels at 64.  d = 96 (SigLIP, r05): measured at
-        # 64 frames x 16 heads x 1024 tokens — dQ (general kernel) 1.43 ms at 128 -> 1.20 ms at 96; dK + dV 1.30 ms at 128 (the pair kernel of
-        # attn_bwd_kvp.hip takes whole 256-row sequences at d = 128) against 2.08 ms through the general kernel at 96.  So: copies padded to 128
-        # for the pair kernel whenever it is eligible, and the dQ pass reads the SAME buffers as d = 96 views (strides are free, the columns
-        # 96 .. 127 are zero and are not read); otherwise both general kernels at 96.
-        pair = D == 96 and sp % 256 == 0 and mode != "96"
-        dp = 128 if (mode == "1" or D not in (64, 96) or pair) else D
-        dq_d = D if (D in (64, 96) and mode != "1") else dp
+        sp, dp, dq_d = non_causal_backward_plan(S, D, os.environ.get("VITA_VIT_BWD_PAD128", "0"))
+        nh = B * H
 
         def pad(t):                                   # [B, S, H, D] -> [1, S_pad, B * H, dp], zero-filled
             buf = torch.zeros(sp, B, H, dp, dtype=t.dtype, device=t.device)

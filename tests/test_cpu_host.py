@@ -1287,3 +1287,15 @@ def test_design_document_stays_reviewable():
     assert len(lines) <= 401, len(lines)                              # 400 lines + the empty piece after a final newline
     assert max(len(l) for l in lines) <= 120, max(len(l) for l in lines)
     assert os.path.exists(os.path.join(root, "HISTORY.md"))
+
+
+def test_head_sizes_of_the_vit_attention_backward():
+    """autograd_fns.non_causal_backward_plan: which head size the padded copies and the dQ pass of the ViT / SigLIP attention backward run at
+    (r05: d = 96 instances; the pair kernel of attn_bwd_kvp.hip only exists at d = 128 and takes whole 256-row sequences)."""
+    from long_vita_amd.autograd_fns import non_causal_backward_plan as plan
+    assert plan(1025, 64) == (1152, 64, 64)                 # InternViT: native head size, both general kernels
+    assert plan(1024, 96) == (1024, 128, 96)                # SigLIP at 448 px: copies at 128 for the pair kernel, dQ on d = 96 views
+    assert plan(729, 96) == (768, 128, 96)
+    assert plan(300, 96) == (384, 96, 96)                   # padded length not a multiple of 256: both general kernels at 96
+    assert plan(1024, 96, "96") == (1024, 96, 96) and plan(1024, 96, "1") == (1024, 128, 128) and plan(1025, 64, "1") == (1152, 128, 128)
+    assert plan(300, 128) == (384, 128, 128) and plan(100, 80)[1:] == (128, 128)       # anything else was padded to 128 by the caller
