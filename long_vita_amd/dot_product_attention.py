@@ -49,6 +49,14 @@ class HipDotProductAttention(torch.nn.Module):
         if not needs_grad:
             if region is not None and phase == "store" and self._impl.causal and query.shape[1] == 1 and packed_seq_params is None:
                 return self._forward_and_keep(query, key, value)
+            if region is not None and phase == "replay" and self._impl.causal and query.shape[1] == 1 and packed_seq_params is None:
+                # a replayed call that needs no gradient (frozen layer, input without grad) still owns the slot its store run
+                # filled: consume it — and use it, the context is the result asked for (skipping it shifted every
+                # later layer's slot)
+                kept = recompute_cache.take(like=query.transpose(0, 1))
+                if kept is not None:
+                    sq, b, np_, hn = query.shape
+                    return kept[0].transpose(0, 1).reshape(sq, b, np_ * hn)
             return self._impl.forward(query, key, value, attention_mask, attn_mask_type, packed_seq_params)
         assert packed_seq_params is None, (
             "Packed sequence is not supported by DotProductAttention."
@@ -70,11 +78,11 @@ class HipDotProductAttention(torch.nn.Module):
             # dK / dV reduce-scatter backward
             if training_utils.get_packed_segments() is not None:
                 raise NotImplementedError("packed samples under context parallelism are not built (reference stage 2 is CP = 1)")
-            out = FlashAttnCPFn.apply(q, k, v, self._impl, recompute_cache.take())
+            out = FlashAttnCPFn.apply(q, k, v, self._impl, recompute_cache.take(like=q))
         else:
             seg = training_utils.get_packed_segments() if self._impl.causal else None
             out = FlashAttnFn.apply(q, k, v, self._impl.softmax_scale, self._impl.causal,
-                                    None if seg is None else seg[0], None if seg is None else seg[1], recompute_cache.take())
+                                    None if seg is None else seg[0], None if seg is None else seg[1], recompute_cache.take(like=q))
         return out.transpose(0, 1).reshape(sq, b, np_ * hn)
 
     def _forward_and_keep(self, query, key, value):

@@ -31,7 +31,7 @@ class Region:
     """One call of tensor_parallel.checkpoint: the attention results of its first run, in call order."""
 
     def __init__(self):
-        self.slots, self.runs, self.cursor = [], 0, 0
+        self.slots, self.runs, self.cursor, self.broken = [], 0, 0, False
 
 
 def current():
@@ -45,14 +45,22 @@ def store(value) -> None:
         region.slots.append(value)
 
 
-def take():
-    """The next kept result of the region being replayed, or None (nothing kept: the caller recomputes)."""
+def take(like=None):
+    """The next kept result of the region being replayed, or None (nothing kept: the caller recomputes).
+    EVERY attention call of the replay that stored in the store run must come here, whether or not it needs a gradient
+    (HipDotProductAttention.forward does so): slots are matched to calls by call order, and a call that skipped its slot would hand
+    the NEXT layer a result of the right shape and the wrong content.  `like` = the call's query [b, sq, np, hn]: a
+    kept context of another shape means the two runs did not make the same calls — the region is then marked broken and this and
+    every later call of it recomputes."""
     region, phase = current()
-    if region is None or phase != "replay" or region.cursor >= len(region.slots):
+    if region is None or phase != "replay" or region.broken or region.cursor >= len(region.slots):
         return None
     value = region.slots[region.cursor]
     region.slots[region.cursor] = None          # the autograd node owns it from here on
     region.cursor += 1
+    if like is not None and tuple(getattr(value[0], "shape", like.shape)) != tuple(like.shape):
+        region.broken = True
+        return None
     return value
 
 
@@ -69,12 +77,19 @@ def checkpoint_wrapper(fn):
             _S.region, _S.phase = region, ("store" if region.runs == 0 else "replay")
             region.runs += 1
             region.cursor = 0
+            replay = region.runs > 1
             try:
-                return function(*a)
+                out = function(*a)
             finally:
                 _S.region, _S.phase = prev
-                if region.runs > 1:
+                left = len(region.slots) - region.cursor
+                if replay:
                     region.slots.clear()
+            if replay and left and not region.broken:
+                # the replay made fewer attention calls than the store run kept results for: call order no longer identifies them
+                raise RuntimeError(f"VITA_KEEP_ATTENTION: {left} kept attention result(s) were not consumed by the recompute of this "
+                                   "checkpointed region; the store and replay runs made different calls")
+            return out
 
         return fn(run, distribute_saved_activations, *args)
 

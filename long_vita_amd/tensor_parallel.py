@@ -11,7 +11,9 @@ M/core/tensor_parallel/layers.py (ColumnParallelLinear: output rows, RowParallel
 
 Row-parallel outputs are summed over the TP group in bf16 and the residual is added afterwards (vita_add_bf16), as
 RowParallelLinear + bias_dropout_add do; column-parallel input gradients are summed the same way in the backward.
-The frozen ViT is replicated (3.5 % of the prefill flops).  Sequence parallelism (--sequence-parallel) is not built.
+The frozen ViT is replicated (3.5 % of the prefill flops).  This file shards the STAND-ALONE step's parameter dict, which runs without
+sequence parallelism; on the module path (layers.py: Column / RowParallelLinear with `sequence_parallel`, the embedding's scatter)
+--sequence-parallel is built and tested (INTEGRATION.md).
 """
 from __future__ import annotations
 

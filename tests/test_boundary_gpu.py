@@ -829,6 +829,36 @@ def test_recompute_keeping_the_attention_result_is_bit_identical_and_skips_the_s
             assert torch.equal(outs[0][2][k], outs[1][2][k]), k           # GEMM products, and the bias gradient (ordered column sum, ABI 18)
 
 
+def test_kept_attention_stays_with_its_call_when_a_replayed_call_needs_no_gradient(megatron, monkeypatch):
+    """two attention calls inside one checkpointed region, the first on inputs that need no gradient in the replay
+    (a frozen layer under an input without grad).  The replayed first call must consume ITS slot (and returns the kept context), so the
+    second call's backward sees its own (context, lse): gradients bit-identical to the run without the switch."""
+    from long_vita_amd import recompute_cache as rc
+    from long_vita_amd.dot_product_attention import HipDotProductAttention
+    mcfg = dm.TransformerConfig(num_layers=1, hidden_size=CFG["hidden"], num_attention_heads=CFG["heads"], num_query_groups=CFG["kv_groups"],
+                                kv_channels=CFG["head_dim"], ffn_hidden_size=CFG["ffn"])
+    att = HipDotProductAttention(mcfg, 1, "causal")
+    S, H, G, D = 512, CFG["heads"], CFG["kv_groups"], CFG["head_dim"]
+    g = torch.Generator().manual_seed(5)
+    mk = lambda h: torch.randn(S, 1, h, D, generator=g).bfloat16().to(DEV)             # noqa: E731
+    q0, k0, v0, q1, k1, v1 = mk(H), mk(G), mk(G), mk(H), mk(G), mk(G)
+    go = torch.randn(S, 1, H * D, generator=g).bfloat16().to(DEV)
+
+    def region(x):                                   # x carries the gradient; call 0's inputs are constants
+        a = att(q0, k0, v0)
+        b = att(q1 * x, k1, v1)
+        return a + b
+
+    res = []
+    for keep in ("0", "1"):
+        monkeypatch.setenv("VITA_KEEP_ATTENTION", keep)
+        x = torch.ones(1, device=DEV, dtype=torch.bfloat16).requires_grad_(True)
+        y = rc.checkpoint_wrapper(dm.checkpoint)(region, False, x)
+        y.backward(go)
+        res.append((y.detach().clone(), x.grad.clone()))
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
 def test_output_layer_with_a_logit_mask_that_selects_nothing(megatron):
     """under CP the answer tokens of a 128K row all sit on CP rank 0 — every other rank's `logit_mask` is all
     False.  ColumnParallelLinear(output_layer).forward must return an empty [0, b, V] tensor (the reference's masked_select does), and

@@ -1279,6 +1279,48 @@ def test_recompute_cache_marks_store_and_replay_runs_of_a_checkpointed_function(
     assert sorted(log) == [("L0", "L0"), ("L1", "L1")]
 
 
+def test_recompute_cache_refuses_misaligned_replays(monkeypatch):
+    """kept attention results are matched to replayed calls by call order.  A replay that leaves a kept result
+    unconsumed raises (the store and replay runs made different calls); a kept context whose shape is not the replayed call's marks
+    the region broken — that call and every later one recompute, nothing is raised."""
+    import pytest
+    import torch
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import dummy_megatron as dm
+    from long_vita_amd import recompute_cache as rc
+    monkeypatch.setenv("VITA_KEEP_ATTENTION", "1")
+    wrapped = rc.checkpoint_wrapper(dm.checkpoint)
+
+    def skips_one(x):
+        _, phase = rc.current()
+        if phase == "store":
+            rc.store(("a", 1)); rc.store(("b", 2))
+        else:
+            rc.take()                                       # one of two
+        return x * 2.0
+
+    x = torch.ones(3, requires_grad=True)
+    y = wrapped(skips_one, False, x)
+    with pytest.raises(RuntimeError, match="were not consumed"):
+        y.sum().backward()
+    assert rc.current() == (None, None)
+
+    got = []
+
+    def wrong_shape(x):
+        _, phase = rc.current()
+        if phase == "store":
+            rc.store((torch.zeros(1, 4, 2, 8), None)); rc.store((torch.zeros(1, 4, 2, 8), None))
+        else:
+            got.append(rc.take(like=torch.zeros(1, 6, 2, 8)))          # not the kept context's shape: broken from here on
+            got.append(rc.take(like=torch.zeros(1, 4, 2, 8)))
+        return x * 2.0
+
+    x.grad = None
+    wrapped(wrong_shape, False, x).sum().backward()
+    assert got == [None, None] and float(x.grad[0]) == 2.0
+
+
 def test_design_document_stays_reviewable():
     """VERDICT r04 housekeeping: DESIGN.md is the current-state document — at most 400 lines of at most 120 bytes (tools/wrap_md.py re-flows it);
     the round-by-round record lives in HISTORY.md."""
