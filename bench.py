@@ -51,6 +51,16 @@ import torch.distributed as dist  # noqa: E402
 MFMA_BF16_PEAK_TFLOPS = 2500.0        # MI355X dense bf16 (MI355X_MICROARCH.md)
 
 
+def committed_pmc_sets():
+    """profiles/rNN_attn128k_pmc.json, newest round first — the PMC measurement `roofline.traffic` is read from (each is
+    tools/pmc_to_json.py applied to the committed raw passes rNN_attn128k_pmc_raw.txt; tests/test_cpu_host.py re-derives the
+    newest one)."""
+    import glob
+    import re
+    found = [p for p in glob.glob(os.path.join(ROOT, "profiles", "r*_attn128k_pmc.json")) if re.fullmatch(r"r\d\d_attn128k_pmc\.json", os.path.basename(p))]
+    return sorted(found, reverse=True)
+
+
 def flops_per_token(seq, frames, cfg, vcfg):
     """algorithmic FLOPs of one prefill / seq."""
     lin = cfg.num_layers * 2 * (cfg.hidden * cfg.qkv_out + cfg.hidden * cfg.heads * cfg.head_dim
@@ -482,12 +492,12 @@ def main():
     # HBM traffic of that kernel: PMC counters cannot be read from inside this process; when a
     # rocprofv3 --pmc measurement of the same launch shape is committed under profiles/, report it
     traffic, traffic_src = None, None
-    for tag in ("r05", "r04", "r03"):                      # the newest committed measurement of this launch shape
+    for path in committed_pmc_sets():                      # the newest committed measurement of this launch shape
         try:
-            pmc = json.load(open(os.path.join(ROOT, "profiles", f"{tag}_attn128k_pmc.json")))
+            pmc = json.load(open(path))
             if pmc["seq"] == seq and pmc["n_gpus"] == world:
                 traffic = pmc["hbm_bytes_per_launch"]
-                traffic_src = f"profiles/{tag}_attn128k_pmc.json (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, offline)"
+                traffic_src = f"profiles/{os.path.basename(path)} (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE, offline)"
                 break
         except (OSError, KeyError, ValueError):
             continue

@@ -101,8 +101,11 @@ class MegatronVisionModel:
             q["layers"].append({k: d(v) for k, v in o.items()})
         return cls(cfg, q)
 
-    @classmethod
-    def random_init(cls, cfg: VisionConfig, seed: int = 1234, device="cuda", std: float = 0.02):
+    @staticmethod
+    def random_params(cfg: VisionConfig, seed: int = 1234, device="cuda", std: float = 0.02) -> dict:
+        """Seeded synthetic weights in the un-padded, per-tensor ("oracle") layout `from_oracle_layout` takes; generated on the device,
+        returned on the host.  bench.py's tower is `from_oracle_layout(random_params(seed=4321))`: the parity tests hand the same
+        dict to the oracle (tests/test_parity_bench_gpu.py)."""
         g = torch.Generator(device=device).manual_seed(seed)
 
         def rn(*shape, s=std):
@@ -122,7 +125,11 @@ class MegatronVisionModel:
                                 "ln2_w": ones(h), "ln2_b": ones(h, 0.0), "fc1_w": rn(cfg.ffn, h), "fc1_b": rn(cfg.ffn),
                                 "fc2_w": rn(h, cfg.ffn), "fc2_b": rn(h), "ls2": ones(h, 0.1)})
         p = {k: (v.cpu() if torch.is_tensor(v) else [{kk: vv.cpu() for kk, vv in lp.items()} for lp in v]) for k, v in p.items()}
-        return cls.from_oracle_layout(cfg, p, device)
+        return p
+
+    @classmethod
+    def random_init(cls, cfg: VisionConfig, seed: int = 1234, device="cuda", std: float = 0.02):
+        return cls.from_oracle_layout(cfg, cls.random_params(cfg, seed, device, std), device)
 
     # -- InternViTModel.forward, intern_vit_model.py:190-261 ---------------------------------------
     def vit(self, images: torch.Tensor) -> torch.Tensor:

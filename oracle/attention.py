@@ -86,3 +86,27 @@ def zigzag_cp_attention(q_local, k_locals, v_locals, cp_size: int, cp_rank: int,
     v_all = torch.cat(v_locals, dim=0)
     k_pos = torch.cat([positions(r) for r in range(cp_size)])
     return core_attention(q_local, k_all, v_all, True, scale, q_pos=positions(cp_rank), k_pos=k_pos)
+
+
+def core_attention_row_blocked(q: torch.Tensor, k: torch.Tensor, v: torch.Tensor, q_pos0: int = 0, chain: bool = False,
+                               score_bytes: int = 20 << 30) -> torch.Tensor:
+    """`core_attention(causal=True)` for sequences whose [np, sq, sk] score tensor does not fit (128K / 1M rows): the same function
+    called on causal ROW BLOCKS, one kv group at a time — rows [r0, r1) of group g against keys [0, q_pos0 + r1) only (a key beyond
+    a row's position gets probability exactly 0 in the full evaluation, so leaving it out changes nothing but the reduction order).
+    q [sq, b, np, hn] = rows q_pos0 .. q_pos0 + sq - 1 of the sequence; k / v [sk, b, ng, hn] = keys 0 .. sk - 1, sk >= q_pos0 + sq.
+    Block height: the largest power of two whose fp32 scores (rep x rows x keys x 4 B) stay under `score_bytes`."""
+    sq, b, np_, hn = q.shape
+    sk, _, ng, _ = k.shape
+    rep = np_ // ng
+    assert sk >= q_pos0 + sq and np_ == rep * ng
+    rows = 1 << max(int(score_bytes // (4 * rep * b * (q_pos0 + sq))).bit_length() - 1, 0)
+    rows = max(min(rows, sq), 1)
+    out = torch.empty(sq, b, np_, hn, dtype=q.dtype, device=q.device)
+    for g in range(ng):
+        for r0 in range(0, sq, rows):
+            r1 = min(r0 + rows, sq)
+            pos = torch.arange(q_pos0 + r0, q_pos0 + r1, device=q.device)
+            o = core_attention(q[r0:r1, :, g * rep:(g + 1) * rep], k[:q_pos0 + r1, :, g:g + 1], v[:q_pos0 + r1, :, g:g + 1], True,
+                               q_pos=pos, chain=chain)
+            out[r0:r1, :, g * rep:(g + 1) * rep] = o.view(r1 - r0, b, rep, hn)
+    return out.view(sq, b, np_ * hn)

@@ -28,11 +28,11 @@ def load_golden(name):
     return torch.load(os.path.join(GOLDEN, name), weights_only=False)
 
 
-PARITY_OUT = os.environ.get("VITA_PARITY_OUT", os.path.join(ROOT, "gpurun_out", "r05_parity.json"))
+PARITY_OUT = os.environ.get("VITA_PARITY_OUT", os.path.join(ROOT, "gpurun_out", "r06_parity.json"))
 
 
 def record_parity(name, **metrics):
-    """Every error a GPU test measures lands in gpurun_out/r05_parity.json (copied to profiles/ after the run): the asserts next
+    """Every error a GPU test measures lands in gpurun_out/r06_parity.json (copied to profiles/ after the run): the asserts next
     to the calls sit at <= 1.5 x these values."""
     import json
     try:
@@ -45,7 +45,7 @@ def record_parity(name, **metrics):
 
 
 def tol(label, value, limit):
-    """assert value < limit, with the measured value recorded next to the limit (gpurun_out/r05_parity.json)."""
+    """assert value < limit, with the measured value recorded next to the limit (gpurun_out/r06_parity.json)."""
     value = float(value)
     node = os.environ.get("PYTEST_CURRENT_TEST", "?").split(" ")[0].replace("tests/", "")
     key = f"{node}:{label}"

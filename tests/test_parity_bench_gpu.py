@@ -8,7 +8,7 @@
 The oracle is evaluated on SAMPLED query rows only (first / last row of chunks and 256-row tiles, 64-key tile edges,
 random rows): fp32 `oracle.attention.core_attention` on the CPU with the rows' global positions — restating
 M/core/transformer/dot_product_attention.py:186-289 with the zig-zag ownership of M/training/utils.py:329-341.
-Every achieved rel-L2 / max-abs lands in gpurun_out/r05_parity.json (copied to profiles/; r03_parity.json is the previous round's record); each limit below is
+Every achieved rel-L2 / max-abs lands in gpurun_out/r06_parity.json (copied to profiles/; r03_parity.json is the previous round's record); each limit below is
 <= 1.5 x the value measured on the MI355X.
 """
 import json
