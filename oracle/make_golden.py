@@ -1198,6 +1198,96 @@ def _tree_map(p, f):
     return f(p)
 
 
+HF_LV_SMALL = dict(llm=dict(num_layers=2, hidden=1024, heads=8, kv_groups=2, head_dim=128, ffn=2816, vocab=1024), vit_layers=2,
+                   seq=600, image_at=5, new_tokens=6, weight_seed=77, input_seed=78)
+
+
+def hf_long_vita_case(case=HF_LV_SMALL):
+    """The seeded small LongVITAForCausalLM-layout checkpoint + request shared by the generator below and tests/test_hf_adaptor_gpu.py:
+    -> (config dict like config_14B.json, state dict in bf16 with the HF class's names, input_ids [1, S], images [1, 3, 448, 448] bf16,
+    image_indices [2, 1, 256])."""
+    import json
+    from oracle import llm as ollm, vit as ovit
+    lc = ollm.LLMConfig(**case["llm"])
+    vc = ovit.ViTConfig(num_layers=case["vit_layers"], llm_hidden=lc.hidden)
+    lp = ollm.init_llm_params(lc, seed=case["weight_seed"])
+    vp = ovit.init_vit_params(vc, seed=case["weight_seed"] + 1)
+    sd = dict(ollm.to_hf_state_dict(lp, lc))
+    sd.update(ovit.to_hf_state_dict(vp, vc, prefix="model.vision_model.", projector_prefix="model.vision_projection."))
+    cfg_path = os.path.join(os.path.dirname(os.path.abspath(__file__)), "hf_long_vita_small_config.json")
+    config = json.load(open(cfg_path))
+    g = torch.Generator().manual_seed(case["input_seed"])
+    ids = torch.randint(3, lc.vocab, (1, case["seq"]), generator=g)
+    images = torch.randn(1, 3, 448, 448, generator=g).bfloat16()
+    pos = torch.arange(case["image_at"], case["image_at"] + 256)
+    idx = torch.stack([torch.zeros(1, 256, dtype=torch.long), pos[None]])
+    return config, sd, ids, images, idx, lc, vc
+
+
+def golden_hf_long_vita():
+    """what `LongVITAForCausalLM.forward` / greedy `generate` compute (H/models/long_vita_qwen2_intern/
+    modeling_long_vita.py:74-221, 238-327) on a small seeded checkpoint, fp32 on the CPU.  The class itself does not import against the
+    transformers of this image (5.x: `LossKwargs` and the 4.48 decoder-layer call signature it was written for are gone), so its forward
+    is composed here from the parts it is made of, each UNMODIFIED: the reference's own InternVisionModel and ResamplerProjector
+    (imported from /root/reference as golden_hf_vit does), transformers' Qwen2ForCausalLM (the class LongVITAForCausalLM derives from),
+    and the three lines of :137-147 that scatter the projected features into the embeddings."""
+    import json
+
+    import transformers
+    timm = types.ModuleType("timm"); timm_m = types.ModuleType("timm.models"); timm_l = types.ModuleType("timm.models.layers")
+
+    class DropPath(torch.nn.Identity):
+        def __init__(self, *a, **k):
+            super().__init__()
+
+    timm_l.DropPath = DropPath
+    sys.modules.update({"timm": timm, "timm.models": timm_m, "timm.models.layers": timm_l})
+    for n in ["long_vita", "long_vita.models", "long_vita.models.long_vita_qwen2_intern"]:
+        m = types.ModuleType(n)
+        m.__path__ = [os.path.join(REF, *n.split("."))]
+        sys.modules[n] = m
+    civ = importlib.import_module("long_vita.models.long_vita_qwen2_intern.configuration_intern_vit")
+    miv = importlib.import_module("long_vita.models.long_vita_qwen2_intern.modeling_intern_vit")
+    rp = importlib.import_module("long_vita.models.long_vita_qwen2_intern.resampler_projector")
+    case = HF_LV_SMALL
+    config, sd, ids, images, idx, lc, vc = hf_long_vita_case(case)
+    sd = {k: v.float() for k, v in sd.items()}
+    vcfg = dict(config["visual"]); vcfg["use_flash_attn"] = False
+    hcfg = civ.InternVisionConfig(**vcfg)
+    vision_model = miv.InternVisionModel(hcfg).eval().float()
+    projection = rp.ResamplerProjector(types.SimpleNamespace(hidden_size=lc.hidden), hcfg).eval().float()
+    vision_model.load_state_dict({k[len("model.vision_model."):]: v for k, v in sd.items() if k.startswith("model.vision_model.")})
+    projection.load_state_dict({k[len("model.vision_projection."):]: v for k, v in sd.items() if k.startswith("model.vision_projection.")})
+    qcfg = transformers.Qwen2Config(vocab_size=lc.vocab, hidden_size=lc.hidden, intermediate_size=lc.ffn, num_hidden_layers=lc.num_layers,
+                                    num_attention_heads=lc.heads, num_key_value_heads=lc.kv_groups, rms_norm_eps=lc.eps, rope_theta=lc.rope_theta,
+                                    max_position_embeddings=4096, tie_word_embeddings=False, attention_dropout=0.0)
+    qcfg._attn_implementation = "eager"
+    llm = transformers.Qwen2ForCausalLM(qcfg).eval().float()
+    missing = llm.load_state_dict({k: v for k, v in sd.items() if not k.startswith(("model.vision_model.", "model.vision_projection."))}, strict=False)
+    assert not missing.unexpected_keys and all("rotary" in k or "inv_freq" in k for k in missing.missing_keys), missing
+
+    def forward(tokens):
+        with torch.no_grad():
+            image_embeds = vision_model(images.float()).last_hidden_state              # :91
+            image_embeds = projection(image_embeds[:, 1:, :])                         # :97-98
+            inputs_embeds = llm.model.embed_tokens(tokens)                            # :137
+            inputs_embeds = inputs_embeds.clone()                                     # :142-147
+            indices_b, indices_s = idx.unbind(dim=0)
+            inputs_embeds[indices_b.view(-1), indices_s.view(-1)] = image_embeds.view(-1, image_embeds.shape[-1])
+            return llm(inputs_embeds=inputs_embeds).logits, image_embeds, inputs_embeds
+
+    logits, image_embeds, embeds = forward(ids)
+    tokens, gaps = ids.clone(), []
+    for _ in range(case["new_tokens"]):                                               # greedy search, no cache: the whole row again
+        last = forward(tokens)[0][0, -1]
+        top = torch.topk(last, 2).values
+        gaps.append(float(top[0] - top[1]))
+        tokens = torch.cat([tokens, last.argmax().view(1, 1)], dim=1)
+    torch.save(dict(case=case, logits_rows=logits[0, ::7].clone(), logits_last=logits[0, -1].clone(), image_embeds_sub=image_embeds[0, ::8, ::8].clone(),
+                    embeds_sub=embeds[0, ::5, ::16].clone(), generated=tokens[0, ids.shape[1]:].clone(), top2_gaps=torch.tensor(gaps),
+                    logits_rms=float(logits.pow(2).mean().sqrt())), os.path.join(OUT, "hf_long_vita.pt"))
+
+
 def main():
     os.makedirs(OUT, exist_ok=True)
     _install_stubs()
@@ -1211,7 +1301,7 @@ def main():
                      ("unfused_attention_bf16", golden_unfused_attention_bf16),
                      ("converters", golden_converters), ("sampling", golden_sampling), ("patch_manager", golden_patch_manager),
                      ("adaptor_targets", golden_adaptor_targets), ("packed_positions", golden_packed_positions),
-                     ("ckpt_scripts", golden_ckpt_scripts), ("tp_batch", golden_tp_batch)]:
+                     ("ckpt_scripts", golden_ckpt_scripts), ("tp_batch", golden_tp_batch), ("hf_long_vita", golden_hf_long_vita)]:
         if only and name not in only:
             continue
         fn()

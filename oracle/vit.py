@@ -103,6 +103,27 @@ def megatron_qkv_to_hf(w_or_b: torch.Tensor, heads: int, head_dim: int) -> torch
     return w_or_b.view(heads, 3, head_dim, *rest).transpose(0, 1).reshape(3 * heads * head_dim, *rest)
 
 
+def to_hf_state_dict(p, cfg: ViTConfig, prefix: str = "", projector_prefix: str = None):
+    """Inverse of the converter (L/ckpt_converter_intern_vit.py:54-107): Megatron-layout ViT params -> the names of the reference's HF
+    InternVisionModel (H/models/long_vita_qwen2_intern/modeling_intern_vit.py) and, with projector_prefix, of its ResamplerProjector
+    (resampler_projector.py:15-22)."""
+    sd = {prefix + "embeddings.class_embedding": p["cls"].reshape(1, 1, -1), prefix + "embeddings.patch_embedding.weight": p["conv_w"],
+          prefix + "embeddings.patch_embedding.bias": p["conv_b"], prefix + "embeddings.position_embedding": p["pos"][None]}
+    names = {"proj_w": "attn.proj.weight", "proj_b": "attn.proj.bias", "fc1_w": "mlp.fc1.weight", "fc1_b": "mlp.fc1.bias",
+             "fc2_w": "mlp.fc2.weight", "fc2_b": "mlp.fc2.bias", "ln1_w": "norm1.weight", "ln1_b": "norm1.bias", "ln2_w": "norm2.weight",
+             "ln2_b": "norm2.bias", "ls1": "ls1", "ls2": "ls2"}
+    for i, lp in enumerate(p["layers"]):
+        pre = f"{prefix}encoder.layers.{i}."
+        sd[pre + "attn.qkv.weight"] = megatron_qkv_to_hf(lp["qkv_w"], cfg.heads, cfg.head_dim)
+        sd[pre + "attn.qkv.bias"] = megatron_qkv_to_hf(lp["qkv_b"], cfg.heads, cfg.head_dim)
+        for k, n in names.items():
+            sd[pre + n] = lp[k]
+    if projector_prefix is not None:
+        sd.update({projector_prefix + "pre_proj_layernorm.weight": p["proj_ln_w"], projector_prefix + "pre_proj_layernorm.bias": p["proj_ln_b"],
+                   projector_prefix + "mlp.0.weight": p["proj_fc1"], projector_prefix + "mlp.2.weight": p["proj_fc2"]})
+    return sd
+
+
 def vit_embed(images, p, cfg: ViTConfig):
     """M/core/models/vision/intern_vit_model.py:203-216: conv14/14 + cls + learned pos-emb -> [b, s, h]."""
     x = F.conv2d(images.float(), p["conv_w"].float(), p["conv_b"].float(), stride=cfg.patch).to(images.dtype)

@@ -33,7 +33,10 @@ DEV = "cuda"
 FULL = os.environ.get("VITA_PARITY_FULL", "0") not in ("", "0")
 
 # name -> limit of hip_vs_exact where the suite evaluates `exact` only: 1.5 x the value measured on the MI355X (profiles/r06_parity.json)
-EXACT_LIMITS = {}
+EXACT_LIMITS = {
+    # measured: HIP 4.50e-2, the reference's bf16 chain 4.55e-2 from exact, 4.6e-2 from each other; top-1 agreement with exact 83 % / 80 %
+    "full_depth_S131072_48L": 6.8e-2,
+}
 
 
 @pytest.fixture(scope="module")
