@@ -7,7 +7,7 @@ shard: real values, so the kernels draw the power they would).  Communication ti
 of the scaling question (N-GPU prefill time >= max over ranks of the cell; bench.py's `comm` object reports the rest on real ranks).
 
     python tools/bench_table.py S:CP[:rank[:steps]] ...      e.g.  16384:1 16384:8:3 131072:4:1 1048576:8:3:1
-Appends JSON lines to gpurun_out/r04_table.jsonl."""
+Appends JSON lines to gpurun_out/r06_table.jsonl."""
 import json
 import os
 import sys
@@ -23,7 +23,7 @@ from long_vita_amd import generation, gpt_vl_model, lib, ops, parallel_state as 
 DEV = "cuda:0"
 lib.load(allow_build=False)
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-LOG = open(os.path.join(ROOT, "gpurun_out", "r04_table.jsonl"), "a")
+LOG = open(os.path.join(ROOT, "gpurun_out", "r06_table.jsonl"), "a")
 _real_all_gather = dist.all_gather_into_tensor
 _CP = [1]
 
