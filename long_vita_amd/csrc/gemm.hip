@@ -564,6 +564,20 @@ __device__ __forceinline__ void static_for(F& f) {            // f(std::integral
 }
 namespace w4 {
 constexpr int LINE = 1040, HALF = 16 * LINE, OPB = 2 * HALF, STAGE = 2 * OPB, LDS_BYTES = 2 * STAGE;   // 133120 B
+// the operand-split schedule's LDS-DMA slots: piece j (0 .. 7: A lines, 8 .. 15: W lines) is issued behind MFMA slot PIECE_SLOT[variant][j];
+// A pieces need slot > 21 (barrier 1), W pieces slot > 51 (barrier 2).  Variant 0: the vendor kernel's positions (three bursts of five, every
+// third slot); variant 1: the same window, evenly spaced (every 6 - 7 slots).
+constexpr int PIECE_SLOT[2][16] = {{22, 25, 28, 31, 34, 52, 55, 58, 61, 64, 85, 87, 89, 96, 100, 124},
+                                   {22, 28, 34, 40, 46, 52, 58, 65, 71, 78, 84, 91, 97, 104, 110, 117}};
+constexpr int piece_at(int variant, int slot) {
+  for (int j = 0; j < 16; ++j) if (PIECE_SLOT[variant][j] == slot) return j;
+  return -1;
+}
+constexpr int pieces_before(int variant, int slot) {
+  int n = 0;
+  for (int j = 0; j < 16; ++j) n += PIECE_SLOT[variant][j] < slot;
+  return n;
+}
 }
 
 // INTERIOR = every tile of the problem is whole (M % 256 == 0, N % tile width == 0): chosen at launch, so that each instantiation has
@@ -588,15 +602,25 @@ constexpr int LINE = 1040, HALF = 16 * LINE, OPB = 2 * HALF, STAGE = 2 * OPB, LD
 #ifndef VITA_GEMM_DMA_STEP
 #define VITA_GEMM_DMA_STEP 4       // two-barrier schedule: one LDS-DMA piece every DMA_STEP slots from slot 40 on (5: a same-box A / B of the window's width alone)
 #endif
+#ifndef VITA_GEMM_RD_STEP
+#define VITA_GEMM_RD_STEP 2        // two-barrier schedule: 1 = the 16 second-half reads in consecutive slots, barrier 1 at slot 20, pieces from slot 22
+#endif
+#ifndef VITA_GEMM_SWIGLU_STEP5
+#define VITA_GEMM_SWIGLU_STEP5 1    // 1: fc1 + SwiGLU keeps the two-barrier schedule, with one piece every 5 slots (the variant it measured best with)
+#endif
 #ifndef VITA_GEMM_SCHED
 #define VITA_GEMM_SCHED 1          // 1: operand-split release of the stage, three barriers (r06); 0: the r05 two-barrier schedule (same-box A / B builds)
 #endif
-template <int EPI, bool INTERIOR, int OPM = 0>
-__global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
+template <int EPI, bool INTERIOR, int OPM>
+__device__ __forceinline__ void gemm_w4_tile(const GemmArgs& p, const int bid_) {
   using namespace w4;
   constexpr bool EARLY_NEXT = VITA_GEMM_EARLY_NEXT != 0;
-  constexpr int DMA_STEP = VITA_GEMM_DMA_STEP;
-  static_assert(DMA_STEP == 4 || DMA_STEP == 5, "vmcnt at slot 63 is written out for steps 4 and 5");      // (0: the r02 - r04 placement, kept for same-box A / B builds)
+  // two-barrier schedule, NT one-pass kernels only (the other modes keep the r05 positions): reads of the second-half fragments every RD_STEP
+  // slots from slot 0, barrier 1 at BAR1, one LDS-DMA piece every DMA_STEP slots from DMA0
+  constexpr bool TUNED = OPM == 0 && EPI != VITA_EPI_F32_PARTIAL;
+  constexpr int DMA_STEP = TUNED ? ((VITA_GEMM_SWIGLU_STEP5 && EPI == VITA_EPI_SWIGLU) ? 5 : VITA_GEMM_DMA_STEP) : 4, RD_STEP = TUNED ? VITA_GEMM_RD_STEP : 2;
+  constexpr int BAR1 = RD_STEP == 2 ? 36 : 20, DMA0 = RD_STEP == 2 ? 40 : 22;
+  static_assert(DMA0 + 15 * DMA_STEP < 128 && (RD_STEP == 1 || RD_STEP == 2), "pieces must fit the tile");      // (0: the r02 - r04 placement, kept for same-box A / B builds)
   constexpr bool TN = OPM == 1, TA = OPM == 1, TW = OPM != 0;          // TN: both operands contraction-major; TA / TW: per operand
   constexpr int STG = TN ? 65536 : STAGE, OPBS = TA ? 32768 : OPB;
   extern __shared__ __attribute__((aligned(16))) char smem[];
@@ -609,7 +633,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   const int nwg = p.tiles_m * p.tiles_n * (SPLITK ? p.splits : 1);
   int pid;
   {
-    const int bid = blockIdx.x, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
+    const int bid = bid_, xcd = bid & 7, q = nwg >> 3, r = nwg & 7;
     pid = (xcd < r ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q) + (bid >> 3);
   }
   // split-K: the split is the SLOW index, so that the workgroups an XCD runs side by side are tiles of one K range sharing operand panels
@@ -676,7 +700,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   const int64_t kstep_a = TA ? (int64_t)BK * p.lda * 2 : BK * 2, kstep_w = TW ? (int64_t)BK * p.ldw * 2 : BK * 2;
   // developer aid VITA_GEMM_STAGGER=1 (NT, no split): XCD x starts its K loop at tile x nk / 8 and wraps, so that the eight XCDs do not
   // pull the same K range of their panels through the fabric at the same time (the accumulation order of a tile then depends on its XCD)
-  int kt_fetch = (OPM == 0 && !SPLITK && p.stagger == 1) ? (int)(((int64_t)(blockIdx.x & 7) * nk) >> 3) : 0;
+  int kt_fetch = (OPM == 0 && !SPLITK && p.stagger == 1) ? (int)(((int64_t)(bid_ & 7) * nk) >> 3) : 0;
   int64_t koff_a = SPLITK ? (int64_t)split * p.k_tiles_per_split * kstep_a : kt_fetch * kstep_a;     // byte offsets of the K tile fetched next
   int64_t koff_w = SPLITK ? (int64_t)split * p.k_tiles_per_split * kstep_w : kt_fetch * kstep_w;
   auto dma_piece = [&](unsigned stage, int j) __attribute__((always_inline)) {              // j = 0..7: A lines, 8..15: W lines
@@ -788,7 +812,9 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   // vmcnt(13) — the 13 pieces of tile t + 2 issued by then stay in flight — and tile t + 1's first-half fragments are read in slots 93 .. 123.
   // The pieces go out in three bursts of five (every third slot) with 18 .. 21 slots of nothing between them, over slots 22 .. 124: the slot
   // positions are the ones the vendor library's MT256x256x64 kernel uses (read off its disassembly: profiles/r06_gemm_schedules.txt).
-  constexpr bool SPLIT_SCHED = VITA_GEMM_SCHED == 1 && OPM == 0 && !SPLITK;
+  constexpr bool SPLIT_SCHED = VITA_GEMM_SCHED >= 1 && OPM == 0 && !SPLITK && !(VITA_GEMM_SWIGLU_STEP5 && EPI == VITA_EPI_SWIGLU);
+  constexpr int SPLIT_VARIANT = VITA_GEMM_SCHED >= 2 ? 1 : 0;
+  constexpr bool PACED_READS = VITA_GEMM_SCHED >= 3;       // 3: fragment reads every other slot (the two-barrier schedule's pace) instead of the vendor's positions
   auto tile_split = [&](const bool DMA, const bool NEXT, unsigned cur, unsigned nxt) __attribute__((always_inline)) {
     const StageBases bcur = bases_of(cur), bnxt = bases_of(NEXT ? nxt : cur);
     // (the slot number is a template constant — std::integral_constant through a generic lambda — so that every fragment / piece index below is a
@@ -799,35 +825,42 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
       asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[nb][mb]) : "v"(wf[ks][nb]), "v"(af[ks][mb]));
       // second-half fragments of `cur`: A blocks 0 .. 7 (q = 1 .. 8), then W blocks 0 .. 7 (q = 0, 9 .. 15)
       if constexpr (s <= 14 && (s & 1) == 0) frag_read(bcur, 1, 1 + (s >> 1));
-      if constexpr (s == 24) frag_read(bcur, 1, 0);
-      if constexpr (s == 27 || s == 30 || s == 33 || s == 36) frag_read(bcur, 1, 9 + (s - 27) / 3);
-      if constexpr (s == 38 || s == 40 || s == 42) frag_read(bcur, 1, 13 + (s - 38) / 2);
+      if constexpr (!PACED_READS) {
+        if constexpr (s == 24) frag_read(bcur, 1, 0);
+        if constexpr (s == 27 || s == 30 || s == 33 || s == 36) frag_read(bcur, 1, 9 + (s - 27) / 3);
+        if constexpr (s == 38 || s == 40 || s == 42) frag_read(bcur, 1, 13 + (s - 38) / 2);
+      } else {                                       // every other slot, 24 .. 38
+        if constexpr (s == 24) frag_read(bcur, 1, 0);
+        if constexpr (s >= 26 && s <= 38 && (s & 1) == 0) frag_read(bcur, 1, 9 + (s - 26) / 2);
+      }
       if constexpr (s == 21 || s == 51) {
         if (DMA) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       }
       if (DMA) {
-        if constexpr (s >= 22 && s <= 34 && (s - 22) % 3 == 0) dma_piece(cur, (s - 22) / 3);              // A 0 .. 4
-        if constexpr (s >= 52 && s <= 58 && (s - 52) % 3 == 0) dma_piece(cur, 5 + (s - 52) / 3);          // A 5 .. 7
-        if constexpr (s == 61 || s == 64) dma_piece(cur, 8 + (s - 61) / 3);                               // W 0, 1
-        if constexpr (s == 85 || s == 87 || s == 89) dma_piece(cur, 10 + (s - 85) / 2);                   // W 2 .. 4
-        if constexpr (s == 96 || s == 100) dma_piece(cur, 13 + (s - 96) / 4);                             // W 5, 6
-        if constexpr (s == 124) dma_piece(cur, 15);                                                       // W 7
+        constexpr int pj = w4::piece_at(SPLIT_VARIANT, s);
+        if constexpr (pj >= 0) dma_piece(cur, pj);
       }
       if constexpr (s == 92) {
         if (NEXT) {
-          if (DMA) asm volatile("s_waitcnt vmcnt(13)\n\ts_barrier" ::: "memory");
+          if (DMA) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(w4::pieces_before(SPLIT_VARIANT, 92)) : "memory");
           else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
       }
       if (NEXT) {                                   // first-half fragments of `nxt`: A blocks, then W blocks
-        if constexpr (s == 93 || s == 94 || s == 95) frag_read(bnxt, 0, 1 + (s - 93));
-        if constexpr (s == 97 || s == 98) frag_read(bnxt, 0, 4 + (s - 97));
-        if constexpr (s == 102 || s == 103 || s == 104) frag_read(bnxt, 0, 6 + (s - 102));
-        if constexpr (s == 105) frag_read(bnxt, 0, 0);
-        if constexpr (s == 106) frag_read(bnxt, 0, 9);
-        if constexpr (s == 109 || s == 112) frag_read(bnxt, 0, 10 + (s - 109) / 3);
-        if constexpr (s == 114) frag_read(bnxt, 0, 12);
-        if constexpr (s == 117 || s == 120 || s == 123) frag_read(bnxt, 0, 13 + (s - 117) / 3);
+        if constexpr (!PACED_READS) {
+          if constexpr (s == 93 || s == 94 || s == 95) frag_read(bnxt, 0, 1 + (s - 93));
+          if constexpr (s == 97 || s == 98) frag_read(bnxt, 0, 4 + (s - 97));
+          if constexpr (s == 102 || s == 103 || s == 104) frag_read(bnxt, 0, 6 + (s - 102));
+          if constexpr (s == 105) frag_read(bnxt, 0, 0);
+          if constexpr (s == 106) frag_read(bnxt, 0, 9);
+          if constexpr (s == 109 || s == 112) frag_read(bnxt, 0, 10 + (s - 109) / 3);
+          if constexpr (s == 114) frag_read(bnxt, 0, 12);
+          if constexpr (s == 117 || s == 120 || s == 123) frag_read(bnxt, 0, 13 + (s - 117) / 3);
+        } else {                                     // every other slot, 93 .. 123
+          if constexpr (s >= 93 && s <= 107 && (s & 1) == 1) frag_read(bnxt, 0, 1 + (s - 93) / 2);
+          if constexpr (s == 109) frag_read(bnxt, 0, 0);
+          if constexpr (s >= 111 && s <= 123 && (s & 1) == 1) frag_read(bnxt, 0, 9 + (s - 111) / 2);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     };
@@ -846,11 +879,11 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
     auto slot = [&](const int s) __attribute__((always_inline)) {
       const int ks = s >> 6, nb = (s >> 3) & 7, mb = s & 7;
       asm volatile("v_mfma_f32_16x16x32_bf16 %0, %1, %2, %0" : "+a"(acc[nb][mb]) : "v"(wf[ks][nb]), "v"(af[ks][mb]));
-      if (s <= 30 && (s & 1) == 0) frag_read(bcur, 1, s >> 1);
-      if (s == 36) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      if (s < 16 * RD_STEP && s % RD_STEP == 0) frag_read(bcur, 1, s / RD_STEP);
+      if (s == BAR1) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       // (r05 null: wave w issuing its piece at slot 40 + 4 j + w instead of all four waves in the same slot — so that the four requests do
       // not queue in the CU's one texture addresser — is 19 % SLOWER: the 64 wave-dependent scalar branches per tile cost more than the queue.)
-      if (DMA && s >= 40 && s < 40 + 16 * DMA_STEP && (s - 40) % DMA_STEP == 0) dma_piece(cur, (s - 40) / DMA_STEP);
+      if (DMA && s >= DMA0 && s < DMA0 + 16 * DMA_STEP && (s - DMA0) % DMA_STEP == 0) dma_piece(cur, (s - DMA0) / DMA_STEP);
       if (EARLY_NEXT) {
         // r05: the next tile's first-half fragments are read at the LDS port's pace — one ds_read_b128 every other slot from slot 64 on,
         // where the first-half registers are dead (slots 0 .. 63 were their last readers) — instead of 16 back to back behind slot
@@ -859,10 +892,7 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
         // Same-box A / B at 128K rows: fc2 13.44 -> 12.96 ms, fc1 + SwiGLU 26.3 -> 25.5, o 4.91 -> 4.81, qkv at 16K 0.859 -> 0.851.
         // (Going on to ONE barrier per tile — at slot 63, the DMA of tile t + 2 issued behind it — was mixed: fc1 - 3 %, fc2 + 1 %.)
         if (NEXT && s == 63) {
-          if (DMA) {
-            if (DMA_STEP == 4) asm volatile("s_waitcnt vmcnt(6)\n\ts_barrier" ::: "memory");       // pieces of tile t + 2 issued by slot 63: 40, 44 .. 60
-            else asm volatile("s_waitcnt vmcnt(5)\n\ts_barrier" ::: "memory");                      // step 5: 40, 45 .. 60
-          }
+          if (DMA) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"((63 - DMA0) / DMA_STEP + 1) : "memory");    // the pieces of tile t + 2 issued by slot 63 stay in flight
           else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
         if (NEXT && s >= 64 && s < 96 && (s & 1) == 0) frag_read(bnxt, 0, (s - 64) >> 1);
@@ -878,10 +908,10 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
     // (two loops: the TN fragment assembly sits between them, outside either body — with it inside, the fully unrolled 128-slot
     // loop exceeded the optimizer's pragma-unroll size limit, stayed a loop, and the accumulators went to scratch)
 #pragma unroll
-    for (int s = 0; s <= 36; ++s) slot(s);
+    for (int s = 0; s <= BAR1; ++s) slot(s);
     frag_commit(1);
 #pragma unroll
-    for (int s = 37; s < 128; ++s) slot(s);
+    for (int s = BAR1 + 1; s < 128; ++s) slot(s);
     if (DMA) next_tile();
     if (NEXT) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
@@ -1017,6 +1047,25 @@ __global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
   }
 }
 
+// r06, VITA_GEMM_PERSIST 1 (a same-box A / B of PERSISTENCE ALONE; off): a grid of one workgroup per CU, each walking the tiles bid, bid + grid, ...
+// (bid % 8 — the XCD the tile order is built on — is the same for all of them).  Nothing is carried from one tile to the next: the prologue of tile
+// i + 1 starts behind the epilogue of tile i, after a workgroup barrier (a wave that is done must not refill a stage a slower wave still reads).
+#ifndef VITA_GEMM_PERSIST
+#define VITA_GEMM_PERSIST 0
+#endif
+template <int EPI, bool INTERIOR, int OPM = 0>
+__global__ __launch_bounds__(256, 1) void gemm_w4_kernel(GemmArgs p) {
+  if (VITA_GEMM_PERSIST && OPM == 0 && EPI != VITA_EPI_F32_PARTIAL) {
+    const int nwg = p.tiles_m * p.tiles_n;
+    for (int bid = blockIdx.x; bid < nwg; bid += gridDim.x) {
+      gemm_w4_tile<EPI, INTERIOR, OPM>(p, bid);
+      __syncthreads();
+    }
+  } else {
+    gemm_w4_tile<EPI, INTERIOR, OPM>(p, blockIdx.x);
+  }
+}
+
 template <int EPI, bool INTERIOR>
 int launch_gemm_w4_cfg(const GemmArgs& a, hipStream_t st) {
   static std::atomic<unsigned long long> attr_set{0};
@@ -1024,7 +1073,9 @@ int launch_gemm_w4_cfg(const GemmArgs& a, hipStream_t st) {
     (void)hipFuncSetAttribute(reinterpret_cast<const void*>(&gemm_w4_kernel<EPI, INTERIOR>), hipFuncAttributeMaxDynamicSharedMemorySize,
                               w4::LDS_BYTES);
   });
-  hipLaunchKernelGGL((gemm_w4_kernel<EPI, INTERIOR>), dim3((unsigned)(a.tiles_m * a.tiles_n)), dim3(256), w4::LDS_BYTES, st, a);
+  unsigned grid = (unsigned)(a.tiles_m * a.tiles_n);
+  if (VITA_GEMM_PERSIST && grid > 256u) grid = 256u;            // one workgroup per CU (256 = 8 XCDs x 32)
+  hipLaunchKernelGGL((gemm_w4_kernel<EPI, INTERIOR>), dim3(grid), dim3(256), w4::LDS_BYTES, st, a);
   return vita_check_launch();
 }
 
