@@ -34,6 +34,7 @@ Prints ONE JSON line on rank 0 (contract in the task statement) with these extra
 from __future__ import annotations
 
 import argparse
+import datetime
 import json
 import os
 import sys
@@ -49,6 +50,9 @@ import torch  # noqa: E402
 import torch.distributed as dist  # noqa: E402
 
 MFMA_BF16_PEAK_TFLOPS = 2500.0        # MI355X dense bf16 (MI355X_MICROARCH.md)
+
+
+FIRST_CONTACT_TIMEOUT_S = 300          # N > 1: how long a rank waits in a collective / in the first-step vote for a peer that is gone
 
 
 def committed_pmc_sets():
@@ -359,7 +363,8 @@ def main():
 
     if args.dry_run:
         args.seq, args.layers, args.vit_layers, args.frames, args.no_cpu_baseline = 4096, 2, 2, 8, True
-    force_spawn = os.environ.get("VITA_BENCH_FORCE_SPAWN", "0") == "1"       # tests: walk the self-launch with N = 1
+    # test hooks (VITA_BENCH_FORCE_SPAWN, VITA_BENCH_INJECT_FAILURE) are honoured under --dry-run only: the measured entry point has none
+    force_spawn = args.dry_run and os.environ.get("VITA_BENCH_FORCE_SPAWN", "0") == "1"       # tests: walk the self-launch with N = 1
     if "WORLD_SIZE" not in os.environ and (args.gpus > 1 or force_spawn):
         raise SystemExit(self_launch(args.gpus, sys.argv[1:], args.steps, args.warmup))
     rank = int(os.environ.get("RANK", "0"))
@@ -385,9 +390,13 @@ def main():
             import gloo_staging
             gloo_staging.install()
         else:
-            dist.init_process_group("nccl", device_id=torch.device(dev))
-        # a control plane that does not ride on the thing being tested: the "did every rank get through the first step" vote
-        ctl = dist.new_group(backend="gloo")
+            dist.init_process_group("nccl", device_id=torch.device(dev), timeout=datetime.timedelta(seconds=FIRST_CONTACT_TIMEOUT_S))
+        # a control plane that does not ride on the thing being tested: the "did every rank get through the first step" vote.
+        # The vote covers failures EVERY rank sees (a collective that raises everywhere).  If ONE rank raises while the others sit in that
+        # step's all-gather, they never reach the vote: RCCL's watchdog ends them after FIRST_CONTACT_TIMEOUT_S, the rank waiting in the vote
+        # gives up after the same time (the gloo group's timeout), and the self-launcher's ONE relaunch on the plain schedule takes over
+        # (a run started by an outside launcher has no second attempt: its ranks exit non-zero) — ADVICE r05.
+        ctl = dist.new_group(backend="gloo", timeout=datetime.timedelta(seconds=FIRST_CONTACT_TIMEOUT_S))
 
     from long_vita_amd import generation, gpt_vl_model, lib, parallel_state as mpu, synthetic, vision
     lib.load(allow_build=False)                      # the HIP path or nothing
@@ -416,7 +425,7 @@ def main():
     if ctl is not None:
         ok, why = 1, ""
         try:
-            inject = os.environ.get("VITA_BENCH_INJECT_FAILURE") if degraded is None else None      # tests only
+            inject = os.environ.get("VITA_BENCH_INJECT_FAILURE") if (degraded is None and args.dry_run) else None      # tests only
             if inject == "exit":
                 os._exit(3)                         # a rank that dies: the self-launcher's second attempt
             if inject == "1":

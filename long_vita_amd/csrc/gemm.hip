@@ -1420,10 +1420,9 @@ extern "C" size_t vita_colsum_workspace_bytes(int64_t rows, int cols) {
   return (size_t)((rows + rpb - 1) / rpb) * (size_t)cols * sizeof(float);
 }
 extern "C" int vita_colsum_bf16_ordered(const void* x, int64_t ldx, float* out, int64_t rows, int cols, void* workspace, void* stream) {
-  if (!x || !out || rows < 0 || cols <= 0) return VITA_ERR_INVALID_ARG;
+  if (!x || !out || rows < 0 || cols <= 0 || (rows > 0 && !workspace)) return VITA_ERR_INVALID_ARG;
   if ((cols & 3) || (ldx & 3) || ((uintptr_t)out & 15) || ((uintptr_t)workspace & 15)) return VITA_ERR_UNSUPPORTED;
   if (rows == 0) return VITA_OK;
-  if (!workspace) return VITA_ERR_INVALID_ARG;
   const int gx = (cols / 4 + 255) / 256;
   const int64_t rpb = colsum_rows_per_block(rows);
   const int64_t gy = (rows + rpb - 1) / rpb;

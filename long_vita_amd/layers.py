@@ -47,6 +47,9 @@ def _add_extra_state_hook(module: torch.nn.Module) -> None:
     """layers.py:819-823: checkpoints written without TE have no `_extra_state` entry."""
     module._register_load_state_dict_pre_hook(
         lambda state_dict, prefix, *args, **kwargs: state_dict.setdefault(f"{prefix}_extra_state"))
+    # a checkpoint load rewrites frozen weights too: drop the zero-padded copies ops.gemm keeps of them (ADVICE r05; `copy_` bumps torch's
+    # version counter, loaders that assign through `.data` do not)
+    module.register_load_state_dict_post_hook(lambda m, incompatible_keys: ops.invalidate_padded_weights())
 
 
 class _TEStateMixin:
