@@ -544,14 +544,7 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
     const int64_t orow = (int64_t)qc * p.chunk_len + q_off + 32 * qb + l31;
     bf16_t* op = p.o + (int64_t)b * p.o_bs + orow * p.o_rs + (int64_t)kvh * p.o_gs + (int64_t)hq * p.o_hs;
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int d = 32 * db + 8 * rg + 4 * hi;
-        const u32x2 w = {pack_bf16x2(o[qb][db][rg * 4 + 0] * inv, o[qb][db][rg * 4 + 1] * inv),
-                         pack_bf16x2(o[qb][db][rg * 4 + 2] * inv, o[qb][db][rg * 4 + 3] * inv)};
-        *reinterpret_cast<u32x2*>(op + d) = w;
-      }
+    for (int db = 0; db < 4; ++db) store_row_block32(op + 32 * db, o[qb][db], inv, hi);       // two 16-byte stores per block (r06)
     if (p.lse && hi == 0) {
       const float lse = l_tot > 0.f ? (m_run[qb] + log2f(l_tot)) * 0.69314718055994530942f : -INFINITY;
       p.lse[((int64_t)b * p.n_q_heads + head) * p.n_q_rows + orow] = lse;
@@ -565,6 +558,8 @@ bool vita_attn64_eligible(const AttnArgs& a, int head_dim, bool causal) {
   if (head_dim != 128 || !causal) return false;
   if (a.seg_start && (a.n_q_chunks != 1 || a.n_kv_chunks != 1 || a.batch != 1)) return false;     // packed samples: one chunk (CP = 1)
   if (a.chunk_len % QTILE || a.q_valid != a.chunk_len || a.kv_valid != a.chunk_len) return false;
+  // 16-byte output stores (r06)
+  if (((uintptr_t)a.o & 15) || (a.o_rs & 7) || (a.o_hs & 7) || (a.o_gs & 7) || (a.o_bs & 7)) return false;
   // a tile's 64 rows x row stride must fit the 32-bit lane offset of the DMA
   if (a.k_rs * 2 * KVT >= (1ll << 31) || a.v_rs * 2 * KVT >= (1ll << 31)) return false;
   // (a query chunk sees whole chunks, its own up to the diagonal, or nothing: the tile count is 0 or a multiple of 4)

@@ -402,14 +402,7 @@ __device__ __forceinline__ void fwd64v_body(const AttnArgs& p, const unsigned ld
     if (orow > q_last) continue;
     bf16_t* op = p.o + (int64_t)b * p.o_bs + (int64_t)orow * p.o_rs + (int64_t)kvh * p.o_gs + (int64_t)hq * p.o_hs;
 #pragma unroll
-    for (int db = 0; db < 2; ++db)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int d = 32 * db + 8 * rg + 4 * hi;
-        const u32x2 w = {pack_bf16x2(o[qb][db][rg * 4 + 0] * inv, o[qb][db][rg * 4 + 1] * inv),
-                         pack_bf16x2(o[qb][db][rg * 4 + 2] * inv, o[qb][db][rg * 4 + 3] * inv)};
-        *reinterpret_cast<u32x2*>(op + d) = w;
-      }
+    for (int db = 0; db < 2; ++db) store_row_block32(op + 32 * db, o[qb][db], inv, hi);       // two 16-byte stores per block (r06)
     if (p.lse && hi == 0) {
       const float lse = l_tot > 0.f ? (m_run[qb] + log2f(l_tot)) * 0.69314718055994530942f : -INFINITY;
       p.lse[((int64_t)b * p.n_q_heads + head) * p.n_q_rows + orow] = lse;
@@ -447,6 +440,7 @@ __global__ __launch_bounds__(512, 2) void flash_fwd64v8_kernel(AttnArgs p) { fwd
 bool vita_attn64v_eligible(const AttnArgs& a, int head_dim, bool causal) {
   if (head_dim != 64 || causal || a.seg_start) return false;
   if (a.n_q_chunks != 1 || a.n_kv_chunks != 1 || a.kv_row[0] != 0) return false;
+  if (((uintptr_t)a.o & 15) || (a.o_rs & 7) || (a.o_hs & 7) || (a.o_gs & 7) || (a.o_bs & 7)) return false;       // 16-byte output stores (r06)
   // a tile's 64 rows x row stride is the buffer descriptor's 32-bit extent and the lanes' 32-bit offsets
   if (a.k_rs * 2 * KVT >= (1ll << 31) || a.v_rs * 2 * KVT >= (1ll << 31)) return false;
   const char* e = vita_dev_getenv("VITA_ATTN64V");                                 // developer A / B switch: 0 = the r01 kernel (attn.hip)

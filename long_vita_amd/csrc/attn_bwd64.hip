@@ -363,14 +363,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(BwdArgs p) {
     const int64_t orow = (int64_t)qc * p.chunk_len + q_off + 32 * qb + l31;
     bf16_t* op = p.dq + orow * p.dq_rs + (int64_t)kvh * p.dq_gs + (int64_t)hq * p.dq_hs;
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int d = 32 * db + 8 * rg + 4 * hi;
-        const u32x2 w = {pack_bf16x2(o[qb][db][rg * 4 + 0], o[qb][db][rg * 4 + 1]),
-                         pack_bf16x2(o[qb][db][rg * 4 + 2], o[qb][db][rg * 4 + 3])};
-        *reinterpret_cast<u32x2*>(op + d) = w;
-      }
+    for (int db = 0; db < 4; ++db) store_row_block32(op + 32 * db, o[qb][db], 1.0f, hi);      // two 16-byte stores per block (r06)
   }
 }
 
@@ -379,6 +372,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(BwdArgs p) {
 bool vita_attn_bwd_dq64_eligible(const BwdArgs& a) {
   if (a.head_dim != 128) return false;                       // the 64-rows-per-wave kernels are built for d = 128
   if (a.chunk_len % QTILE) return false;
+  if (((uintptr_t)a.dq & 15) || (a.dq_rs & 7) || (a.dq_hs & 7) || (a.dq_gs & 7)) return false;                      // 16-byte output stores (r06)
   if (a.seg_start && (a.n_q_chunks != 1 || a.n_kv_chunks != 1)) return false;      // packed samples: one chunk
   for (int i = 0; i < a.n_q_chunks; ++i) {           // every query chunk meets its own keys (the diagonal) in this launch
     bool found = false;

@@ -410,14 +410,7 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_kv64_kernel(BwdArgs p) {
     const int64_t orow = k_row0 + 32 * kb + l31;
     bf16_t* op = IS_DK ? p.dk + orow * p.dk_rs + (int64_t)kvh * p.dk_hs : p.dv + orow * p.dv_rs + (int64_t)kvh * p.dv_hs;
 #pragma unroll
-    for (int db = 0; db < 4; ++db)
-#pragma unroll
-      for (int rg = 0; rg < 4; ++rg) {
-        const int d = 32 * db + 8 * rg + 4 * hi;
-        const u32x2 w = {pack_bf16x2(o[kb][db][rg * 4 + 0], o[kb][db][rg * 4 + 1]),
-                         pack_bf16x2(o[kb][db][rg * 4 + 2], o[kb][db][rg * 4 + 3])};
-        *reinterpret_cast<u32x2*>(op + d) = w;
-      }
+    for (int db = 0; db < 4; ++db) store_row_block32(op + 32 * db, o[kb][db], 1.0f, hi);      // two 16-byte stores per block (r06)
   }
 }
 
@@ -439,6 +432,7 @@ int launch_kv64(const BwdArgs& a, hipStream_t st) {
 bool vita_attn_bwd_kv64_eligible(const BwdArgs& a) {
   if (a.head_dim != 128) return false;                       // the 64-rows-per-wave kernels are built for d = 128
   if (a.chunk_len % KTILE) return false;                    // (a key chunk sees whole chunks, its own from the diagonal on, or nothing)
+  if (((uintptr_t)a.dk & 15) || ((uintptr_t)a.dv & 15) || (a.dk_rs & 7) || (a.dk_hs & 7) || (a.dv_rs & 7) || (a.dv_hs & 7)) return false;   // 16-byte stores (r06)
   if (a.seg_start && (a.n_q_chunks != 1 || a.n_kv_chunks != 1)) return false;      // packed samples: one chunk
   if ((int64_t)QT * a.q_rs * 2 > 0x7fffffffLL || (int64_t)QT * a.do_rs * 2 > 0x7fffffffLL) return false;
   const char* e = vita_dev_getenv("VITA_ATTN_BWD64");

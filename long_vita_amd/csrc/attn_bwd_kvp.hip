@@ -562,14 +562,7 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
     for (int kb = 0; kb < 2; ++kb) {
       bf16_t* op = out + (k_row0 + 32 * kb + l31) * out_rs;
   #pragma unroll
-      for (int db = 0; db < 4; ++db)
-  #pragma unroll
-        for (int rg = 0; rg < 4; ++rg) {
-          const int d = 32 * db + 8 * rg + 4 * hi;
-          const u32x2 w = {pack_bf16x2(o[kb][db][rg * 4 + 0], o[kb][db][rg * 4 + 1]),
-                           pack_bf16x2(o[kb][db][rg * 4 + 2], o[kb][db][rg * 4 + 3])};
-          *reinterpret_cast<u32x2*>(op + d) = w;
-        }
+      for (int db = 0; db < 4; ++db) store_row_block32(op + 32 * db, o[kb][db], 1.0f, hi);    // two 16-byte stores per block (r06)
     }
     // the counted `vmcnt` waits of the next key block assume that nothing but its own LDS-DMA is in flight: drain the stores above
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");

@@ -73,6 +73,39 @@ __device__ __forceinline__ float block_reduce_sum(float v, float* red) {
 
 // RoPE (non-interleaved halves), bf16 rounding chain of rotary_pos_embedding.py:200-203 — shared by rope.hip and decode.hip
 // rotate one pair of 8-wide vectors (x1 = first half, x2 = second half) with cos/sin vectors.
+// ---- store of one 32 x 32 accumulator block of a "row per lane" epilogue (attention O, dQ, dK, dV) --------------------------------------
+// The lane holds columns 8 rg + 4 hi .. + 3 (rg = 0 .. 3, hi = lane / 32) of ITS row in acc[4 rg .. 4 rg + 3]: lane i and lane i + 32 own
+// the two 8-byte halves of every 16-byte column group.  r06: column groups (rg, rg + 1) are exchanged between the half-waves with
+// v_permlane32_swap (lanes 32-63 of the first operand swap with lanes 0-31 of the second), after which the lower lanes hold group rg
+// whole and the upper lanes group rg + 1 whole: two 16-byte stores per block instead of four 8-byte ones.  A workgroup's store tail is
+// bound by store ISSUE, not bytes (MI355X_MICROARCH.md: ~9.3 k -> ~5.3 k cycles for the attention forward's shape).  `dst` = the row's
+// first column of this block; it must be 16-byte aligned (the launchers check the strides).  Both lanes of a pair must be active.
+// VITA_WIDE_STORE 0 builds the r05 form (same-box A / B).
+#ifndef VITA_WIDE_STORE
+#define VITA_WIDE_STORE 1
+#endif
+template <class Acc>
+__device__ __forceinline__ void store_row_block32(bf16_t* dst, const Acc& acc, float scale, int hi) {
+#if VITA_WIDE_STORE
+#pragma unroll
+  for (int pr = 0; pr < 2; ++pr) {
+    const int k0 = 8 * pr, k1 = 8 * pr + 4;                      // accumulator registers of groups rg = 2 pr and 2 pr + 1
+    const unsigned a0 = pack_bf16x2(acc[k0 + 0] * scale, acc[k0 + 1] * scale), a1 = pack_bf16x2(acc[k0 + 2] * scale, acc[k0 + 3] * scale);
+    const unsigned b0 = pack_bf16x2(acc[k1 + 0] * scale, acc[k1 + 1] * scale), b1 = pack_bf16x2(acc[k1 + 2] * scale, acc[k1 + 3] * scale);
+    const auto r0 = __builtin_amdgcn_permlane32_swap(a0, b0, false, false);
+    const auto r1 = __builtin_amdgcn_permlane32_swap(a1, b1, false, false);
+    const u32x4 w = {r0[0], r1[0], r0[1], r1[1]};
+    *reinterpret_cast<u32x4*>(dst + 16 * pr + 8 * hi) = w;
+  }
+#else
+#pragma unroll
+  for (int rg = 0; rg < 4; ++rg) {
+    const u32x2 w = {pack_bf16x2(acc[rg * 4 + 0] * scale, acc[rg * 4 + 1] * scale), pack_bf16x2(acc[rg * 4 + 2] * scale, acc[rg * 4 + 3] * scale)};
+    *reinterpret_cast<u32x2*>(dst + 8 * rg + 4 * hi) = w;
+  }
+#endif
+}
+
 __device__ __forceinline__ void rope_rotate8(u32x4& x1, u32x4& x2, const u32x4& c, const u32x4& s,
                                              float sign) {
   u32x4 o1, o2;
