@@ -602,6 +602,9 @@ constexpr int pieces_before(int variant, int slot) {
 #ifndef VITA_GEMM_DMA_STEP
 #define VITA_GEMM_DMA_STEP 4       // two-barrier schedule: one LDS-DMA piece every DMA_STEP slots from slot 40 on (5: a same-box A / B of the window's width alone)
 #endif
+#ifndef VITA_GEMM_DMA_STEP_OTHER
+#define VITA_GEMM_DMA_STEP_OTHER 5 // the TN / NN / split-K modes (weight and input gradients): one piece every DMA_STEP_OTHER slots from slot 40 on
+#endif
 #ifndef VITA_GEMM_RD_STEP
 #define VITA_GEMM_RD_STEP 2        // two-barrier schedule: 1 = the 16 second-half reads in consecutive slots, barrier 1 at slot 20, pieces from slot 22
 #endif
@@ -618,7 +621,7 @@ __device__ __forceinline__ void gemm_w4_tile(const GemmArgs& p, const int bid_) 
   // two-barrier schedule, NT one-pass kernels only (the other modes keep the r05 positions): reads of the second-half fragments every RD_STEP
   // slots from slot 0, barrier 1 at BAR1, one LDS-DMA piece every DMA_STEP slots from DMA0
   constexpr bool TUNED = OPM == 0 && EPI != VITA_EPI_F32_PARTIAL;
-  constexpr int DMA_STEP = TUNED ? ((VITA_GEMM_SWIGLU_STEP5 && EPI == VITA_EPI_SWIGLU) ? 5 : VITA_GEMM_DMA_STEP) : 4, RD_STEP = TUNED ? VITA_GEMM_RD_STEP : 2;
+  constexpr int DMA_STEP = TUNED ? ((VITA_GEMM_SWIGLU_STEP5 && EPI == VITA_EPI_SWIGLU) ? 5 : VITA_GEMM_DMA_STEP) : VITA_GEMM_DMA_STEP_OTHER, RD_STEP = TUNED ? VITA_GEMM_RD_STEP : 2;
   constexpr int BAR1 = RD_STEP == 2 ? 36 : 20, DMA0 = RD_STEP == 2 ? 40 : 22;
   static_assert(DMA0 + 15 * DMA_STEP < 128 && (RD_STEP == 1 || RD_STEP == 2), "pieces must fit the tile");      // (0: the r02 - r04 placement, kept for same-box A / B builds)
   constexpr bool TN = OPM == 1, TA = OPM == 1, TW = OPM != 0;          // TN: both operands contraction-major; TA / TW: per operand

@@ -19,7 +19,7 @@
             the figure is the rank's compute time with zero exposed communication — to be put beside the modelled one.
 
     python tools/bench_config5.py rank [step [N]] [rankstep [N]]
-Writes JSON lines to gpurun_out/r05_config5.jsonl."""
+Writes JSON lines to gpurun_out/r06_config5.jsonl."""
 import json
 import os
 import sys
@@ -34,7 +34,7 @@ from long_vita_amd import gpt_vl_model, lib, ops, training  # noqa: E402
 DEV = "cuda:0"
 OUT = os.path.join(ROOT, "gpurun_out")
 os.makedirs(OUT, exist_ok=True)
-LOG = open(os.path.join(OUT, "r05_config5.jsonl"), "a")
+LOG = open(os.path.join(OUT, "r06_config5.jsonl"), "a")
 lib.load(allow_build=False)
 
 
