@@ -25,7 +25,7 @@ def golden_dir():
 def load_golden(name):
     import torch
 
-    return torch.load(os.path.join(GOLDEN, name), weights_only=False)
+    return torch.load(os.path.join(GOLDEN, name), weights_only=True)    # plain tensors / numbers / strings only: no code runs on load
 
 
 PARITY_OUT = os.environ.get("VITA_PARITY_OUT", os.path.join(ROOT, "gpurun_out", "r06_parity.json"))

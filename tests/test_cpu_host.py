@@ -517,7 +517,7 @@ import os, sys, torch, torch.distributed as dist
 sys.path.insert(0, os.environ["VITA_ROOT"])
 from long_vita_amd import parallel_state as mpu, training_utils as tu
 from oracle.make_golden import TP_BATCH_CASES, tp_batch_data
-g = torch.load(os.path.join(os.environ["VITA_ROOT"], "tests", "golden", "tp_batch.pt"), weights_only=False)
+g = torch.load(os.path.join(os.environ["VITA_ROOT"], "tests", "golden", "tp_batch.pt"), weights_only=True)
 rank = int(os.environ["RANK"])
 dist.init_process_group("gloo", rank=rank, world_size=2)
 mpu.initialize_model_parallel(tensor_model_parallel_size=2, context_parallel_size=1)
