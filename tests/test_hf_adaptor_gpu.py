@@ -138,3 +138,32 @@ def test_argument_errors_match_the_class_surface():
     emb = model.model.p["embed"][ids.to(DEV)]
     b = model(inputs_embeds=emb, use_cache=False).logits
     assert torch.equal(a, b)
+
+
+def test_from_pretrained_reads_a_checkpoint_directory(tmp_path):
+    """`AutoModelForCausalLM.from_pretrained(model_path, trust_remote_code=True, device_map="auto", torch_dtype=torch.bfloat16,
+    attn_implementation="flash_attention_2")` of R/tools/inference_long_vita.py:811-817 on a `*_HF`-layout directory (config.json,
+    generation_config.json, sharded safetensors + index): the same logits, bit for bit, as `from_state_dict` on the tensors it was written from."""
+    import json
+    from safetensors.torch import save_file
+    from long_vita_amd import hf_adaptor
+    sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+    from oracle import make_golden as mg
+    config, sd, ids, images, idx, lc, vc = mg.hf_long_vita_case()
+    names = sorted(sd)
+    half = len(names) // 2
+    shards = {"model-00001-of-00002.safetensors": names[:half], "model-00002-of-00002.safetensors": names[half:]}
+    for fn, keys in shards.items():
+        save_file({k: sd[k].contiguous() for k in keys}, str(tmp_path / fn))
+    json.dump({"metadata": {}, "weight_map": {k: fn for fn, keys in shards.items() for k in keys}}, open(tmp_path / "model.safetensors.index.json", "w"))
+    json.dump(config, open(tmp_path / "config.json", "w"))
+    json.dump({"max_new_tokens": 3, "do_sample": False, "eos_token_id": [2, 5]}, open(tmp_path / "generation_config.json", "w"))
+    a = hf_adaptor.LongVITAForCausalLM.from_pretrained(str(tmp_path), trust_remote_code=True, device_map="auto", torch_dtype=torch.bfloat16,
+                                                       attn_implementation="flash_attention_2").eval()
+    b = hf_adaptor.LongVITAForCausalLM.from_state_dict(config, sd, device=DEV)
+    la = a(input_ids=ids, images=images, image_indices=idx, num_logits_to_keep=4, use_cache=False).logits
+    lb = b(input_ids=ids, images=images, image_indices=idx, num_logits_to_keep=4, use_cache=False).logits
+    assert la.shape == (1, 4, lc.vocab) and torch.equal(la, lb)
+    assert a.generation_config.max_new_tokens == 3 and a.generation_config.eos_token_id == [2, 5]
+    gen = a.generate(inputs=ids, images=images, image_indices=idx)
+    assert ids.shape[1] < gen.shape[1] <= ids.shape[1] + 3
