@@ -256,7 +256,8 @@ __global__ __launch_bounds__(256, 1) void attn_bwd_dq64_kernel(BwdArgs p) {
         sb[par ^ 1][qb] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fr[ds & 3], qf[qb][ds], sb[par ^ 1][qb], 0, 0, 0);
       }
       if (fill) part2_pair(par, s);
-      if (dma_t && s >= 1 && s <= 8) dma_kv_piece(*dma_t, dma_slot, s - 1);
+      if (DQ64_DMA_SPREAD == 2) { if (dma_t && (s & 1) == 1) dma_kv_piece(*dma_t, dma_slot, s >> 1); }      // every other slot, 1 .. 15 (A / B)
+      else if (dma_t && s >= 1 && s <= 8) dma_kv_piece(*dma_t, dma_slot, s - 1);
       __builtin_amdgcn_sched_barrier(0);
     }
   };
