@@ -97,7 +97,7 @@ struct TileIt {
 template <int NSLOT, bool PACKED, bool LTILE = true>
 __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
   constexpr int LDS_V = NSLOT * TILEB;
-  constexpr bool DMA_SPREAD = VITA_ATTN64_DMA_SPREAD != 0 && NSLOT == 2;      // (0: the r02 - r04 burst at the top of a tile, for A / B builds)
+  constexpr bool DMA_SPREAD = VITA_ATTN64_DMA_SPREAD != 0;      // (0: the r02 - r04 burst at the top of a tile / pair, for A / B builds)
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const unsigned lds0 = (unsigned)(uintptr_t)(lds_char*)smem;
   const int tid = threadIdx.x, lane = tid & 63, hi = lane >> 5, l31 = lane & 31;
@@ -329,6 +329,10 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
   vita_rsrc_t rk_next = vita_make_rsrc_uniform(kbase), rv_next = rk_next;     // descriptors of the tiles being fetched (spread issue)
   bool spread_k = false, spread_v = false;
   int spread_k_slot = 0, spread_v_slot = 0;
+  // ring of four (r06): a pair of tiles fetches FOUR tiles; the second two (K(c+4), V(c+3)) go out behind the MFMAs of the pair's first P V phase
+  vita_rsrc_t rk_next2 = rk_next, rv_next2 = rk_next;
+  bool spread2_k = false, spread2_v = false;
+  int spread2_k_slot = 0, spread2_v_slot = 0;
   auto qk_phase = [&](int dst, unsigned kslot, bool fill, int par) __attribute__((always_inline)) {
     bf16x8 kr[4];
     kr[0] = k_frag(kslot, 0); kr[1] = k_frag(kslot, 1);
@@ -372,6 +376,11 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
       const u32x4 pw = {pk[par][qb][t][0], pk[par][qb][t][1], pk[par][qb][t][2], pk[par][qb][t][3]};
       const bf16x8 pf = __builtin_bit_cast(bf16x8, pw);
       asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(o[qb][db]) : "v"(vr[i & 3]), "v"(pf));
+      if (DMA_SPREAD && NSLOT == 4 && has_next && (s & 3) == 1) {   // ring of four: pieces of K(c+4) behind MFMAs 1, 5, 9, 13; of V(c+3) behind 17 .. 29
+        const int q = s >> 2;
+        if (q < 4) { if (spread2_k) dma_piece(rk_next2, dk_off, lds_kw, spread2_k_slot, q); }
+        else if (spread2_v) dma_piece(rv_next2, dv_off, lds_vw, spread2_v_slot, q - 4);
+      }
       if (has_next) {
 #pragma unroll
         for (int u = MAP2.first[s]; u < MAP2.first[s + 1]; ++u) {
@@ -516,11 +525,23 @@ __global__ __launch_bounds__(256, 1) void flash_fwd64_kernel(AttnArgs p) {
     };
     // pair with c = 4i + 2 b: fetches K(c+3), K(c+4) -> slots (3 + 2b) & 3, (4 + 2b) & 3 and V(c+2), V(c+3) -> slots (2 + 2b) & 3, (3 + 2b) & 3
     auto pair = [&](int b, bool k4) __attribute__((always_inline)) {
-      dma_k(it_k, (3 + 2 * b) & 3); advance(it_k);
-      if (k4) { dma_k(it_k, (4 + 2 * b) & 3); advance(it_k); }
-      dma_v(it_v, (2 + 2 * b) & 3); advance(it_v);
-      dma_v(it_v, (3 + 2 * b) & 3); advance(it_v);
+      if (DMA_SPREAD) {
+        // r06: K(c+3), V(c+2) — what the NEXT pair's first call reads — go out one piece per four MFMAs inside this pair's first S phase, K(c+4),
+        // V(c+3) inside its first P V phase; the second call issues nothing, so every piece has at least two phases to land before the
+        // wait + barrier at the pair's end.  (r03's ring of four issued all 16 pieces in one burst at the top of the pair and was 6.8 % slower.)
+        rk_next = vita_make_rsrc_uniform(it_k.kp); spread_k = true; spread_k_slot = (3 + 2 * b) & 3; advance(it_k);
+        spread2_k = k4;
+        if (k4) { rk_next2 = vita_make_rsrc_uniform(it_k.kp); spread2_k_slot = (4 + 2 * b) & 3; advance(it_k); }
+        rv_next = vita_make_rsrc_uniform(it_v.vp); spread_v = true; spread_v_slot = (2 + 2 * b) & 3; advance(it_v);
+        rv_next2 = vita_make_rsrc_uniform(it_v.vp); spread2_v = true; spread2_v_slot = (3 + 2 * b) & 3; advance(it_v);
+      } else {
+        dma_k(it_k, (3 + 2 * b) & 3); advance(it_k);
+        if (k4) { dma_k(it_k, (4 + 2 * b) & 3); advance(it_k); }
+        dma_v(it_v, (2 + 2 * b) & 3); advance(it_v);
+        dma_v(it_v, (3 + 2 * b) & 3); advance(it_v);
+      }
       call(0, (1 + 2 * b) & 3, (2 * b) & 3);
+      spread_k = spread_v = spread2_k = spread2_v = false;
       call(1, (2 + 2 * b) & 3, (1 + 2 * b) & 3);
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
       __syncthreads();

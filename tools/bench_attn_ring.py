@@ -1,6 +1,6 @@
 """A/B of flash_fwd64_kernel's ring depth in one process: NSLOT = 2 (shipped: one barrier per 64-key tile) vs
 NSLOT = 4 (VITA_ATTN64_RING=4: four-slot K / V rings, a barrier every TWO tiles), interleaved rounds on random data, outputs compared
-bit for bit.  Prints JSON lines; writes gpurun_out/r03_attn_ring.jsonl."""
+bit for bit.  Prints JSON lines; writes gpurun_out/r06_attn_ring.jsonl."""
 import json, os, sys
 os.environ.setdefault("VITA_DEBUG", "1")
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
@@ -9,7 +9,7 @@ import torch
 from long_vita_amd import ops
 DEV = "cuda"
 os.makedirs(os.path.join(ROOT, "gpurun_out"), exist_ok=True)
-LOG = open(os.path.join(ROOT, "gpurun_out", "r03_attn_ring.jsonl"), "a")
+LOG = open(os.path.join(ROOT, "gpurun_out", "r06_attn_ring.jsonl"), "a")
 Hq, Hkv, D = 40, 8, 128
 # generalised: --var NAME A B switches any developer variable between two values (default: the ring depth 2 vs 4)
 VAR, VA, VB = "VITA_ATTN64_RING", "2", "4"

@@ -14,6 +14,7 @@ def main(root):
             elif "flash_fwd" in k: k = "flash_fwd<" + ("128" if "128" in k else "64") + ">"
             elif "gemm_bf16" in k: k = "gemm_bf16<" + k.split("<")[1].split(">")[0] + ">"
             elif "gemm_w4" in k: k = "gemm_w4<" + k.split("<")[1].split(">")[0] + ">"
+            elif "Cijk" in k: k = "vendor " + k[:48]
             else: continue
             agg[k][row["Counter_Name"]].append(float(row["Counter_Value"]))
     for k in sorted(agg):
