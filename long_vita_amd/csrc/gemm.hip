@@ -608,6 +608,9 @@ constexpr int pieces_before(int variant, int slot) {
 #ifndef VITA_GEMM_RD_STEP
 #define VITA_GEMM_RD_STEP 2        // two-barrier schedule: 1 = the 16 second-half reads in consecutive slots, barrier 1 at slot 20, pieces from slot 22
 #endif
+#ifndef VITA_GEMM_WAVE_STAGGER
+#define VITA_GEMM_WAVE_STAGGER 0   // 1: the operand-split loop in four copies, wave w's LDS-DMA pieces w slots behind the table (same-box A / B)
+#endif
 #ifndef VITA_GEMM_SWIGLU_STEP5
 #define VITA_GEMM_SWIGLU_STEP5 1    // 1: fc1 + SwiGLU keeps the two-barrier schedule, with one piece every 5 slots (the variant it measured best with)
 #endif
@@ -818,7 +821,8 @@ __device__ __forceinline__ void gemm_w4_tile(const GemmArgs& p, const int bid_) 
   constexpr bool SPLIT_SCHED = VITA_GEMM_SCHED >= 1 && OPM == 0 && !SPLITK && !(VITA_GEMM_SWIGLU_STEP5 && EPI == VITA_EPI_SWIGLU);
   constexpr int SPLIT_VARIANT = VITA_GEMM_SCHED >= 2 ? 1 : 0;
   constexpr bool PACED_READS = VITA_GEMM_SCHED >= 3;       // 3: fragment reads every other slot (the two-barrier schedule's pace) instead of the vendor's positions
-  auto tile_split = [&](const bool DMA, const bool NEXT, unsigned cur, unsigned nxt) __attribute__((always_inline)) {
+  auto tile_split = [&](auto W_, const bool DMA, const bool NEXT, unsigned cur, unsigned nxt) __attribute__((always_inline)) {
+    constexpr int WOFF = decltype(W_)::value;      // VITA_GEMM_WAVE_STAGGER: this wave's pieces go out WOFF slots behind the table's positions
     const StageBases bcur = bases_of(cur), bnxt = bases_of(NEXT ? nxt : cur);
     // (the slot number is a template constant — std::integral_constant through a generic lambda — so that every fragment / piece index below is a
     // constant expression: the "i" operands of the fragment reads need that, and a run-time `s` left them to the unroller's mercy)
@@ -840,12 +844,12 @@ __device__ __forceinline__ void gemm_w4_tile(const GemmArgs& p, const int bid_) 
         if (DMA) asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
       }
       if (DMA) {
-        constexpr int pj = w4::piece_at(SPLIT_VARIANT, s);
+        constexpr int pj = w4::piece_at(SPLIT_VARIANT, s - WOFF);
         if constexpr (pj >= 0) dma_piece(cur, pj);
       }
       if constexpr (s == 92) {
         if (NEXT) {
-          if (DMA) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(w4::pieces_before(SPLIT_VARIANT, 92)) : "memory");
+          if (DMA) asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"i"(w4::pieces_before(SPLIT_VARIANT, 93 - WOFF)) : "memory");   // (a piece AT slot 92 is issued in front of this wait)
           else asm volatile("s_waitcnt vmcnt(0)\n\ts_barrier" ::: "memory");
         }
       }
@@ -922,18 +926,31 @@ __device__ __forceinline__ void gemm_w4_tile(const GemmArgs& p, const int bid_) 
     }
   };
 
-  auto tile = [&](const bool DMA, const bool NEXT, unsigned cur, unsigned nxt) __attribute__((always_inline)) {
-    if (SPLIT_SCHED) tile_split(DMA, NEXT, cur, nxt);
-    else tile_two_barriers(DMA, NEXT, cur, nxt);
+  // the K loop; W_ = std::integral_constant<int, slots this wave's LDS-DMA pieces are shifted by>
+  auto k_loop = [&](auto W_) __attribute__((always_inline)) {
+    auto tile = [&](const bool DMA, const bool NEXT, unsigned cur, unsigned nxt) __attribute__((always_inline)) {
+      if (SPLIT_SCHED) tile_split(W_, DMA, NEXT, cur, nxt);
+      else tile_two_barriers(DMA, NEXT, cur, nxt);
+    };
+    int t = 0;
+    for (; t + 2 < nk; ++t) tile(true, true, lds0 + (t & 1) * STG, lds0 + ((t + 1) & 1) * STG);
+    if (t + 1 < nk) {
+      tile(false, true, lds0 + (t & 1) * STG, lds0 + ((t + 1) & 1) * STG);
+      ++t;
+    }
+    tile(false, false, lds0 + (t & 1) * STG, 0u);
   };
-
-  int t = 0;
-  for (; t + 2 < nk; ++t) tile(true, true, lds0 + (t & 1) * STG, lds0 + ((t + 1) & 1) * STG);
-  if (t + 1 < nk) {
-    tile(false, true, lds0 + (t & 1) * STG, lds0 + ((t + 1) & 1) * STG);
-    ++t;
+  if (VITA_GEMM_WAVE_STAGGER && SPLIT_SCHED) {
+    // r06 A / B: the four waves of a workgroup issue their pieces in DIFFERENT slots (wave w one slot behind wave w - 1), so that the texture
+    // addresser does not get four 1-KiB requests in the same cycle.  Four copies of the loop behind one branch on the wave number (r05's attempt
+    // branched per piece and lost 19 % to the branches); barriers and waits are at the same slots in all four.
+    if (wave == 0) k_loop(std::integral_constant<int, 0>{});
+    else if (wave == 1) k_loop(std::integral_constant<int, 1>{});
+    else if (wave == 2) k_loop(std::integral_constant<int, 2>{});
+    else k_loop(std::integral_constant<int, 3>{});
+  } else {
+    k_loop(std::integral_constant<int, 0>{});
   }
-  tile(false, false, lds0 + (t & 1) * STG, 0u);
 
   // ---- epilogue.  The inline-asm MFMAs are invisible to the compiler's hazard tracking: one wait for the matrix pipe, then every row
   // block's accumulators pass through an (empty) asm statement of their own right before they are read — asm volatile statements
