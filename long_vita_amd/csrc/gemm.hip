@@ -578,6 +578,17 @@ constexpr int pieces_before(int variant, int slot) {
   for (int j = 0; j < 16; ++j) n += PIECE_SLOT[variant][j] < slot;
   return n;
 }
+// what the schedule relies on: A pieces (0 .. 7) behind barrier 1 (slot 21), W pieces (8 .. 15) behind barrier 2 (slot 51), increasing slots (the
+// vmcnt of barrier 3 counts the pieces in front of it), and room for the three slots a staggered wave adds
+constexpr bool piece_table_ok(int variant) {
+  for (int j = 0; j < 16; ++j) {
+    const int sl = PIECE_SLOT[variant][j];
+    if (sl <= (j < 8 ? 21 : 51) || sl + 3 > 127) return false;
+    if (j > 0 && sl <= PIECE_SLOT[variant][j - 1]) return false;
+  }
+  return true;
+}
+static_assert(piece_table_ok(0) && piece_table_ok(1), "LDS-DMA piece slots of the operand-split schedule");
 }
 
 // INTERIOR = every tile of the problem is whole (M % 256 == 0, N % tile width == 0): chosen at launch, so that each instantiation has
