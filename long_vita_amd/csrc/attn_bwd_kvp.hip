@@ -57,6 +57,9 @@ constexpr int PF_NONE = 0, PF_FRAG = 1, PF_TR = 2;
 #define KVP_ABL 0
 #endif
 constexpr int ABL = KVP_ABL;
+#ifndef KVP_HAND_SPREAD
+#define KVP_HAND_SPREAD 1          // r06: three of the four hand-over stores of P behind MFMAs of the S group (0: all four in front of the pair barrier)
+#endif
 #ifndef KVP_DMA_SPREAD
 #define KVP_DMA_SPREAD 1
 #endif
@@ -266,6 +269,14 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
         *(lds_u32x4*)(uintptr_t)(xaddr + par * 8192 + (kb * 2 + t2) * 1024) = w;
       }
   };
+  // r06 (KVP_HAND_SPREAD): one of the four 16-byte stores of a hand-over.  Issued back to back in front of the pair barrier, the four stores of
+  // the two A waves fill the LDS data FIFO (SQ_LDS_DATA_FIFO_FULL 2.4e7 per 16K launch: a ds_write_b128 moves 5 source dwords at 2 cycles each)
+  // and the wave stalls with the matrix pipe draining; three of them now go out behind MFMAs of the S group, as soon as their pairs are packed
+  auto hand_over_part = [&](int par, int i) __attribute__((always_inline)) {
+    const int kb = i >> 1, t2 = i & 1;
+    const u32x4 w = {pk[par][kb][t2][0], pk[par][kb][t2][1], pk[par][kb][t2][2], pk[par][kb][t2][3]};
+    *(lds_u32x4*)(uintptr_t)(xaddr + par * 8192 + (kb * 2 + t2) * 1024) = w;
+  };
   auto take_over = [&](int par) __attribute__((always_inline)) {                 // B: the pair's packed P of buffer `par`
 #pragma unroll
     for (int kb = 0; kb < 2; ++kb)
@@ -305,7 +316,7 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
     if (pf == PF_TR) { fr_pre[0] = tr_frag(pf_img, 2 * pf_qh, 0); fr_pre[1] = tr_frag(pf_img, 2 * pf_qh, 1); }
   };
   auto x_group = [&](int par, unsigned img, int qh_n, bool fill, bool use_pre, int pf, unsigned pf_img, int pf_qh, bool pf_stat,
-                     unsigned pf_st, int pf_st_qh, const bool dma = false) __attribute__((always_inline)) {
+                     unsigned pf_st, int pf_st_qh, const bool dma = false, const bool hand = false) __attribute__((always_inline)) {
     bf16x8 fr[4];
     if (use_pre) { fr[0] = fr_pre[0]; fr[1] = fr_pre[1]; }
     else { fr[0] = frag(img, 0, qh_n); fr[1] = frag(img, 1, qh_n); }
@@ -334,10 +345,19 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
       if (!ROLE_B && fill) {                                  // A: elements 16 .. 31 of S(u + 1), one exp2 per slot; a pair is packed a slot late
         exp_one(par, 16 + s);
         if (s >= 2 && (s & 1) == 0) pack_pair(par, 8 + ((s - 2) >> 1));
+        // pairs 0 .. 7 were packed under the previous group, pairs 8 .. 11 by slot 8
+        if (KVP_HAND_SPREAD && hand) {
+          if (s == 1) hand_over_part(par, 0);
+          if (s == 5) hand_over_part(par, 1);
+          if (s == 11) hand_over_part(par, 2);
+        }
       }
       __builtin_amdgcn_sched_barrier(0);
     }
-    if (!ROLE_B && fill) pack_pair(par, 15);
+    if (!ROLE_B && fill) {
+      pack_pair(par, 15);
+      if (KVP_HAND_SPREAD && hand) hand_over_part(par, 3);
+    }
   };
   // 16 slots: gradient^T += X^T(half qh of the image at `img`, transposed reads) packed(par)   (A: dV^T += dO^T P, B: dK^T += Q^T dS);
   // A with FILL: exp2 of pairs 0 .. 7 of buffer par ^ 1 (even slots) and their bf16 pack (odd slots: an exp2 result is never consumed
@@ -420,14 +440,14 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
       g_group(0, g_cur, 0, true, true, has1 ? PF_FRAG : PF_TR, has1 ? x_nxt : g_cur, has1 ? 0 : 1, false, 0, 0, has3);   // dV^T += dO^T P(u) || exp2 0 .. 7 of S(u + 1)
       step_cursor();
       if (has1) {
-        x_group(1, x_nxt, 0, true, true, PF_TR, g_cur, 1, true, st_nxt, 0);                      // S(u + 2) -> buffers 0  ||  pairs 8 .. 15 of S(u + 1)
+        x_group(1, x_nxt, 0, true, true, PF_TR, g_cur, 1, true, st_nxt, 0, false, true);         // S(u + 2) -> buffers 0  ||  pairs 8 .. 15 of S(u + 1)  [+ P(u + 1) -> the partner]
       } else {
 #pragma unroll
         for (int e = 8; e < 16; ++e) exp_pair(1, e);
 #pragma unroll
         for (int e = 8; e < 16; ++e) pack_pair(1, e);
       }
-      hand_over(1);                                      // P(u + 1) -> the partner, before the barrier that ends this trip
+      if (!(KVP_HAND_SPREAD && has1)) hand_over(1);      // P(u + 1) -> the partner, before the barrier that ends this trip
       if (has1 && m_nx1 >= 0) mask_half(0, m_nx1);                                       // wave-uniform, diagonal tiles only
     }
     if (ABL != 1) pair_barrier();
@@ -447,8 +467,8 @@ __device__ __forceinline__ void kvp_body(const BwdArgs& p, const unsigned lds0, 
       if (has1) stat_finish();                           // lse of (tile t + 1, rows 0 ..)
       g_group(1, g_cur, 1, has1, true, has1 ? PF_FRAG : PF_NONE, x_nxt, 1, false, 0, 0);
       if (has1) {
-        x_group(0, x_nxt, 1, true, true, PF_TR, g_nxt, 0, true, st_nxt, 1);                      // S(u + 2) -> buffers 1; next: trip 0 of tile t + 1
-        hand_over(0);
+        x_group(0, x_nxt, 1, true, true, PF_TR, g_nxt, 0, true, st_nxt, 1, false, true);         // S(u + 2) -> buffers 1; next: trip 0 of tile t + 1
+        if (!KVP_HAND_SPREAD) hand_over(0);
         if (m_nx1 >= 0) mask_half(1, m_nx1 + 32);
       }
     }
