@@ -619,6 +619,9 @@ static_assert(piece_table_ok(0) && piece_table_ok(1), "LDS-DMA piece slots of th
 #ifndef VITA_GEMM_RD_STEP
 #define VITA_GEMM_RD_STEP 2        // two-barrier schedule: 1 = the 16 second-half reads in consecutive slots, barrier 1 at slot 20, pieces from slot 22
 #endif
+#ifndef VITA_GEMM_SPLIT_TN
+#define VITA_GEMM_SPLIT_TN 1       // the operand-split schedule in the TN mode (weight gradients, also split-K) too: -1 to -2.4 % same box; NN (input gradients) measured +0.3 to +1 % with it and keeps two barriers
+#endif
 #ifndef VITA_GEMM_WAVE_STAGGER
 #define VITA_GEMM_WAVE_STAGGER 0   // 1: the operand-split loop in four copies, wave w's LDS-DMA pieces w slots behind the table (same-box A / B)
 #endif
@@ -829,7 +832,7 @@ __device__ __forceinline__ void gemm_w4_tile(const GemmArgs& p, const int bid_) 
   // vmcnt(13) — the 13 pieces of tile t + 2 issued by then stay in flight — and tile t + 1's first-half fragments are read in slots 93 .. 123.
   // The pieces go out in three bursts of five (every third slot) with 18 .. 21 slots of nothing between them, over slots 22 .. 124: the slot
   // positions are the ones the vendor library's MT256x256x64 kernel uses (read off its disassembly: profiles/r06_gemm_schedules.txt).
-  constexpr bool SPLIT_SCHED = VITA_GEMM_SCHED >= 1 && OPM == 0 && !SPLITK && !(VITA_GEMM_SWIGLU_STEP5 && EPI == VITA_EPI_SWIGLU);
+  constexpr bool SPLIT_SCHED = VITA_GEMM_SCHED >= 1 && ((OPM == 0 && !SPLITK) || (VITA_GEMM_SPLIT_TN && OPM == 1)) && !(VITA_GEMM_SWIGLU_STEP5 && EPI == VITA_EPI_SWIGLU);
   constexpr int SPLIT_VARIANT = VITA_GEMM_SCHED >= 2 ? 1 : 0;
   constexpr bool PACED_READS = VITA_GEMM_SCHED >= 3;       // 3: fragment reads every other slot (the two-barrier schedule's pace) instead of the vendor's positions
   auto tile_split = [&](auto W_, const bool DMA, const bool NEXT, unsigned cur, unsigned nxt) __attribute__((always_inline)) {
@@ -886,9 +889,13 @@ __device__ __forceinline__ void gemm_w4_tile(const GemmArgs& p, const int bid_) 
     // there is a DMA, and explicitly otherwise
     static_for<0, 52>(slot);
     if (!DMA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    frag_commit(1);                                     // (contraction-major operands: assemble the second-half fragments behind their wait)
     static_for<52, 128>(slot);
     if (DMA) next_tile();
-    if (NEXT) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+    if (NEXT) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+      frag_commit(0);
+    }
   };
 
   // one K tile: DMA = tile t+2 exists (goes into `cur`), NEXT = tile t+1 exists (its first-half fragments come from `nxt`)
